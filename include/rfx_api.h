@@ -1,0 +1,164 @@
+/*
+ * rfx_api.h -- C ABI of librfx.so: the MI355X (gfx950 / CDNA4) kernels behind the RANSAC-Flow
+ * coarse-to-fine alignment hot path.
+ *
+ * The reference (XiSHEN0220/RANSAC-Flow) is pure Python on PyTorch: it has no FFI of its own, its
+ * "native" layer is the set of ATen/cuDNN/LAPACK ops its hot path issues.
+ * Each entry point below replaces one of those op groups; the reference call site it stands in for
+ * is cited as file:line relative to the reference root.  The Python drop-in modules
+ * (ransac-flow_amd/dropin/{outil,model,coarseAlignFeatMatch}.py) keep the reference's Python
+ * surface and bind these symbols through ctypes (see INTEGRATION.md for the stub a maintainer adds).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in
+ *     _host; all tensors are dense, row-major, float32 ("f32") unless stated; NCHW images.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), allocates nothing, and never throws: the return value is 0 on success, a negative
+ *     RFX_E_* code for a bad argument, or a positive hipError_t from the launch.
+ *   - workspaces are caller-owned; rfx_*_ws_bytes() reports the size needed.
+ */
+#ifndef RFX_API_H
+#define RFX_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFX_OK 0
+#define RFX_E_ARG (-1)     /* null pointer / non-positive size / unsupported geometry */
+#define RFX_E_LIMIT (-2)   /* size above a compiled-in limit */
+
+#define RFX_ACT_NONE 0
+#define RFX_ACT_RELU 1
+#define RFX_ACT_SIGMOID 2
+
+/* library / build identification; returns a static string "rfx <version> gfx950". */
+const char* rfx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family (ResNet-50 conv1..layer3 trunk: model/resnet50.py:68-104,112-169 as used by
+ * quick_start/coarseAlignFeatMatch.py:34-52,106,124; FeatureExtractor model/model.py:59-125;
+ * NetFlowCoarse / NetMatchability convs model/model.py:210-226,289-305).
+ *
+ * rfx_conv2d_f32: implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32), NCHW,
+ * groups=1, dilation=1, with a fused per-output-channel affine (eval-mode BatchNorm folded to
+ * scale/shift), optional residual add and activation:
+ *     out[n,m,oh,ow] = act( scale[m] * sum_{c,kh,kw} in[n,c,oh*s-p+kh,ow*s-p+kw] * w[m,c,kh,kw]
+ *                           + shift[m] + residual[n,m,oh,ow] )
+ * wT    : packed weights [Kpad][Mpad], wT[k*Mpad+m] = w[m,c,kh,kw] with k=(c*KH+kh)*KW+kw,
+ *         Kpad = roundup(Cin*KH*KW,16), Mpad = roundup(Cout,128), zero padded.
+ * ktab  : int32[Kpad], (c<<8)|(kh<<4)|kw for k < K and -1 for the padding rows.
+ * scale/shift may be NULL (treated as 1 / 0); residual may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                   const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                   int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream);
+
+/* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;
+ * model/model.py:71: k=2,s=1,p=0).  Hout = (Hin+2p-k)/s+1. */
+int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int k, int stride,
+                      int pad, void* stream);
+
+/* Anti-aliased down-sampling (model/downsample.py:12-46, filt_size=3): reflect-pad 1, depthwise
+ * [1 2 1]x[1 2 1]/16, stride.  Hout = (Hin-1)/stride+1. */
+int rfx_blurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream);
+
+/* F.normalize(x, p=2, dim=1, eps=1e-12) on NCHW (quick_start/coarseAlignFeatMatch.py:106,124;
+ * quick_start/align2images.py:87-88).  `in` is dense; element (n,c,p) of the result goes to
+ * out[n*out_batch_stride + c*out_chan_stride + p] (0 = dense defaults C*HW / HW), which lets the coarse
+ * aligner write every pyramid scale straight into the concatenated (C, nA) match matrix
+ * (quick_start/coarseAlignFeatMatch.py:108,115).  In-place allowed for the dense case. */
+int rfx_l2norm_nchw_f32(const float* in, float* out, int N, int C, int HW, long long out_batch_stride,
+                        long long out_chan_stride, void* stream);
+
+/* NetFlowCoarse tail (model/model.py:228-233): softmax over the K*K logits, expectation of the tap
+ * offsets; flow[n,0] = sum_q p_q * gx_q / cols * 2, flow[n,1] = sum_q p_q * gy_q / rows * 2 with
+ * q = i*K+j, gx_q = j-K/2, gy_q = i-K/2.  logits (N,K*K,rows,cols) -> flow (N,2,rows,cols). */
+int rfx_flow_head_f32(const float* logits, float* flow, int N, int K, int rows, int cols, void* stream);
+
+/* Bilinear resize of NCHW maps: F.interpolate(mode='bilinear', align_corners=False)
+ * (quick_start/align2images.py:92, evaluation/evalHpatch/evaluation.py:37-40) or
+ * F.upsample_bilinear (= align_corners=True; model/model.py:234,309). */
+int rfx_resize_bilinear_f32(const float* in, float* out, int NC, int Hin, int Win, int Hout, int Wout,
+                            int align_corners, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7x7 local correlation volume (model/model.py:129-160, CorrNeigh.do_forward):
+ *     out[n, i*K+j, r, c] = sum_ch x[n,ch,r,c] * y[n,ch,r+i-K/2,c+j-K/2]   (zero outside y)
+ * K must be 7 (the only size the reference instantiates: quick_start/align2images.py:38).
+ * C must be a multiple of 8.
+ * ------------------------------------------------------------------------------------------ */
+int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Warping (kornia HomographyWarper.warp_grid: quick_start/align2images.py:61,65;
+ * F.grid_sample: quick_start/align2images.py:66,95,97, evaluation/evalHpatch/evaluation.py:25,45).
+ * ------------------------------------------------------------------------------------------ */
+/* grid[b,y,x,:] = proj( Hm[b] * (lin(x,w), lin(y,h), 1) ),  lin(i,n) = -1 + 2 i/(n-1). */
+int rfx_warp_grid_f32(const float* Hm, float* grid, int B, int h, int w, void* stream);
+
+/* bilinear, zeros padding; input (N,C,Hi,Wi), grid (N,Ho,Wo,2) -> out (N,C,Ho,Wo). */
+int rfx_grid_sample_f32(const float* in, const float* grid, float* out, int N, int C, int Hi, int Wi,
+                        int Ho, int Wo, int align_corners, void* stream);
+
+/* Fused fine-flow composition (quick_start/align2images.py:92-95;
+ * evaluation/evalHpatch/evaluation.py:40-45,51): up-sample flowDown (N,2,hd,wd) to (H,W) with
+ * align_corners=False, add the linspace identity grid, optionally clamp to [-1,1], sample the coarse
+ * grid (N,H,W,2) there (bilinear, zeros, align_corners=False) -> flow12 (N,H,W,2).  If inb != NULL it
+ * receives the in-bounds mask (N,H,W) = (-1<=fx<=1)&(-1<=fy<=1) as 0/1 floats; if flowUp != NULL it
+ * receives the (clamped) sampling grid (N,H,W,2). */
+int rfx_compose_flow_f32(const float* flowDown, const float* coarseGrid, float* flow12, float* inb,
+                         float* flowUp, int N, int hd, int wd, int H, int W, int clamp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * All-pairs correlation + mutual nearest neighbours (utils/outil.py:32-45, mutualMatching).
+ * featA: (C, nA) and featB: (C, nB), column = one cell ("K-major": element (k,i) at k*ld+i).
+ * maskB (optional, nB floats, 0/1) multiplies featB's columns (quick_start/coarseAlignFeatMatch.py:143).
+ * Outputs: idx1/idx2 (int64, capacity min(nA,nB)) in ascending idx1 order, count (int32[1]).
+ * The nA x nB score matrix is never written to memory.
+ * ws: rfx_mutual_nn_ws_bytes(nA, nB) bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t rfx_mutual_nn_ws_bytes(int nA, int nB);
+int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
+                      const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RANSAC over 4-point DLT homographies (utils/outil.py:68-164).
+ * match1/match2: (n,3) source / target points (x,y,1); samples: (N,4) int64 indices into them.
+ * ------------------------------------------------------------------------------------------ */
+/* outil.Homography (utils/outil.py:68-87): per hypothesis the unit-norm null vector of the 8x9 DLT
+ * system in float64 with LAPACK dgesdd's sign (dgebd2 Householder sweep), cast to float32.
+ * X,Y: (N,4,3) source / target samples -> Hout (N,3,3). */
+int rfx_dlt4_homography(const float* X, const float* Y, int N, float* Hout, void* stream);
+
+/* outil.Prediction (utils/outil.py:97-100): reprojection error ||X[:, :2] - proj(Y H^T)||_2 for every
+ * (hypothesis, match) pair, float32 in the reference's operation order.  match1/match2 (n,3), Hs (N,3,3)
+ * -> err (N,n).  N <= 65535. */
+int rfx_prediction_f32(const float* match1, const float* match2, int n, const float* Hs, int N, float* err,
+                       void* stream);
+
+/* outil.ScoreRANSAC (utils/outil.py:102-113): H per hypothesis + inlier count * (det(H) > 1e-6).
+ * Hout (N,3,3) f32, counts (N) int64.  ws: rfx_ransac_ws_bytes(n, N). */
+int rfx_score_hypotheses(const float* match1, const float* match2, int n, const int64_t* samples, int N,
+                         float tol, float* Hout, int64_t* counts, void* ws, void* stream);
+
+/* outil.RANSAC (utils/outil.py:117-164) given the index draw: duplicate filter (:122-133), chunks of
+ * 100 with the zero-chunk abort (:140-146), tail chunk (:153-160), first-maximum selection, final
+ * inlier mask (:162-163).
+ * result (int32[4]): [0] status 0 = ok, 1 = aborted (reference returns (None,0,[],[])), 2 = no
+ * hypothesis beat 0 (reference raises TypeError); [1] best inlier count; [2] index of the winning
+ * hypothesis in `samples`; [3] number of hypotheses that survived the duplicate filter.
+ * bestH (9 f32), inlier (n uint8).  ws: rfx_ransac_ws_bytes(n, N). */
+size_t rfx_ransac_ws_bytes(int n, int N);
+int rfx_ransac_h4(const float* match1, const float* match2, int n, const int64_t* samples, int N,
+                  float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_API_H */

@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE ONLY -- loads the *real* reference (XiSHEN0220/RANSAC-Flow) on CPU.
+
+This module imports the reference's own Python modules from ``/root/reference`` under three
+stubs so that they run on a GPU-less host:
+
+1. ``Tensor.cuda`` / ``Module.cuda`` -> identity, ``torch.cuda.FloatTensor = torch.FloatTensor``
+   (the reference hard-codes ``.cuda()``: utils/outil.py:86, quick_start/coarseAlignFeatMatch.py:51,100,106).
+2. a fake ``torchvision`` (``models.resnet50`` -> the reference's own model/resnet50.py:185,
+   ``transforms.{ToTensor,Normalize,Compose,ToPILImage}``).
+3. a fake ``kornia.geometry.HomographyWarper`` whose ``warp_grid`` restates kornia 0.1.4's
+   documented behaviour (requirements.txt:59; kornia itself is not in /root/reference).
+
+It exists ONLY in the authoring container (``/root/reference`` is absent on the GPU box): it is
+used by ``tests/golden/make_golden.py`` to generate the committed golden vectors and by the
+``-m "not gpu"`` tests that pin ``oracle/restate.py`` against the real reference.  Nothing in the
+product path (``ransac-flow_amd/``) may import it.
+"""
+import os
+import sys
+import types
+import contextlib
+import io
+
+import numpy as np
+import torch
+
+REF_ROOT = os.environ.get("RFX_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "utils"))
+
+
+_loaded = {}
+
+
+def _install_stubs():
+    # 1. .cuda() -> identity
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+
+    # 2. torchvision shim
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    def _resnet50(pretrained=False, **kw):
+        sys.path.insert(0, os.path.join(REF_ROOT, "model"))
+        import importlib
+        r50 = importlib.import_module("resnet50")
+        return r50.resnet50()
+
+    tvm.resnet50 = _resnet50
+
+    class ToTensor:
+        def __call__(self, pic):
+            arr = np.asarray(pic, dtype=np.uint8)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            t = torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous()
+            return t.float().div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+            self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage:
+        def __call__(self, t):
+            import PIL.Image as Image
+            arr = (t.detach().cpu().clamp(0, 1) * 255).byte().permute(1, 2, 0).numpy()
+            return Image.fromarray(arr)
+
+    tvt.ToTensor, tvt.Normalize, tvt.Compose, tvt.ToPILImage = ToTensor, Normalize, Compose, ToPILImage
+    tv.models, tv.transforms = tvm, tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    sys.modules["torchvision.transforms"] = tvt
+
+    # 3. kornia shim (kornia==0.1.4.post2 HomographyWarper)
+    ko = types.ModuleType("kornia")
+    kg = types.ModuleType("kornia.geometry")
+
+    class HomographyWarper:
+        def __init__(self, height, width):
+            self.height, self.width = height, width
+            xs = torch.linspace(-1, 1, width)
+            ys = torch.linspace(-1, 1, height)
+            gx = xs.view(1, 1, width).expand(1, height, width)
+            gy = ys.view(1, height, 1).expand(1, height, width)
+            self.grid = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1)  # 1,h,w,3
+
+        def warp_grid(self, H):
+            # (x', y', z') = H (x, y, 1); return (x'/z', y'/z')
+            B = H.shape[0]
+            pts = self.grid.expand(B, -1, -1, -1).reshape(B, -1, 3)
+            out = torch.bmm(pts, H.transpose(1, 2))
+            out = out[..., :2] / out[..., 2:]
+            return out.view(B, self.height, self.width, 2)
+
+    kg.HomographyWarper = HomographyWarper
+    ko.geometry = kg
+    sys.modules["kornia"] = ko
+    sys.modules["kornia.geometry"] = kg
+
+    # eval variants import scipy.misc.imresize (removed from scipy) and segEval
+    import scipy
+    sm = types.ModuleType("scipy.misc")
+    sm.imresize = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("imresize stub"))
+    sys.modules["scipy.misc"] = sm
+    scipy.misc = sm
+    sys.modules.setdefault("segEval", types.ModuleType("segEval"))
+
+
+def load():
+    """Return dict with the reference modules: outil, model, resnet50, CoarseAlignA (quick_start), CoarseAlignB (evalHpatch)."""
+    if _loaded:
+        return _loaded
+    if not available():
+        raise RuntimeError("reference not available at %s" % REF_ROOT)
+    _install_stubs()
+    import importlib.util
+
+    def _imp(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    sys.path.insert(0, os.path.join(REF_ROOT, "model"))
+    sys.path.insert(0, os.path.join(REF_ROOT, "utils"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        outil = _imp("outil", os.path.join(REF_ROOT, "utils", "outil.py"))
+        sys.modules["outil"] = outil
+        downsample = _imp("downsample", os.path.join(REF_ROOT, "model", "downsample.py"))
+        sys.modules["downsample"] = downsample
+        resnet50 = _imp("resnet50", os.path.join(REF_ROOT, "model", "resnet50.py"))
+        sys.modules["resnet50"] = resnet50
+        model = _imp("ref_model", os.path.join(REF_ROOT, "model", "model.py"))
+        cwd = os.getcwd()
+        try:
+            os.chdir(os.path.join(REF_ROOT, "quick_start"))
+            caA = _imp("ref_coarseAlignA", os.path.join(REF_ROOT, "quick_start", "coarseAlignFeatMatch.py"))
+            os.chdir(os.path.join(REF_ROOT, "evaluation", "evalHpatch"))
+            # variant B refers to a module-level name `resnet50` only when imageNet=False
+            caB = _imp("ref_coarseAlignB", os.path.join(REF_ROOT, "evaluation", "evalHpatch", "coarseAlignFeatMatch.py"))
+        finally:
+            os.chdir(cwd)
+    _loaded.update(dict(outil=outil, model=model, resnet50=resnet50, downsample=downsample,
+                        CoarseAlignA=caA.CoarseAlign, CoarseAlignB=caB.CoarseAlign,
+                        kornia_geometry=sys.modules["kornia.geometry"]))
+    return _loaded
+
+
+def quiet(fn, *a, **k):
+    """Run fn with stdout silenced (the reference prints scaleList / 'Not initializing')."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)

@@ -1,0 +1,212 @@
+// conv.hip -- implicit-GEMM fp32 convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the cuDNN convolutions + eval-mode BatchNorm + ReLU (+ residual add) the reference issues
+// for the ResNet-50 conv1..layer3 trunk (model/resnet50.py:68-104,112-169 via
+// quick_start/coarseAlignFeatMatch.py:106,124), the FeatureExtractor (model/model.py:27-56,106-115)
+// and the NetFlowCoarse / NetMatchability conv stacks (model/model.py:210-226,289-305).
+//
+// GEMM view (NCHW, no layout change anywhere in the pipeline):
+//     D[m][p] = sum_k  W^T[k][m] * im2col[k][p]      m = output channel, p = (n,oh,ow), k = (c,kh,kw)
+// A operand = packed weights [Kpad][Mpad] (k-major, zero padded, so tile loads need no guards),
+// B operand = input patches gathered on the fly (coalesced along ow), both staged through LDS as
+// [BK][tile] so that a 32x32x2 MFMA lane reads one float per operand: lane l supplies
+// A[m = l&31][k = l>>5] and B[k = l>>5][p = l&31]; conflict-free ds_read_b32.
+// The fp32 MFMA is bit-for-bit a k-ordered fmaf chain, so results are deterministic and within
+// fp32 round-off of the reference's cuDNN/oneDNN sums.
+//
+// Block = 256 threads = 2x2 waves; wave tile = (32*TM) x (32*TN); BK = 16; register-prefetch double
+// buffering (global loads of step s+1 are in flight while step s runs on the matrix pipe).
+// Epilogue fused: y = fma(acc, scale[m], shift[m]) (+ residual) -> ReLU / sigmoid; stores coalesced
+// along the pixel dimension (the MFMA C/D column index is the pixel).
+#include "common.h"
+
+struct ConvArgs {
+    const float* in;
+    const float* wT;
+    const int32_t* ktab;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* out;
+    int N, Cin, Hin, Win, Cout, Hout, Wout, stride, pad, act;
+    int Kpad, Mpad;
+    long long P;  // N*Hout*Wout
+    int tilesM, tilesP;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+    constexpr int B_RPT = 256 / BN;   // k-rows covered by one pass of the block
+    constexpr int B_NP = BK / B_RPT;  // passes per K step
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: each XCD (observed: block b -> XCD b%8) walks a contiguous chunk of
+    // the tile space, m-tile fastest, so the blocks that share one im2col pixel tile run on one L2.
+    const int nwg = a.tilesM * a.tilesP;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tm_idx = bid % a.tilesM;
+    const int tp_idx = bid / a.tilesM;
+    const int m0 = tm_idx * BM;
+    const long long n0 = (long long)tp_idx * BN;
+
+    const int HWo = a.Hout * a.Wout;
+    // this thread's im2col column (fixed for the whole K loop)
+    const int pc = t % BN;
+    const int krow0 = __builtin_amdgcn_readfirstlane(t / BN);
+    const long long p = n0 + pc;
+    const bool pvalid = p < a.P;
+    int ih0 = 0, iw0 = 0;
+    const float* inb = a.in;
+    if (pvalid) {
+        const int n = (int)(p / HWo);
+        const int rem = (int)(p - (long long)n * HWo);
+        const int oh = rem / a.Wout, ow = rem - oh * a.Wout;
+        ih0 = oh * a.stride - a.pad;
+        iw0 = ow * a.stride - a.pad;
+        inb = a.in + (size_t)n * a.Cin * a.Hin * a.Win;
+    }
+
+    f32x4 ra[TM];
+    float rb[B_NP];
+
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+            ra[i] = *reinterpret_cast<const f32x4*>(a.wT + (size_t)(k0 + row) * a.Mpad + m0 + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < B_NP; ++i) {
+            const int kr = krow0 + B_RPT * i;
+            const int e = a.ktab[k0 + kr];  // wave-uniform -> scalar load
+            const int cin = e >> 8, kh = (e >> 4) & 15, kw = e & 15;
+            const int ih = ih0 + kh, iw = iw0 + kw;
+            const bool ok = pvalid && (e >= 0) && ((unsigned)ih < (unsigned)a.Hin) && ((unsigned)iw < (unsigned)a.Win);
+            const int off = ok ? ((cin * a.Hin + ih) * a.Win + iw) : 0;
+            const float v = inb[off];  // always a valid address; selected below (no branch around the load)
+            rb[i] = ok ? v : 0.0f;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+            *reinterpret_cast<f32x4*>(&As[buf][row][c4 * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_NP; ++i) Bs[buf][krow0 + B_RPT * i][pc] = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = a.Kpad / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int lrow = lane >> 5, lcol = lane & 31;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_global((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[cur][kk * 2 + lrow][(wm * TM + i) * 32 + lcol];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[cur][kk * 2 + lrow][(wn * TN + j) * 32 + lcol];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long long pp = n0 + (wn * TN + j) * 32 + lcol;
+        if (pp >= a.P) continue;
+        const int n = (int)(pp / HWo);
+        const int rem = (int)(pp - (long long)n * HWo);
+        const size_t obase = (size_t)n * a.Cout * HWo + rem;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                if (m < a.Cout) {
+                    float v = acc[i][j][r];
+                    const float sc = a.scale ? a.scale[m] : 1.0f;
+                    const float sh = a.shift ? a.shift[m] : 0.0f;
+                    v = fmaf(v, sc, sh);
+                    const size_t o = obase + (size_t)m * HWo;
+                    if (a.res) v += a.res[o];
+                    if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
+                    else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    a.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+static int launch_conv(ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    a.tilesM = (a.Cout + BM - 1) / BM;
+    a.tilesP = (int)((a.P + BN - 1) / BN);
+    const long long nwg = (long long)a.tilesM * a.tilesP;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                              const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                              int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
+    if (!in || !wT || !ktab || !out) return RFX_E_ARG;
+    if (N <= 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return RFX_E_ARG;
+    if (KH > 15 || KW > 15 || Cin >= (1 << 22)) return RFX_E_LIMIT;
+    ConvArgs a;
+    a.in = in; a.wT = wT; a.ktab = ktab; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.stride = stride; a.pad = pad; a.act = act;
+    a.Hout = (Hin + 2 * pad - KH) / stride + 1;
+    a.Wout = (Win + 2 * pad - KW) / stride + 1;
+    if (a.Hout <= 0 || a.Wout <= 0) return RFX_E_ARG;
+    if ((long long)Cin * Hin * Win > 0x7fffffffLL) return RFX_E_LIMIT;
+    const int K = Cin * KH * KW;
+    a.Kpad = (K + 15) / 16 * 16;
+    a.Mpad = (Cout + 127) / 128 * 128;
+    a.P = (long long)N * a.Hout * a.Wout;
+    hipStream_t st = rfx_stream(stream);
+    // tile choice: largest tile that still gives >= ~2 workgroups per CU (256 CUs)
+    const long long b22 = (long long)((Cout + 127) / 128) * ((a.P + 127) / 128);
+    const long long b12 = (long long)((Cout + 63) / 64) * ((a.P + 127) / 128);
+    if (Cout > 64 && b22 >= 512) return launch_conv<2, 2>(a, st);
+    if (b12 >= 512 || a.P >= 8192) return launch_conv<1, 2>(a, st);
+    return launch_conv<1, 1>(a, st);
+}

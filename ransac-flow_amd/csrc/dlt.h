@@ -1,0 +1,123 @@
+// dlt.h -- 4-point DLT homography: sign-exact null vector of the 8x9 system (utils/outil.py:68-87).
+//
+// The reference builds A (8x9, float64, entries formed from float32 products) and takes the last row of
+// Vh from numpy's LAPACK dgesdd, whose sign decides whether the hypothesis survives the det(H) > 1e-6 gate
+// (utils/outil.py:108,113).  For an 8x9 matrix dgesdd runs the unblocked bidiagonalisation dgebd2 (m < n
+// branch) and finishes with dormbr('P','R','T'), so that row 9 of Vh is exactly G_1 G_2 ... G_8 e_9, the
+// product of dgebd2's right Householder reflectors applied to the last unit vector.
+// That is a fixed-length, non-iterative float64 computation: below it is restated with dlarfg / dlarf /
+// dlapy2's operation order.  The same header compiles for the host (tests/host_dlt_check.cpp pins it
+// against numpy.linalg.svd without a GPU) and for the device (one hypothesis per lane, A in registers).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define RFX_HD __host__ __device__ __forceinline__
+#else
+#define RFX_HD inline
+#endif
+
+// dlapy2: sqrt(x^2 + y^2) without unnecessary overflow
+RFX_HD double rfx_dlapy2(double x, double y) {
+    const double xa = fabs(x), ya = fabs(y);
+    const double w = xa > ya ? xa : ya, z = xa > ya ? ya : xa;
+    if (z == 0.0) return w;
+    const double q = z / w;
+    return w * sqrt(1.0 + q * q);
+}
+
+// src: 4 source points (u', v'), tgt: 4 target points (u, v), float32 as in the reference; h: 9 doubles.
+RFX_HD void rfx_dlt4_nullvec(const float src[4][2], const float tgt[4][2], double h[9]) {
+    double A[8][9];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float u = tgt[p][0], v = tgt[p][1], us = src[p][0], vs = src[p][1];
+        // float32 products, widened on store (utils/outil.py:74-81)
+        const float vsu = vs * u, vsv = vs * v, usu = -us * u, usv = -us * v;
+        double* r0 = A[2 * p];
+        double* r1 = A[2 * p + 1];
+        r0[0] = 0.0; r0[1] = 0.0; r0[2] = 0.0; r0[3] = -(double)u; r0[4] = -(double)v; r0[5] = -1.0;
+        r0[6] = (double)vsu; r0[7] = (double)vsv; r0[8] = (double)vs;
+        r1[0] = (double)u; r1[1] = (double)v; r1[2] = 1.0; r1[3] = 0.0; r1[4] = 0.0; r1[5] = 0.0;
+        r1[6] = (double)usu; r1[7] = (double)usv; r1[8] = -(double)us;
+    }
+    double taup[8];
+    // dgebd2, m < n: for each i a right reflector G_i (stored in A[i][i+1..8]) then a left reflector H_i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // ---- dlarfg(9-i, A[i][i], A[i][i+1..8]) ----
+        double ss = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < 9; ++j) ss += A[i][j] * A[i][j];
+        const double xnorm = sqrt(ss);
+        double tau = 0.0;
+        if (xnorm != 0.0) {
+            const double alpha = A[i][i];
+            const double nrm = rfx_dlapy2(alpha, xnorm);
+            const double beta = alpha >= 0.0 ? -nrm : nrm;  // -sign(nrm, alpha), sign(+0) = +
+            tau = (beta - alpha) / beta;
+            const double sc = 1.0 / (alpha - beta);
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) A[i][j] *= sc;
+            A[i][i] = beta;
+        }
+        taup[i] = tau;
+        if (i < 7) {
+            // ---- dlarf('Right'): rows i+1..7, v = (1, A[i][i+1..8]) on columns i..8 ----
+            if (tau != 0.0) {
+#pragma unroll
+                for (int r = i + 1; r < 8; ++r) {
+                    double w = A[r][i];
+#pragma unroll
+                    for (int j = i + 1; j < 9; ++j) w += A[r][j] * A[i][j];
+                    const double tw = tau * w;
+                    A[r][i] -= tw;
+#pragma unroll
+                    for (int j = i + 1; j < 9; ++j) A[r][j] -= tw * A[i][j];
+                }
+            }
+            // ---- dlarfg(7-i, A[i+1][i], A[i+2..7][i]) ----
+            double s2 = 0.0;
+#pragma unroll
+            for (int r = i + 2; r < 8; ++r) s2 += A[r][i] * A[r][i];
+            const double ynorm = sqrt(s2);
+            if (ynorm != 0.0) {
+                const double alpha = A[i + 1][i];
+                const double nrm = rfx_dlapy2(alpha, ynorm);
+                const double beta = alpha >= 0.0 ? -nrm : nrm;
+                const double tauq = (beta - alpha) / beta;
+                const double sc = 1.0 / (alpha - beta);
+#pragma unroll
+                for (int r = i + 2; r < 8; ++r) A[r][i] *= sc;
+                A[i + 1][i] = beta;
+                // ---- dlarf('Left'): u = (1, A[i+2..7][i]) on rows i+1..7, columns i+1..8 ----
+#pragma unroll
+                for (int j = i + 1; j < 9; ++j) {
+                    double w = A[i + 1][j];
+#pragma unroll
+                    for (int r = i + 2; r < 8; ++r) w += A[r][i] * A[r][j];
+                    const double tw = tauq * w;
+                    A[i + 1][j] -= tw;
+#pragma unroll
+                    for (int r = i + 2; r < 8; ++r) A[r][j] -= tw * A[r][i];
+                }
+            }
+        }
+    }
+    // last row of Vh = G_1 ... G_8 e_9: apply G_8 first
+#pragma unroll
+    for (int j = 0; j < 9; ++j) h[j] = 0.0;
+    h[8] = 1.0;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (taup[i] != 0.0) {
+            double w = h[i];
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) w += A[i][j] * h[j];
+            const double tw = taup[i] * w;
+            h[i] -= tw;
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) h[j] -= tw * A[i][j];
+        }
+    }
+}

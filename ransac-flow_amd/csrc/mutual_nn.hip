@@ -1,0 +1,291 @@
+// mutual_nn.hip -- all-pairs feature correlation fused with mutual-nearest-neighbour selection
+// (utils/outil.py:32-45, mutualMatching; mask multiply of quick_start/coarseAlignFeatMatch.py:143).
+//
+// The reference materialises score = A^T B (nA x nB fp32, 41 MB at 480x640, 850 MB at KITTI size) plus
+// four more nA x nB temporaries (topk x2, scatter_ x2, product, nonzero).  Here the score tile lives only
+// in the MFMA accumulators:
+//   1. mnn_tile_kernel    one 128x128 score tile per workgroup on v_mfma_f32_32x32x2_f32 (K = C in
+//                         feature order, k-ordered fma chain), then in-register arg-max along both axes
+//                         -> per-tile row/column partial maxima (value, index) in the workspace;
+//   2. mnn_reduce_kernel  first-maximum reduction of the partials -> row arg-max, column arg-max;
+//   3. mnn_compact_kernel mutual test + (v*v > 0) test + ordered compaction (ascending source index,
+//                         i.e. the row-major order of the reference's nonzero()).
+// Ties (bit-equal scores) resolve to the smallest index on both axes; they only occur for all-zero
+// (masked) columns, which the v*v > 0 test drops exactly as the reference's product test does.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+struct MnnArgs {
+    const float* A; const float* B; const float* maskB;
+    int ldA, ldB, nA, nB, C;
+    int tilesA, tilesB;
+    float* rowPartVal; int* rowPartIdx;   // [tilesB][nA]
+    float* colPartVal; int* colPartIdx;   // [tilesA][nB]
+};
+
+__device__ __forceinline__ void take_min_idx(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+__global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    const int nwg = a.tilesA * a.tilesB;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap; column tile fastest so an XCD's L2 keeps one A panel hot
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tb = bid % a.tilesB, ta = bid / a.tilesB;
+    const int i0 = ta * BM, j0 = tb * BN;
+
+    const int col = t % 128;
+    const int krow0 = __builtin_amdgcn_readfirstlane(t / 128);
+    const bool aval = (i0 + col) < a.nA, bval = (j0 + col) < a.nB;
+    const float* Ap = a.A + (aval ? i0 + col : 0);
+    const float* Bp = a.B + (bval ? j0 + col : 0);
+    const float mk = (bval && a.maskB) ? a.maskB[j0 + col] : 1.0f;
+
+    float ra[8], rb[8];
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + krow0 + 2 * i;
+            const bool kin = k < a.C;
+            const float va = Ap[(size_t)(kin ? k : 0) * a.ldA];
+            const float vb = Bp[(size_t)(kin ? k : 0) * a.ldB];
+            ra[i] = (kin && aval) ? va : 0.0f;
+            rb[i] = (kin && bval) ? vb * mk : 0.0f;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            As[buf][krow0 + 2 * i][col] = ra[i];
+            Bs[buf][krow0 + 2 * i][col] = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = (a.C + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_global((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = As[cur][kk * 2 + lrow][(wm * 2 + i) * 32 + lcol];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bs[cur][kk * 2 + lrow][(wn * 2 + j) * 32 + lcol];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // all waves are past the last barrier: the staging buffers are free for the exchange below
+    float* xval = &As[0][0][0];                        // [2][128] values
+    int* xidx = reinterpret_cast<int*>(&Bs[0][0][0]);  // [2][128] indices
+
+    // ---- column arg-max over this tile's rows (C/D: col = lcol, row = (r&3) + 8*(r>>2) + 4*lrow) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = i0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const float v = acc[i][j][r];
+                if (gi < a.nA && v > bv) { bv = v; bi = gi; }  // rows visited in increasing order: first max kept
+            }
+        const float ov = __shfl_xor(bv, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        take_min_idx(bv, bi, ov, oi);
+        if (lrow == 0) {
+            xval[wm * 128 + (wn * 2 + j) * 32 + lcol] = bv;
+            xidx[wm * 128 + (wn * 2 + j) * 32 + lcol] = bi;
+        }
+    }
+    __syncthreads();
+    if (t < 128 && j0 + t < a.nB) {
+        float bv = xval[t];
+        int bi = xidx[t];
+        take_min_idx(bv, bi, xval[128 + t], xidx[128 + t]);
+        a.colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
+        a.colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
+    }
+    __syncthreads();
+
+    // ---- row arg-max over this tile's columns ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float bv = -INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gj = j0 + (wn * 2 + j) * 32 + lcol;
+                const float v = acc[i][j][r];
+                if (gj < a.nB && v > bv) { bv = v; bj = gj; }
+            }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                const float ov = __shfl_xor(bv, m, 64);
+                const int oj = __shfl_xor(bj, m, 64);
+                take_min_idx(bv, bj, ov, oj);
+            }
+            if (lcol == 0) {
+                const int li = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                xval[wn * 128 + li] = bv;
+                xidx[wn * 128 + li] = bj;
+            }
+        }
+    __syncthreads();
+    if (t < 128 && i0 + t < a.nA) {
+        float bv = xval[t];
+        int bj = xidx[t];
+        take_min_idx(bv, bj, xval[128 + t], xidx[128 + t]);
+        a.rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
+        a.rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
+    }
+}
+
+__global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a, float* rowVal, int* rowIdx, int* colIdx) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < a.nA) {
+        float bv = -INFINITY;
+        int bj = 0x7fffffff;
+        for (int tb = 0; tb < a.tilesB; ++tb)
+            take_min_idx(bv, bj, a.rowPartVal[(size_t)tb * a.nA + g], a.rowPartIdx[(size_t)tb * a.nA + g]);
+        rowVal[g] = bv;
+        rowIdx[g] = bj;
+    } else if (g - a.nA < a.nB) {
+        const int j = g - a.nA;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int ta = 0; ta < a.tilesA; ++ta)
+            take_min_idx(bv, bi, a.colPartVal[(size_t)ta * a.nB + j], a.colPartIdx[(size_t)ta * a.nB + j]);
+        colIdx[j] = bi;
+    }
+}
+
+// single workgroup, ordered compaction by ascending source index
+__global__ __launch_bounds__(1024) void mnn_compact_kernel(const float* rowVal, const int* rowIdx, const int* colIdx,
+                                                           int nA, int nB, int64_t* idx1, int64_t* idx2, int32_t* count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int s = 0; s < nA; s += 1024) {
+        const int i = s + t;
+        bool keep = false;
+        int j = 0;
+        if (i < nA) {
+            j = rowIdx[i];
+            const float v = rowVal[i];
+            keep = ((unsigned)j < (unsigned)nB) && (colIdx[j] == i) && (v * v > 0.0f);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int c = wsum[w];
+            if (w < wave) woff += c;
+            tot += c;
+        }
+        const int b = base;
+        if (keep) {
+            idx1[b + woff + before] = i;
+            idx2[b + woff + before] = j;
+        }
+        __syncthreads();
+        if (t == 0) base = b + tot;
+        __syncthreads();
+    }
+    if (t == 0) count[0] = base;
+}
+
+struct WsLayout {
+    size_t rowPartVal, rowPartIdx, colPartVal, colPartIdx, rowVal, rowIdx, colIdx, total;
+};
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+inline WsLayout layout(int nA, int nB) {
+    const size_t tA = (nA + BM - 1) / BM, tB = (nB + BN - 1) / BN;
+    WsLayout L;
+    size_t o = 0;
+    L.rowPartVal = o; o += al(tB * nA * 4);
+    L.rowPartIdx = o; o += al(tB * nA * 4);
+    L.colPartVal = o; o += al(tA * nB * 4);
+    L.colPartIdx = o; o += al(tA * nB * 4);
+    L.rowVal = o; o += al((size_t)nA * 4);
+    L.rowIdx = o; o += al((size_t)nA * 4);
+    L.colIdx = o; o += al((size_t)nB * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t rfx_mutual_nn_ws_bytes(int nA, int nB) {
+    if (nA <= 0 || nB <= 0) return 0;
+    return layout(nA, nB).total;
+}
+
+extern "C" int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
+                                 const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
+                                 void* stream) {
+    if (!featA || !featB || !idx1 || !idx2 || !count || !ws) return RFX_E_ARG;
+    if (nA <= 0 || nB <= 0 || C <= 0 || ldA < nA || ldB < nB) return RFX_E_ARG;
+    const WsLayout L = layout(nA, nB);
+    char* w = static_cast<char*>(ws);
+    MnnArgs a;
+    a.A = featA; a.B = featB; a.maskB = maskB; a.ldA = ldA; a.ldB = ldB; a.nA = nA; a.nB = nB; a.C = C;
+    a.tilesA = (nA + BM - 1) / BM; a.tilesB = (nB + BN - 1) / BN;
+    a.rowPartVal = reinterpret_cast<float*>(w + L.rowPartVal);
+    a.rowPartIdx = reinterpret_cast<int*>(w + L.rowPartIdx);
+    a.colPartVal = reinterpret_cast<float*>(w + L.colPartVal);
+    a.colPartIdx = reinterpret_cast<int*>(w + L.colPartIdx);
+    float* rowVal = reinterpret_cast<float*>(w + L.rowVal);
+    int* rowIdx = reinterpret_cast<int*>(w + L.rowIdx);
+    int* colIdx = reinterpret_cast<int*>(w + L.colIdx);
+    hipStream_t st = rfx_stream(stream);
+    const long long nwg = (long long)a.tilesA * a.tilesB;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL(mnn_tile_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mnn_reduce_kernel, dim3((nA + nB + 255) / 256), dim3(256), 0, st, a, rowVal, rowIdx, colIdx);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mnn_compact_kernel, dim3(1), dim3(1024), 0, st, rowVal, rowIdx, colIdx, nA, nB, idx1, idx2, count);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

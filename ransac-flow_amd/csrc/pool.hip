@@ -1,0 +1,216 @@
+// pool.hip -- HBM-bound element-wise / small-stencil kernels of the feature nets.
+//   maxpool      nn.MaxPool2d                       (model/resnet50.py:120, model/model.py:71)
+//   blurpool     anti-aliased Downsample            (model/downsample.py:12-46)
+//   l2norm       F.normalize(dim=1)                 (quick_start/coarseAlignFeatMatch.py:106,124)
+//   flow_head    softmax-49 + tap-offset expectation (model/model.py:228-233)
+//   resize       F.interpolate / F.upsample_bilinear (model/model.py:234,309; align2images.py:92)
+// One thread per output element, consecutive threads along W (coalesced); grids are capped and
+// grid-strided.  All arithmetic fp32 with the operation order of the ATen CPU kernels.
+#include "common.h"
+#include <math.h>
+
+static inline int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    const long long cap = 256LL * 32;  // 256 CUs x 32 resident blocks of 256 is plenty; grid-stride the rest
+    return (int)(g < cap ? g : cap);
+}
+
+__global__ __launch_bounds__(256) void maxpool2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        long long total, int Hin, int Win, int Hout, int Wout,
+                                                        int k, int stride, int pad) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(idx % Wout);
+        const long long r = idx / Wout;
+        const int oh = (int)(r % Hout);
+        const long long nc = r / Hout;
+        const float* src = in + nc * Hin * Win;
+        float m = -INFINITY;
+        const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+        for (int i = 0; i < k; ++i) {
+            const int ih = ih0 + i;
+            if ((unsigned)ih >= (unsigned)Hin) continue;
+            for (int j = 0; j < k; ++j) {
+                const int iw = iw0 + j;
+                if ((unsigned)iw >= (unsigned)Win) continue;
+                const float v = src[(size_t)ih * Win + iw];
+                m = (v > m || v != v) ? v : m;  // NaN propagates like ATen's max_pool2d
+            }
+        }
+        out[idx] = m;
+    }
+}
+
+extern "C" int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int k, int stride,
+                                 int pad, void* stream) {
+    if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || k <= 0 || stride <= 0 || pad < 0 || pad > k / 2)
+        return RFX_E_ARG;
+    const int Hout = (Hin + 2 * pad - k) / stride + 1, Wout = (Win + 2 * pad - k) / stride + 1;
+    if (Hout <= 0 || Wout <= 0) return RFX_E_ARG;
+    const long long total = (long long)NC * Hout * Wout;
+    hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), in, out,
+                       total, Hin, Win, Hout, Wout, k, stride, pad);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) {  // ReflectionPad2d(1): -1 -> 1, n -> n-2
+    return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+}
+
+__global__ __launch_bounds__(256) void blurpool2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         long long total, int Hin, int Win, int Hout, int Wout,
+                                                         int stride) {
+    // depthwise 3x3 filter [1 2 1]^T [1 2 1] / 16 accumulated in the (kh, kw) order of a direct conv
+    const float w[3] = {0.25f, 0.5f, 0.25f};
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(idx % Wout);
+        const long long r = idx / Wout;
+        const int oh = (int)(r % Hout);
+        const long long nc = r / Hout;
+        const float* src = in + nc * Hin * Win;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ih = reflect1(oh * stride - 1 + i, Hin);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int iw = reflect1(ow * stride - 1 + j, Win);
+                acc = fmaf(src[(size_t)ih * Win + iw], w[i] * w[j], acc);
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
+extern "C" int rfx_blurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream) {
+    if (!in || !out || NC <= 0 || Hin < 2 || Win < 2 || stride <= 0) return RFX_E_ARG;
+    const int Hout = (Hin + 2 - 3) / stride + 1, Wout = (Win + 2 - 3) / stride + 1;
+    const long long total = (long long)NC * Hout * Wout;
+    hipLaunchKernelGGL(blurpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), in, out,
+                       total, Hin, Win, Hout, Wout, stride);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// One thread per pixel; the channel loop strides by HW so that a wave reads 64 consecutive floats per
+// channel (coalesced).  Two passes over C (the second one hits L2).
+__global__ __launch_bounds__(256) void l2norm_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long long NP, int C, int HW, long long obs, long long ocs) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < NP;
+         p += (long long)gridDim.x * blockDim.x) {
+        const long long n = p / HW;
+        const int px = (int)(p - n * HW);
+        const float* src = in + (size_t)n * C * HW + px;
+        float* dst = out + (size_t)n * obs + px;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = 0;
+        for (; c + 3 < C; c += 4) {
+            const float a0 = src[(size_t)c * HW], a1 = src[(size_t)(c + 1) * HW];
+            const float a2 = src[(size_t)(c + 2) * HW], a3 = src[(size_t)(c + 3) * HW];
+            s0 = fmaf(a0, a0, s0); s1 = fmaf(a1, a1, s1); s2 = fmaf(a2, a2, s2); s3 = fmaf(a3, a3, s3);
+        }
+        for (; c < C; ++c) { const float a0 = src[(size_t)c * HW]; s0 = fmaf(a0, a0, s0); }
+        const float nrm = sqrtf((s0 + s1) + (s2 + s3));
+        const float d = nrm > 1e-12f ? nrm : 1e-12f;
+        for (c = 0; c < C; ++c) dst[(size_t)c * ocs] = src[(size_t)c * HW] / d;
+    }
+}
+
+extern "C" int rfx_l2norm_nchw_f32(const float* in, float* out, int N, int C, int HW, long long out_batch_stride,
+                                   long long out_chan_stride, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || HW <= 0 || out_batch_stride < 0 || out_chan_stride < 0) return RFX_E_ARG;
+    const long long NP = (long long)N * HW;
+    const long long ocs = out_chan_stride ? out_chan_stride : HW;
+    const long long obs = out_batch_stride ? out_batch_stride : (long long)C * HW;
+    hipLaunchKernelGGL(l2norm_nchw_kernel, dim3(grid_for(NP, 64)), dim3(64), 0, rfx_stream(stream), in, out, NP, C, HW,
+                       obs, ocs);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// softmax over K*K taps + expectation of the tap offsets.  One thread per pixel; the K*K logits of a
+// pixel are HW apart (coalesced across the wave).  K*K <= 64 logits are kept in registers.
+__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ logits, float* __restrict__ flow,
+                                                        long long NP, int K, int rows, int cols) {
+    const int HW = rows * cols, KK = K * K, half = K / 2;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < NP;
+         p += (long long)gridDim.x * blockDim.x) {
+        const long long n = p / HW;
+        const int px = (int)(p - n * HW);
+        const float* src = logits + (size_t)n * KK * HW + px;
+        float mx = -INFINITY;
+        for (int q = 0; q < KK; ++q) mx = fmaxf(mx, src[(size_t)q * HW]);
+        float sum = 0.f, sx = 0.f, sy = 0.f;
+        for (int q = 0; q < KK; ++q) {
+            const float e = expf(src[(size_t)q * HW] - mx);
+            sum += e;
+        }
+        // p_q = e_q / sum first (as torch.softmax does), then the two expectations, accumulated in tap order
+        for (int q = 0; q < KK; ++q) {
+            const float pq = expf(src[(size_t)q * HW] - mx) / sum;
+            const int i = q / K, j = q - i * K;
+            sx += pq * (float)(j - half);
+            sy += pq * (float)(i - half);
+        }
+        float* dst = flow + (size_t)n * 2 * HW + px;
+        dst[0] = sx / (float)cols * 2.0f;
+        dst[HW] = sy / (float)rows * 2.0f;
+    }
+}
+
+extern "C" int rfx_flow_head_f32(const float* logits, float* flow, int N, int K, int rows, int cols, void* stream) {
+    if (!logits || !flow || N <= 0 || K <= 0 || (K & 1) == 0 || rows <= 0 || cols <= 0) return RFX_E_ARG;
+    const long long NP = (long long)N * rows * cols;
+    hipLaunchKernelGGL(flow_head_kernel, dim3(grid_for(NP, 64)), dim3(64), 0, rfx_stream(stream), logits, flow, NP, K,
+                       rows, cols);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// ATen upsample_bilinear2d index rule.
+__device__ __forceinline__ float src_index(float scale, int dst, bool align_corners) {
+    if (align_corners) return scale * (float)dst;
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              long long total, int Hin, int Win, int Hout, int Wout,
+                                                              float sh, float sw, int align) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wout);
+        const long long r = idx / Wout;
+        const int oy = (int)(r % Hout);
+        const long long nc = r / Hout;
+        const float* src = in + nc * Hin * Win;
+        const float fy = src_index(sh, oy, align), fx = src_index(sw, ox, align);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float v00 = src[(size_t)y0 * Win + x0], v01 = src[(size_t)y0 * Win + x1];
+        const float v10 = src[(size_t)y1 * Win + x0], v11 = src[(size_t)y1 * Win + x1];
+        out[idx] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+
+extern "C" int rfx_resize_bilinear_f32(const float* in, float* out, int NC, int Hin, int Win, int Hout, int Wout,
+                                       int align_corners, void* stream) {
+    if (!in || !out || NC <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return RFX_E_ARG;
+    float sh, sw;
+    if (align_corners) {
+        sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+        sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    } else {
+        sh = (float)Hin / (float)Hout;
+        sw = (float)Win / (float)Wout;
+    }
+    const long long total = (long long)NC * Hout * Wout;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), in, out,
+                       total, Hin, Win, Hout, Wout, sh, sw, align_corners);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

@@ -1,0 +1,290 @@
+// ransac.hip -- RANSAC over 4-point DLT homographies (utils/outil.py:68-164).
+//
+// The reference drives the loop from the host in chunks of 100 hypotheses: 16 device->host copies, a CPU
+// LAPACK SVD, one host->device copy and >= 2 synchronising reads per chunk (utils/outil.py:73,84,86,
+// 143-150).  Here the whole search is four asynchronous launches with no host round trip:
+//   pack     matches -> (x1,y1,x2,y2) float4 + z2, so scoring issues one 16-byte load per match
+//   dlt      one hypothesis per lane: duplicate test (:122-133), float64 Householder DLT (dlt.h,
+//            LAPACK-sign-exact), float32 cast, det(H) > 1e-6 gate (:108,113)
+//   count    one hypothesis per wavefront: lanes stride over the matches, reprojection error in the
+//            reference's float32 operation order (k-ordered fma chain for Y.H^T as sgemm does, IEEE
+//            divide, separate squares / add / sqrt), __ballot + popcount for the inlier tally (:97-100,110-113)
+//   select   chunk-of-100 zero-abort (:140-146), first maximum over the filtered order (:143-160), inlier
+//            mask of the winner (:162-163)
+// This TU is compiled with -ffp-contract=off so that only the fmaf calls written below fuse.
+#include "common.h"
+#include "dlt.h"
+#include <math.h>
+
+namespace {
+
+constexpr int CHUNK = 100;         // nbMaxIter, utils/outil.py:136
+constexpr int MAX_CHUNKS = 8192;   // LDS table in select kernel -> N <= 819200 hypotheses
+
+__global__ __launch_bounds__(256) void ransac_pack_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
+                                                          int n, float4* __restrict__ P, float* __restrict__ Z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float4 p;
+        p.x = m1[i * 3 + 0]; p.y = m1[i * 3 + 1];
+        p.z = m2[i * 3 + 0]; p.w = m2[i * 3 + 1];
+        P[i] = p;
+        Z[i] = m2[i * 3 + 2];
+    }
+}
+
+__device__ __forceinline__ float det3_f32(const float* h) {
+    // cofactor expansion along the first row, float32, no contraction
+    const float c0 = __fsub_rn(__fmul_rn(h[4], h[8]), __fmul_rn(h[5], h[7]));
+    const float c1 = __fsub_rn(__fmul_rn(h[3], h[8]), __fmul_rn(h[5], h[6]));
+    const float c2 = __fsub_rn(__fmul_rn(h[3], h[7]), __fmul_rn(h[4], h[6]));
+    return __fadd_rn(__fsub_rn(__fmul_rn(h[0], c0), __fmul_rn(h[1], c1)), __fmul_rn(h[2], c2));
+}
+
+// X,Y given either as gathered samples (N,4,3) [direct != 0] or through indices into the match arrays.
+__global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict__ m1, const float* __restrict__ m2, int n,
+                                                        const int64_t* __restrict__ samples, int N, int filter_dup,
+                                                        float* __restrict__ Hout, uint8_t* __restrict__ flags) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= N) return;
+    float src[4][2], tgt[4][2];
+    bool dup = false, bad = false;
+    if (samples) {
+        int64_t s[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) s[p] = samples[(size_t)h * 4 + p];
+        dup = (s[0] == s[1]) | (s[0] == s[2]) | (s[0] == s[3]) | (s[1] == s[2]) | (s[1] == s[3]) | (s[2] == s[3]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int64_t q = s[p];
+            if (q < 0) q += n;  // python-style negative index
+            if (q < 0 || q >= n) { bad = true; q = 0; }
+            src[p][0] = m1[q * 3 + 0]; src[p][1] = m1[q * 3 + 1];
+            tgt[p][0] = m2[q * 3 + 0]; tgt[p][1] = m2[q * 3 + 1];
+        }
+    } else {  // m1 = X (N,4,3), m2 = Y (N,4,3)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            src[p][0] = m1[((size_t)h * 4 + p) * 3 + 0]; src[p][1] = m1[((size_t)h * 4 + p) * 3 + 1];
+            tgt[p][0] = m2[((size_t)h * 4 + p) * 3 + 0]; tgt[p][1] = m2[((size_t)h * 4 + p) * 3 + 1];
+        }
+    }
+    uint8_t fl = 0;  // bit0: evaluated (survives the duplicate filter), bit1: det gate passed
+    if (!(filter_dup && dup) && !bad) {
+        double hv[9];
+        rfx_dlt4_nullvec(src, tgt, hv);
+        float hf[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { hf[j] = (float)hv[j]; Hout[(size_t)h * 9 + j] = hf[j]; }
+        fl = 1 | (det3_f32(hf) > 1e-6f ? 2 : 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) Hout[(size_t)h * 9 + j] = 0.0f;
+    }
+    if (flags) flags[h] = fl;
+}
+
+__device__ __forceinline__ float reproj_error(const float4 p, const float z, const float* H) {
+    // estimX = Y @ H^T : k-ordered fma chain (what the reference's K=3 sgemm evaluates)
+    const float px = fmaf(z, H[2], fmaf(p.w, H[1], __fmul_rn(p.z, H[0])));
+    const float py = fmaf(z, H[5], fmaf(p.w, H[4], __fmul_rn(p.z, H[3])));
+    const float pz = fmaf(z, H[8], fmaf(p.w, H[7], __fmul_rn(p.z, H[6])));
+    const float ex = __fdiv_rn(px, pz), ey = __fdiv_rn(py, pz);
+    const float dx = __fsub_rn(p.x, ex), dy = __fsub_rn(p.y, ey);
+    const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+    return __fsqrt_rn(d2);
+}
+
+__device__ __forceinline__ bool is_inlier(const float4 p, const float z, const float* H, const float tol) {
+    return reproj_error(p, z, H) < tol;  // NaN (pz == 0) compares false, as in the reference
+}
+
+// outil.Prediction (utils/outil.py:97-100): err[h][m] for every (hypothesis, match) pair
+__global__ __launch_bounds__(256) void prediction_kernel(const float* __restrict__ m1, const float* __restrict__ m2, int n,
+                                                         const float* __restrict__ Hs, int N, float* __restrict__ err) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (m >= n) return;
+    float H[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) H[j] = Hs[(size_t)h * 9 + j];
+    float4 p;
+    p.x = m1[m * 3 + 0]; p.y = m1[m * 3 + 1]; p.z = m2[m * 3 + 0]; p.w = m2[m * 3 + 1];
+    err[(size_t)h * n + m] = reproj_error(p, m2[m * 3 + 2], H);
+}
+
+// one hypothesis per wavefront, 4 wavefronts per workgroup
+__global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restrict__ P, const float* __restrict__ Z, int n,
+                                                           const float* __restrict__ Hs, const uint8_t* __restrict__ flags,
+                                                           int N, float tol, int* __restrict__ counts32,
+                                                           int64_t* __restrict__ counts64) {
+    const int lane = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (h >= N) return;
+    const uint8_t fl = flags[h];
+    int cnt = 0;
+    if (fl & 1) {
+        float H[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) H[j] = Hs[(size_t)h * 9 + j];  // wave-uniform -> scalar loads
+        for (int m0 = 0; m0 < n; m0 += 64) {  // wave-uniform trip count (the ballot needs every lane)
+            const int m = m0 + lane;
+            bool in = false;
+            if (m < n) in = is_inlier(P[m], Z[m], H, tol);
+            cnt += __popcll(__ballot(in));
+        }
+        if (!(fl & 2)) cnt = 0;  // counts * (det > 1e-6)
+    }
+    if (lane == 0) {
+        if (counts32) counts32[h] = (fl & 1) ? cnt : -1;
+        if (counts64) counts64[h] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __restrict__ P, const float* __restrict__ Z, int n,
+                                                             const float* __restrict__ Hs, const uint8_t* __restrict__ flags,
+                                                             const int* __restrict__ counts, int N, float tol,
+                                                             float* __restrict__ bestH, uint8_t* __restrict__ inlier,
+                                                             int32_t* __restrict__ result) {
+    __shared__ int chunkmax[MAX_CHUNKS];
+    __shared__ int wsum[16];
+    __shared__ int base;
+    __shared__ unsigned long long bestkey;
+    __shared__ int s_status;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int c = t; c < MAX_CHUNKS; c += 1024) chunkmax[c] = 0;
+    if (t == 0) { base = 0; bestkey = 0ull; s_status = 0; }
+    __syncthreads();
+    // rank of every surviving hypothesis in the filtered order, per-chunk maxima, global first maximum
+    for (int s = 0; s < N; s += 1024) {
+        const int h = s + t;
+        const bool keep = h < N && (flags[h] & 1);
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) woff += c; tot += c; }
+        const int b = base;
+        if (keep) {
+            const int rank = b + woff + before;
+            const int c = counts[h];
+            atomicMax(&chunkmax[rank / CHUNK], c);
+            // larger count wins; equal counts: smaller index wins
+            const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | (unsigned)(0xffffffffu - (unsigned)h);
+            atomicMax(&bestkey, key);
+        }
+        __syncthreads();
+        if (t == 0) base = b + tot;
+        __syncthreads();
+    }
+    const int nUnique = base;
+    const int nFull = nUnique / CHUNK;
+    bool ab = false;
+    for (int c = t; c < nFull; c += 1024) ab |= (chunkmax[c] == 0);
+    if (ab) s_status = 1;  // benign race: all writers store 1
+    __syncthreads();
+    const unsigned long long key = bestkey;
+    const int bestCnt = (int)(key >> 32);
+    const int bestIdx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    int status = s_status;
+    if (status == 0 && (nUnique == 0 || bestCnt == 0)) status = 2;
+    if (t == 0) {
+        result[0] = status;
+        result[1] = status == 0 ? bestCnt : 0;
+        result[2] = status == 0 ? bestIdx : -1;
+        result[3] = nUnique;
+    }
+    if (status != 0) {
+        for (int m = t; m < n; m += 1024) inlier[m] = 0;
+        if (t < 9) bestH[t] = 0.0f;
+        return;
+    }
+    float H[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) H[j] = Hs[(size_t)bestIdx * 9 + j];
+    if (t < 9) bestH[t] = H[t];
+    for (int m = t; m < n; m += 1024) inlier[m] = is_inlier(P[m], Z[m], H, tol) ? 1 : 0;
+}
+
+struct RansacWs {
+    size_t P, Z, H, flags, counts, total;
+};
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+inline RansacWs ws_layout(int N, int n_cap) {
+    RansacWs L;
+    size_t o = 0;
+    L.P = o; o += al((size_t)n_cap * 16);
+    L.Z = o; o += al((size_t)n_cap * 4);
+    L.H = o; o += al((size_t)N * 36);
+    L.flags = o; o += al((size_t)N);
+    L.counts = o; o += al((size_t)N * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int rfx_dlt4_homography(const float* X, const float* Y, int N, float* Hout, void* stream) {
+    if (!X || !Y || !Hout || N <= 0) return RFX_E_ARG;
+    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
+                       (const int64_t*)nullptr, N, 0, Hout, (uint8_t*)nullptr);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_prediction_f32(const float* match1, const float* match2, int n, const float* Hs, int N, float* err,
+                                  void* stream) {
+    if (!match1 || !match2 || !Hs || !err || n <= 0 || N <= 0 || N > 65535) return RFX_E_ARG;
+    hipLaunchKernelGGL(prediction_kernel, dim3((n + 255) / 256, N), dim3(256), 0, rfx_stream(stream), match1, match2, n,
+                       Hs, N, err);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" size_t rfx_ransac_ws_bytes(int n, int N) {
+    if (N <= 0 || n <= 0) return 0;
+    return ws_layout(N, n).total;
+}
+
+static int ransac_common(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
+                         int filter_dup, const RansacWs& L, char* w, float* Hs, int64_t* counts64, hipStream_t st) {
+    float4* P = reinterpret_cast<float4*>(w + L.P);
+    float* Z = reinterpret_cast<float*>(w + L.Z);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(w + L.flags);
+    int* counts = reinterpret_cast<int*>(w + L.counts);
+    hipLaunchKernelGGL(ransac_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, match1, match2, n, P, Z);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, st, match1, match2, n, samples, N,
+                       filter_dup, Hs, flags);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((N + 3) / 4), dim3(256), 0, st, P, Z, n, Hs, flags, N, tol, counts,
+                       counts64);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_score_hypotheses(const float* match1, const float* match2, int n, const int64_t* samples, int N,
+                                    float tol, float* Hout, int64_t* counts, void* ws, void* stream) {
+    if (!match1 || !match2 || !samples || !Hout || !counts || !ws || n <= 0 || N <= 0) return RFX_E_ARG;
+    const RansacWs L = ws_layout(N, n);
+    return ransac_common(match1, match2, n, samples, N, tol, 0, L, static_cast<char*>(ws), Hout, counts,
+                         rfx_stream(stream));
+}
+
+extern "C" int rfx_ransac_h4(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
+                             float* bestH, uint8_t* inlier, int32_t* result, void* ws, void* stream) {
+    if (!match1 || !match2 || !samples || !bestH || !inlier || !result || !ws || n <= 0 || N <= 0) return RFX_E_ARG;
+    if ((N + CHUNK - 1) / CHUNK > MAX_CHUNKS) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, n);
+    char* w = static_cast<char*>(ws);
+    float* Hs = reinterpret_cast<float*>(w + L.H);
+    hipStream_t st = rfx_stream(stream);
+    int rc = ransac_common(match1, match2, n, samples, N, tol, 1, L, w, Hs, nullptr, st);
+    if (rc != RFX_OK) return rc;
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
+                       reinterpret_cast<const float*>(w + L.Z), n, Hs, reinterpret_cast<const uint8_t*>(w + L.flags),
+                       reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

@@ -1,0 +1,2 @@
+"""rfx: host-side package of the MI355X-native RANSAC-Flow hot path (ctypes over librfx.so)."""
+__version__ = "0.1.0"

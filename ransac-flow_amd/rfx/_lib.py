@@ -1,0 +1,67 @@
+"""ctypes binding of librfx.so (the C ABI in include/rfx_api.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C ransac-flow_amd/csrc``.  There is
+no fallback: if the shared object is missing or a symbol cannot be resolved the import of any op fails
+loudly (RuntimeError), and every op refuses tensors that are not on a HIP device.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_float, c_void_p, c_size_t, c_longlong, c_char_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "librfx.so"))
+
+# name -> (restype, argtypes); mirrors include/rfx_api.h one to one
+SIGNATURES = {
+    "rfx_version": (c_char_p, []),
+    "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
+    "rfx_maxpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "rfx_blurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "rfx_l2norm_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
+    "rfx_flow_head_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "rfx_resize_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "rfx_corr_neigh_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
+    "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "rfx_grid_sample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    "rfx_compose_flow_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
+    "rfx_mutual_nn_ws_bytes": (c_size_t, [c_int, c_int]),
+    "rfx_mutual_nn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "rfx_dlt4_homography": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rfx_prediction_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "rfx_score_hypotheses": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4),
+    "rfx_ransac_ws_bytes": (c_size_t, [c_int, c_int]),
+    "rfx_ransac_h4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 5),
+}
+
+_lib = None
+
+
+def load():
+    """Load librfx.so and attach prototypes.  Raises RuntimeError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "librfx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError("librfx.so is missing symbol %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class RfxError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "bad argument" if rc == -1 else ("limit exceeded" if rc == -2 else "hipError_t %d" % rc)
+        raise RfxError("%s failed: %s" % (what, kind))

@@ -1,0 +1,117 @@
+"""The four networks of the hot path as sequences of librfx kernel launches.
+
+Each class is built from a reference-keyed ``state_dict`` (see rfx/weights.py), packs the conv weights and
+folds eval-mode BatchNorm once, and then runs forward-only on device tensors.  Activations stay NCHW fp32
+from the first layer to the last: there is no layout conversion between kernels.
+"""
+import torch
+
+from . import ops
+from .ops import ConvPlan, ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+
+def _bn(sd, p):
+    return {k: sd[p + "." + k] for k in ("weight", "bias", "running_mean", "running_var")}
+
+
+class ResNet50Trunk:
+    """ResNet-50 conv1..layer3 (stride 16, 1024 channels): model/resnet50.py:68-104,112-169 as sliced by
+    quick_start/coarseAlignFeatMatch.py:34-52.  Bottleneck = 1x1 -> 3x3 (stride here) -> 1x1, BN folded into
+    every conv's epilogue, residual add + ReLU fused into the third conv."""
+
+    def __init__(self, sd, device="cuda"):
+        self.conv1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), stride=2, pad=3, act=ACT_RELU, device=device)
+        self.blocks = []
+        for layer, nblk, stride in (("layer1", 3, 1), ("layer2", 4, 2), ("layer3", 6, 2)):
+            for b in range(nblk):
+                p = "%s.%d" % (layer, b)
+                s = stride if b == 0 else 1
+                blk = {
+                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), 1, 0, ACT_RELU, device),
+                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device),
+                    "c3": ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device),
+                    "ds": None,
+                }
+                if (p + ".downsample.0.weight") in sd:
+                    blk["ds"] = ConvPlan(sd[p + ".downsample.0.weight"], _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE,
+                                         device)
+                self.blocks.append(blk)
+
+    def __call__(self, x):
+        x = self.conv1(x)
+        x = ops.maxpool2d(x, 3, 2, 1)
+        for blk in self.blocks:
+            o = blk["c1"](x)
+            o = blk["c2"](o)
+            r = blk["ds"](x) if blk["ds"] is not None else x
+            x = blk["c3"](o, residual=r)  # relu(bn3(conv3(o)) + r)
+        return x
+
+
+class FeatureExtractorNet:
+    """model/model.py:59-125: conv3x3(3->64)+BN+ReLU, MaxPool(2,1)+BlurPool/2, 2xBasicBlock(64),
+    2x(128,/2), 2x(256,/2).  Shortcut of the strided blocks = BlurPool/2 -> 1x1 conv -> BN (:92-93)."""
+
+    def __init__(self, sd, device="cuda"):
+        self.conv1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), 1, 1, ACT_RELU, device)
+        self.blocks = []
+        for layer, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
+            for b in range(2):
+                p = "%s.%d" % (layer, b)
+                s = stride if b == 0 else 1
+                blk = {
+                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), s, 1, ACT_RELU, device),
+                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), 1, 1, ACT_RELU, device),
+                    "ds": None, "stride": s,
+                }
+                if (p + ".downsample.1.weight") in sd:
+                    blk["ds"] = ConvPlan(sd[p + ".downsample.1.weight"], _bn(sd, p + ".downsample.2"), 1, 0, ACT_NONE,
+                                         device)
+                self.blocks.append(blk)
+
+    def __call__(self, x):
+        x = self.conv1(x)
+        x = ops.blurpool2d(ops.maxpool2d(x, 2, 1, 0), 2)
+        for blk in self.blocks:
+            o = blk["c1"](x)
+            r = blk["ds"](ops.blurpool2d(x, blk["stride"])) if blk["ds"] is not None else x
+            x = blk["c2"](o, residual=r)
+        return x
+
+
+class _HeadTrunk:
+    def __init__(self, sd, last_act, device):
+        self.c1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), 1, 1, ACT_RELU, device)
+        self.c2 = ConvPlan(sd["conv2.weight"], _bn(sd, "bn2"), 1, 1, ACT_RELU, device)
+        self.c3 = ConvPlan(sd["conv3.weight"], _bn(sd, "bn3"), 1, 1, ACT_RELU, device)
+        self.c4 = ConvPlan(sd["conv4.weight"], None, 1, 1, last_act, device)
+
+    def __call__(self, coef):
+        return self.c4(self.c3(self.c2(self.c1(coef))))
+
+
+class NetFlowCoarseNet:
+    """model/model.py:167-249.  up8X=True -> F.upsample_bilinear x8 (align_corners=True, :234)."""
+
+    def __init__(self, sd, kernelSize=7, device="cuda"):
+        self.k = kernelSize
+        self.trunk = _HeadTrunk(sd, ACT_NONE, device)
+
+    def __call__(self, coef, up8X=True):
+        flow = ops.flow_head(self.trunk(coef), self.k)
+        if up8X:
+            flow = ops.resize_bilinear(flow, (flow.shape[2] * 8, flow.shape[3] * 8), align_corners=True)
+        return flow
+
+
+class NetMatchabilityNet:
+    """model/model.py:254-322: sigmoid fused into the last conv's epilogue."""
+
+    def __init__(self, sd, kernelSize=7, device="cuda"):
+        self.trunk = _HeadTrunk(sd, ACT_SIGMOID, device)
+
+    def __call__(self, feat, up8X=True):
+        m = self.trunk(feat)
+        if up8X:
+            m = ops.resize_bilinear(m, (m.shape[2] * 8, m.shape[3] * 8), align_corners=True)
+        return m

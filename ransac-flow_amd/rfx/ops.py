@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the librfx C ABI.
+
+PyTorch is used for device memory and streams only: every function takes ``torch`` tensors that already
+live on a HIP device, passes ``data_ptr()`` / sizes / ``torch.cuda.current_stream()`` to the C entry point
+and returns freshly allocated output tensors.  No op has a CPU or eager-PyTorch fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name="tensor", dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: rfx ops run only on a HIP device (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class ConvPlan:
+    """Packed weights + folded BatchNorm of one convolution (see rfx_conv2d_f32 in include/rfx_api.h)."""
+
+    def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5):
+        # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None
+        w = weight.detach().float().cpu()
+        self.Cout, self.Cin, self.KH, self.KW = w.shape
+        self.stride, self.pad, self.act = stride, pad, act
+        K = self.Cin * self.KH * self.KW
+        Kpad, Mpad = (K + 15) // 16 * 16, (self.Cout + 127) // 128 * 128
+        wT = torch.zeros(Kpad, Mpad, dtype=torch.float32)
+        wT[:K, :self.Cout] = w.reshape(self.Cout, K).t()
+        k = torch.arange(K)
+        c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)
+        ktab = torch.full((Kpad,), -1, dtype=torch.int32)
+        ktab[:K] = ((c << 8) | ((r // self.KW) << 4) | (r % self.KW)).int()
+        dev = device or "cuda"
+        self.wT, self.ktab = wT.to(dev), ktab.to(dev)
+        if bn is not None:
+            # eval-mode BatchNorm as ATen's CPU kernel evaluates it: alpha = w * (1/sqrt(var+eps)), beta = b - mean*alpha
+            invstd = 1.0 / torch.sqrt(bn["running_var"].detach().float().cpu() + eps)
+            alpha = bn["weight"].detach().float().cpu() * invstd
+            beta = bn["bias"].detach().float().cpu() - bn["running_mean"].detach().float().cpu() * alpha
+            self.scale, self.shift = alpha.to(dev), beta.to(dev)
+        else:
+            self.scale = self.shift = None
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1
+
+    def __call__(self, x, residual=None, act=None):
+        x = _dev(x, "conv input")
+        N, C, H, W = x.shape
+        if C != self.Cin:
+            raise ValueError("conv expects %d input channels, got %d" % (self.Cin, C))
+        Ho, Wo = self.out_hw(H, W)
+        out = torch.empty((N, self.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        res = _dev(residual, "residual") if residual is not None else None
+        if res is not None and res.shape != out.shape:
+            raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
+        rc = _lib.load().rfx_conv2d_f32(_p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift), _p(res),
+                                        _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
+                                        self.act if act is None else act, _stream())
+        _lib.check(rc, "rfx_conv2d_f32")
+        return out
+
+
+def maxpool2d(x, k, stride, pad=0):
+    x = _dev(x, "maxpool input")
+    N, C, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rfx_maxpool2d_f32(_p(x), _p(out), N * C, H, W, k, stride, pad, _stream()), "rfx_maxpool2d_f32")
+    return out
+
+
+def blurpool2d(x, stride=2):
+    x = _dev(x, "blurpool input")
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rfx_blurpool2d_f32(_p(x), _p(out), N * C, H, W, stride, _stream()), "rfx_blurpool2d_f32")
+    return out
+
+
+def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):
+    """F.normalize(x, dim=1) for (N,C,H,W) or (N,C,L).  With ``out`` (a float32 device tensor/view start) the
+    result is scattered with the given strides (elements)."""
+    x = _dev(x, "l2norm input")
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C)
+    if out is None:
+        out = torch.empty_like(x)
+        obs = ocs = 0
+    else:
+        if not out.is_cuda or out.dtype != torch.float32:
+            raise TypeError("l2norm out must be a float32 device tensor")
+        obs, ocs = out_batch_stride, out_chan_stride
+    _lib.check(_lib.load().rfx_l2norm_nchw_f32(_p(x), _p(out), N, C, HW, obs, ocs, _stream()), "rfx_l2norm_nchw_f32")
+    return out
+
+
+def flow_head(logits, K=7):
+    logits = _dev(logits, "flow logits")
+    N, C, R, Cc = logits.shape
+    if C != K * K:
+        raise ValueError("flow head expects %d logits, got %d" % (K * K, C))
+    out = torch.empty((N, 2, R, Cc), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().rfx_flow_head_f32(_p(logits), _p(out), N, K, R, Cc, _stream()), "rfx_flow_head_f32")
+    return out
+
+
+def resize_bilinear(x, size, align_corners=False):
+    x = _dev(x, "resize input")
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rfx_resize_bilinear_f32(_p(x), _p(out), N * C, H, W, Ho, Wo, 1 if align_corners else 0,
+                                                  _stream()), "rfx_resize_bilinear_f32")
+    return out
+
+
+def corr_neigh(x, y, K=7):
+    x, y = _dev(x, "corr x"), _dev(y, "corr y")
+    if x.shape != y.shape:
+        raise ValueError("corr_neigh: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
+    N, C, H, W = x.shape
+    out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rfx_corr_neigh_f32(_p(x), _p(y), _p(out), N, C, H, W, K, _stream()), "rfx_corr_neigh_f32")
+    return out
+
+
+def warp_grid(Hm, h, w):
+    Hm = _dev(Hm, "homography")
+    B = Hm.shape[0]
+    grid = torch.empty((B, h, w, 2), dtype=torch.float32, device=Hm.device)
+    _lib.check(_lib.load().rfx_warp_grid_f32(_p(Hm), _p(grid), B, h, w, _stream()), "rfx_warp_grid_f32")
+    return grid
+
+
+def grid_sample(inp, grid, align_corners=False):
+    inp, grid = _dev(inp, "grid_sample input"), _dev(grid, "grid")
+    N, C, Hi, Wi = inp.shape
+    if grid.shape[0] != N or grid.shape[3] != 2:
+        raise ValueError("grid must be (N,Ho,Wo,2)")
+    Ho, Wo = grid.shape[1], grid.shape[2]
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=inp.device)
+    _lib.check(_lib.load().rfx_grid_sample_f32(_p(inp), _p(grid), _p(out), N, C, Hi, Wi, Ho, Wo,
+                                              1 if align_corners else 0, _stream()), "rfx_grid_sample_f32")
+    return out
+
+
+def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up=False):
+    flowDown, coarseGrid = _dev(flowDown, "flowDown"), _dev(coarseGrid, "coarse grid")
+    N, two, hd, wd = flowDown.shape
+    _, H, W, _ = coarseGrid.shape
+    flow12 = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device)
+    inb = torch.empty((N, H, W), dtype=torch.float32, device=flowDown.device) if want_inb else None
+    fup = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device) if want_flow_up else None
+    _lib.check(_lib.load().rfx_compose_flow_f32(_p(flowDown), _p(coarseGrid), _p(flow12), _p(inb), _p(fup), N, hd, wd,
+                                               H, W, 1 if clamp else 0, _stream()), "rfx_compose_flow_f32")
+    return flow12, inb, fup
+
+
+def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
+    """featA (C,nA), featB (C,nB) -> (index1, index2) int64 device tensors (ascending index1).
+    Synchronises once to read the match count (the reference's nonzero() does the same)."""
+    featA, featB = _dev(featA, "featA"), _dev(featB, "featB")
+    C = featA.shape[0]
+    nA = nA or featA.shape[1]
+    nB = nB or featB.shape[1]
+    ldA = ldA or featA.stride(0)
+    ldB = ldB or featB.stride(0)
+    lib = _lib.load()
+    ws = torch.empty(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=featA.device)
+    cap = min(nA, nB)
+    idx1 = torch.empty(cap, dtype=torch.int64, device=featA.device)
+    idx2 = torch.empty(cap, dtype=torch.int64, device=featA.device)
+    count = torch.zeros(1, dtype=torch.int32, device=featA.device)
+    m = _dev(maskB, "maskB") if maskB is not None else None
+    _lib.check(lib.rfx_mutual_nn_f32(_p(featA), ldA, nA, _p(featB), ldB, nB, C, _p(m), _p(idx1), _p(idx2), _p(count),
+                                     _p(ws), _stream()), "rfx_mutual_nn_f32")
+    n = int(count.item())
+    return idx1[:n], idx2[:n]
+
+
+def dlt4_homography(X, Y):
+    X, Y = _dev(X, "X"), _dev(Y, "Y")
+    N = X.shape[0]
+    H = torch.empty((N, 3, 3), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.load().rfx_dlt4_homography(_p(X), _p(Y), N, _p(H), _stream()), "rfx_dlt4_homography")
+    return H
+
+
+def prediction(match1, match2, Hs):
+    """outil.Prediction for match1/match2 (n,3) and Hs (N,3,3) -> (N,n) float32 errors."""
+    match1, match2, Hs = _dev(match1, "match1"), _dev(match2, "match2"), _dev(Hs, "H21")
+    n, N = match1.shape[0], Hs.shape[0]
+    err = torch.empty((N, n), dtype=torch.float32, device=match1.device)
+    _lib.check(_lib.load().rfx_prediction_f32(_p(match1), _p(match2), n, _p(Hs), N, _p(err), _stream()),
+               "rfx_prediction_f32")
+    return err
+
+
+def score_hypotheses(match1, match2, samples, tol):
+    match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
+    samples = _dev(samples, "samples", torch.int64)
+    n, N = match1.shape[0], samples.shape[0]
+    lib = _lib.load()
+    H = torch.empty((N, 3, 3), dtype=torch.float32, device=match1.device)
+    counts = torch.empty(N, dtype=torch.int64, device=match1.device)
+    ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=match1.device)
+    _lib.check(lib.rfx_score_hypotheses(_p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts), _p(ws),
+                                        _stream()), "rfx_score_hypotheses")
+    return H, counts
+
+
+def ransac_h4(match1, match2, samples, tol):
+    """Device RANSAC.  Returns (bestH (3,3) f32, inlier (n,) bool, result int32[4]) as device tensors
+    (result = [status, best count, winning hypothesis index, #hypotheses after the duplicate filter])."""
+    match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
+    samples = _dev(samples, "samples", torch.int64)
+    n, N = match1.shape[0], samples.shape[0]
+    lib = _lib.load()
+    dev = match1.device
+    bestH = torch.empty((3, 3), dtype=torch.float32, device=dev)
+    inl = torch.empty(n, dtype=torch.uint8, device=dev)
+    res = torch.empty(4, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=dev)
+    _lib.check(lib.rfx_ransac_h4(_p(match1), _p(match2), n, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res),
+                                 _p(ws), _stream()), "rfx_ransac_h4")
+    return bestH, inl.bool(), res

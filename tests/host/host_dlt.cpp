@@ -1,0 +1,15 @@
+// Host build of ransac-flow_amd/csrc/dlt.h so that the sign-exact DLT null vector can be pinned against
+// numpy.linalg.svd (the reference's utils/outil.py:84) on a GPU-less machine.  Test infrastructure only.
+#include "../../ransac-flow_amd/csrc/dlt.h"
+extern "C" void rfx_host_dlt4(const float* X, const float* Y, int N, double* h_out, float* H_out) {
+    for (int n = 0; n < N; ++n) {
+        float src[4][2], tgt[4][2];
+        for (int p = 0; p < 4; ++p) {
+            src[p][0] = X[(n * 4 + p) * 3 + 0]; src[p][1] = X[(n * 4 + p) * 3 + 1];
+            tgt[p][0] = Y[(n * 4 + p) * 3 + 0]; tgt[p][1] = Y[(n * 4 + p) * 3 + 1];
+        }
+        double h[9];
+        rfx_dlt4_nullvec(src, tgt, h);
+        for (int j = 0; j < 9; ++j) { h_out[n * 9 + j] = h[j]; H_out[n * 9 + j] = (float)h[j]; }
+    }
+}

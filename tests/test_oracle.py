@@ -1,0 +1,233 @@
+"""CPU tests: the oracle restatement (oracle/restate.py) against the committed golden vectors that were
+produced by the real reference (tests/golden/make_golden.py), the host build of the DLT header against
+numpy's LAPACK SVD, and the C-ABI surface of librfx.so.  No GPU needed."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import restate
+from rfx import weights, synth, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+# ---------------------------------------------------------------- RANSAC
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_ransac_restatement_matches_reference_golden(seed):
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["m1_%d" % seed]), torch.from_numpy(g["m2_%d" % seed])
+    samples = torch.from_numpy(g["samples_%d" % seed])
+    Hb, cnt, inl, m2in = restate.ransac(m1, m2, 0.05, samples)
+    assert int(cnt) == int(g["count_%d" % seed])
+    assert np.array_equal(inl, g["inlier_%d" % seed])            # inlier indices: bit exact
+    assert np.abs(Hb - g["H_%d" % seed]).max() <= 1e-6
+    assert Hb.dtype == np.float32 and inl.dtype == np.bool_
+    assert np.array_equal(m2in, m2.numpy()[inl])
+
+
+def test_score_ransac_restatement_matches_golden():
+    g = gold("ransac.npz")
+    for seed in range(4):
+        m1, m2 = torch.from_numpy(g["m1_%d" % seed]), torch.from_numpy(g["m2_%d" % seed])
+        uniq = restate.filter_samples(torch.from_numpy(g["samples_%d" % seed]))[:300]
+        H21, cnt = restate.score_ransac(m1, m2, 0.05, uniq)
+        assert np.abs(H21.numpy() - g["score_H_%d" % seed]).max() <= 1e-6
+        assert np.array_equal(cnt.numpy(), g["score_counts_%d" % seed])
+
+
+def test_ransac_abort_and_sentinels():
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["abort_m1"]), torch.from_numpy(g["abort_m2"])
+    res = restate.ransac(m1, m2, -1.0, torch.from_numpy(g["abort_samples"]))
+    assert res[0] is None and res[1] == 0 and res[2] == [] and res[3] == []
+    # fewer than 100 surviving hypotheses and nothing beats 0 -> the reference's TypeError (utils/outil.py:162)
+    with pytest.raises(TypeError):
+        restate.ransac(m1, m2, -1.0, torch.from_numpy(g["abort_samples"])[:50])
+
+
+def test_duplicate_filter_keeps_order():
+    s = torch.tensor([[0, 1, 2, 3], [1, 1, 2, 3], [4, 5, 6, 4], [7, 8, 9, 10], [3, 2, 2, 0]])
+    assert restate.filter_samples(s).tolist() == [[0, 1, 2, 3], [7, 8, 9, 10]]
+
+
+# ---------------------------------------------------------------- DLT null vector
+
+
+def _host_dlt_lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hostdlt")
+    so = str(d / "libhostdlt.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "host", "host_dlt.cpp")])
+    return ctypes.CDLL(so)
+
+
+def test_householder_dlt_is_lapack_sign_exact(tmp_path_factory):
+    """The kernel's DLT header (compiled for the host) and the numpy restatement of SURVEY A.1 agree with
+    numpy.linalg.svd's last row of Vh (the reference's utils/outil.py:84-86) incl. its sign."""
+    lib = _host_dlt_lib(tmp_path_factory)
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["m1_0"]), torch.from_numpy(g["m2_0"])
+    torch.manual_seed(9)
+    samples = restate.filter_samples(torch.randint(len(m1), (6000, 4)))
+    X, Y = m1[samples].contiguous().numpy(), m2[samples].contiguous().numpy()
+    N = len(X)
+    h = np.zeros((N, 9))
+    Hf = np.zeros((N, 9), dtype=np.float32)
+    vp = ctypes.c_void_p
+    lib.rfx_host_dlt4(X.ctypes.data_as(vp), Y.ctypes.data_as(vp), N, h.ctypes.data_as(vp), Hf.ctypes.data_as(vp))
+    A = restate.dlt_matrix(X, Y)
+    _, s, vh = np.linalg.svd(A)
+    ref = vh[:, 8]
+    good = s[:, 7] > 1e-9          # rank-8 systems (collinear samples are numerically rank deficient)
+    assert good.mean() > 0.99
+    assert ((h * ref).sum(1)[good] > 0).all()                       # sign: 100 %
+    assert np.abs(Hf[good] - ref[good].astype(np.float32)).max() <= 1.2e-7
+    py = restate.householder_nullvec(A[:64])
+    wc = s[:64, 7] > 1e-3          # well conditioned: the two implementations agree to rounding
+    assert np.abs(py - h[:64])[wc].max() < 1e-10
+    # the float32 H of restate.homography_svd is what the reference returns
+    Href = restate.homography_svd(torch.from_numpy(X[:64]), torch.from_numpy(Y[:64])).numpy().reshape(-1, 9)
+    assert np.abs(Href - Hf[:64]).max() <= 1.2e-7
+
+
+def test_identity_matches_give_identity_homography():
+    """KAT: identical match lists -> H proportional to I, every match an inlier."""
+    W, Hh = restate.get_wh(12, 16)
+    m = torch.stack((Hh, W, torch.ones_like(W)), 1)
+    torch.manual_seed(3)
+    samples = torch.randint(len(m), (300, 4))
+    Hb, cnt, inl, _ = restate.ransac(m, m, 0.05, samples)
+    assert inl.all() and int(cnt) == len(m)
+    Hn = Hb / Hb[2, 2]
+    assert np.abs(Hn - np.eye(3)).max() < 1e-4
+
+
+# ---------------------------------------------------------------- mutual matching
+
+
+def test_mutual_matching_matches_golden():
+    g = gold("mutual.npz")
+    i1, i2 = restate.mutual_matching(torch.from_numpy(g["A"]), torch.from_numpy(g["B"]))
+    assert np.array_equal(i1.numpy(), g["index1"]) and np.array_equal(i2.numpy(), g["index2"])
+    assert (np.diff(g["index1"]) > 0).all()
+    assert not np.isin(g["index2"], np.arange(5, 20)).any()   # masked (all-zero) columns never match
+
+
+# ---------------------------------------------------------------- networks
+
+
+def test_trunk_and_fine_nets_match_golden():
+    g = gold("nets.npz")
+    with torch.no_grad():
+        t = restate.resnet50_trunk(weights.resnet50_trunk_sd(seed=31, randomize_bn=True), torch.from_numpy(g["trunk_in"]))
+    scale = np.abs(g["trunk_out"]).max()
+    assert np.abs(t.numpy() - g["trunk_out"]).max() <= 2e-5 * scale
+    fe = weights.feature_extractor_sd(seed=32, randomize_bn=True)
+    nf = weights.net_flow_coarse_sd(seed=33, randomize_bn=True)
+    nm = weights.net_matchability_sd(seed=34, randomize_bn=True, last_std=0.02)
+    with torch.no_grad():
+        fa = F.normalize(restate.feature_extractor(fe, torch.from_numpy(g["fine_xa"])))
+        fb = F.normalize(restate.feature_extractor(fe, torch.from_numpy(g["fine_xb"])))
+        assert np.abs(fa.numpy() - g["fine_fa"]).max() < 2e-6
+        c12 = restate.corr_neigh(fa, fb)
+        assert np.abs(c12.numpy() - g["fine_corr"]).max() < 2e-6
+        gc = torch.from_numpy(g["fine_corr"])
+        assert np.abs(restate.net_flow_coarse(nf, gc, False).numpy() - g["fine_flow"]).max() < 1e-6
+        assert np.abs(restate.net_flow_coarse(nf, gc, True).numpy() - g["fine_flow8"]).max() < 1e-6
+        assert np.abs(restate.net_matchability(nm, gc, False).numpy() - g["fine_match"]).max() < 1e-6
+        grid = restate.identity_grid(48, 64)
+        fg, fc = restate.pred_flow_coarse(nf, gc, grid, True)
+        assert np.abs(fg.numpy() - g["fine_flowGrad"]).max() < 1e-6
+        assert np.abs(fc.numpy() - g["fine_flowCoarse"]).max() < 1e-6
+
+
+def test_corr_neigh_centre_tap_is_one_for_normalised_features():
+    f = F.normalize(torch.randn(1, 32, 5, 6), dim=1)
+    c = restate.corr_neigh(f, f)
+    assert torch.allclose(c[:, 24], torch.ones(1, 5, 6), atol=1e-6)
+    assert c[0, 0, 0, 0] == 0  # top-left tap of the top-left pixel reads the zero padding
+
+
+def test_flow_head_uniform_logits_give_zero_flow():
+    sd = weights.net_flow_coarse_sd(seed=2)
+    sd = {k: (torch.zeros_like(v) if k == "conv4.weight" else v) for k, v in sd.items()}
+    flow = restate.net_flow_coarse(sd, torch.randn(1, 49, 6, 8), False)
+    assert flow.abs().max() < 1e-7
+
+
+def test_warp_and_sample_match_golden():
+    g = gold("nets.npz")
+    wg = restate.warp_grid(torch.from_numpy(g["warp_H"]), 48, 64)
+    assert np.abs(wg.numpy() - g["warp_grid"]).max() < 1e-6
+    out = restate.grid_sample(torch.from_numpy(g["fine_xa"]), wg)
+    assert np.abs(out.numpy() - g["warp_sample"]).max() < 1e-6
+    ident = restate.grid_sample(torch.from_numpy(g["fine_xa"]), _ac_false_identity(48, 64))
+    assert np.abs(ident.numpy() - g["fine_xa"]).max() < 1e-6
+
+
+def _ac_false_identity(h, w):
+    xs = (torch.arange(w, dtype=torch.float32) + 0.5) / w * 2 - 1
+    ys = (torch.arange(h, dtype=torch.float32) + 0.5) / h * 2 - 1
+    return torch.stack((xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w)), -1)[None]
+
+
+# ---------------------------------------------------------------- config 1 end to end (CPU reference path)
+
+
+def test_config1_coarse_to_fine_matches_reference_golden():
+    g = gold("config1.npz")
+    I1, I2 = synth.make_pair(240, 320, seed=0)
+    ca = restate.CoarseAlignOracle(weights.resnet50_trunk_sd(seed=0), 7, 100, 0.05, 320, 1.2, variant="A")
+    assert np.allclose(ca.scaleList, g["scaleList"])
+    ca.setSource(I1)
+    ca.setTarget(I2)
+    assert ca.featsMultiScale.shape[1] == 2107 and ca.featt.shape[2:] == (15, 20)
+    torch.manual_seed(123)
+    r = ca.getCoarse(np.zeros((240, 320)))
+    assert np.array_equal(r["index1"], g["index1"]) and np.array_equal(r["index2"], g["index2"])
+    assert np.abs(r["H"] - g["H"]).max() <= 1e-6
+    assert np.array_equal(r["inlierMask"], g["inlierMask"])
+    nets = dict(feat=weights.feature_extractor_sd(seed=1), flow=weights.net_flow_coarse_sd(seed=2))
+    with torch.no_grad():
+        flowCoarse = restate.warp_grid(torch.from_numpy(r["H"])[None], 240, 320)
+        st = restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, flowCoarse)
+    assert np.abs(st["flowDown"].numpy() - g["flowDown"]).max() < 1e-5
+    assert np.abs(st["flow12"][:, ::8, ::8].numpy() - g["flow12_sub"]).max() < 1e-4
+
+
+# ---------------------------------------------------------------- C ABI surface
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rfx_api.h")).read()
+    declared = set(re.findall(r"\b(rfx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rfx_version().decode().startswith("rfx ")
+    assert lib.rfx_mutual_nn_ws_bytes(8531, 1200) > 0 and lib.rfx_ransac_ws_bytes(900, 1000) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    from rfx import ops
+    with pytest.raises(RuntimeError):
+        ops.corr_neigh(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4))
+    with pytest.raises(RuntimeError):
+        ops.ransac_h4(torch.zeros(8, 3), torch.zeros(8, 3), torch.zeros(4, 4, dtype=torch.int64), 0.05)
