@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- aligned image pairs / s at 480x640 on N MI355X (one process per GPU).
+
+A "step" = one pass of the whole hot path over one batch of synthetic pairs already resident in HBM:
+ResNet-50 conv4 features of the 7-level source pyramid + target -> L2 norm -> all-pairs correlation +
+mutual NN -> 4-point DLT RANSAC (nbIter hypotheses) -> homography grid -> warp -> FeatureExtractor x2 ->
+7x7 local correlation -> NetFlowCoarse -> flow composition -> final warp  (the quick_start/align2images.py
+path, BASELINE configs 2+3 at the metric's resolution).  float32 end to end.
+
+N > 1: launched by torch.distributed.run, one rank per GPU over RCCL; every rank aligns its own batch per
+step (pairs shard embarrassingly: weak scaling) and the per-pair result records (H + flowDown8) are
+collected with ONE all_gather per step.
+
+Prints one JSON line on rank 0 (see the driver's contract): value = pairs/s over all ranks, plus
+  roofline     -- dominant kernel (conv2d_mfma_kernel<2,2>, fp32 MFMA bound): algorithmic FLOP per launch /
+                  average launch duration, measured with HIP events on the launch stream inside the timed
+                  region; roofline_corr -- same for the HBM-bound 7x7 correlation kernel;
+  cpu_baseline -- the CPU oracle (oracle/restate.py, a port of the reference path) on this host's cores,
+                  rank 0 / N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 matrix peak)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
+
+
+def cpu_baseline(sds, args):
+    """Bounded CPU sample: the oracle restatement on `cpu_pairs` pairs of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate
+    from rfx import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    H, W = args.height, args.width
+    ca = restate.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
+    nets = dict(feat=sds["feat"], flow=sds["flow"])
+
+    def one(seed):
+        I1, I2 = synth.make_pair(H, W, seed=seed)
+        ca.setSource(I1)
+        ca.setTarget(I2)
+        r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
+        with torch.no_grad():
+            fc = restate.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
+            restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
+
+    one(1000)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_pairs:
+        one(2000 + n)
+        n += 1
+        if time.perf_counter() - t0 > 25:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic %dx%d pairs, full coarse+fine path (oracle/restate.py), %.1f s" % (n, H, W, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--nb-scale", type=int, default=7)
+    ap.add_argument("--nb-iter", type=int, default=1000)
+    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rfx import weights, synth, ops
+    from rfx.pipeline import AlignPipeline
+    from rfx import dist as rdist
+
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1),
+               flow=weights.net_flow_coarse_sd(2), match=weights.net_matchability_sd(3))
+    H, W, B = args.height, args.width, args.batch
+    pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
+                         variant="A", device=dev)
+    # this rank's shard of the synthetic stream: pair i -> rank i mod world
+    pairs = [synth.make_pair(H, W, seed=rank + world * i) for i in range(B)]
+    prep = pipe.prepare(pairs)          # host PIL pyramid + upload: outside the timed region (inputs resident in HBM)
+    torch.manual_seed(123 + rank)
+
+    def step():
+        res = pipe.align_prepared(prep, fine=True)
+        rec = rdist.pack_records(res)                       # (B, 9 + 1 + 2*h8*w8) float32 on device
+        return rdist.gather_records(rec, dist)              # ONE all_gather per step (no-op copy when world == 1)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.ConvPlan.timer, ops.corr_neigh.timer = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    conv_t, corr_t = ops.ConvPlan.timer, ops.corr_neigh.timer
+    ops.ConvPlan.timer = ops.corr_neigh.timer = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok_pairs = int((out[:, 9] == 0).sum().item())
+
+    # ---- roofline of the dominant kernel (events were recorded on the launch stream inside the timed region)
+    dom = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1) in conv_t if v == 0]
+    allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1) in conv_t]
+    if not dom:
+        dom = allc
+    flops_per_launch = sum(f for f, _ in dom) / len(dom)
+    avg_dur = sum(d for _, d in dom) / len(dom)
+    ach = flops_per_launch / avg_dur / 1e12
+    roofline = {"kernel": "conv2d_mfma_kernel<2,2>", "bound": "mfma", "achieved": round(ach, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches": len(dom), "avg_launch_us": round(avg_dur * 1e6, 2),
+                "flop_per_launch": flops_per_launch,
+                "all_conv_tflops": round(sum(f for f, _ in allc) / sum(d for _, d in allc) / 1e12, 2),
+                "conv_time_share": round(sum(d for _, d in allc) / elapsed, 3)}
+    cb = sum(b for b, _, _ in corr_t) / len(corr_t)
+    cd = sum(e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in corr_t) / len(corr_t)
+    roofline_corr = {"kernel": "corr7_dma_kernel", "bound": "hbm", "achieved": round(cb / cd / 1e9, 1),
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cb / cd / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                     "bytes_per_launch": cb, "avg_launch_us": round(cd * 1e6, 2)}
+
+    if rank == 0:
+        total_pairs = B * args.steps * world
+        line = {
+            "metric": "aligned image-pairs/sec @480x640", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batch of %d %dx%d pairs per GPU per step, full pipeline: ResNet-50 conv4 feat x%d scales"
+                                   " + mutual NN + RANSAC(nbIter=%d, 4-pt DLT) + FeatureExtractor + 7x7 corr + NetFlowCoarse"
+                                   " + grid_sample (BASELINE configs 2+3 at the metric's 480x640)" % (B, H, W, args.nb_scale, args.nb_iter),
+                       "pairs_per_step_per_gpu": B, "nbIter": args.nb_iter, "nbScale": args.nb_scale,
+                       "parallelism": "pairs sharded over %d rank(s), one all_gather of result records per step" % world,
+                       "weights": "random-init", "aligned_ok_last_step": ok_pairs},
+            "roofline": roofline, "roofline_corr": roofline_corr,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sds, args)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,11 @@ int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const 
                    const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
                    int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream);
 
+/* Which tile configuration rfx_conv2d_f32 launches for an output of (N, Cout, Hout, Wout):
+ * 0 = 128x128 (kernel conv2d_mfma_kernel<2,2>), 1 = 64x128 (<1,2>), 2 = 64x64 (<1,1>).  Lets a profiler-side
+ * caller attribute algorithmic FLOPs to the kernel instance rocprofv3 reports. */
+int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
+
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;
  * model/model.py:71: k=2,s=1,p=0).  Hout = (Hin+2p-k)/s+1. */
 int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int k, int stride,

@@ -184,6 +184,17 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return RFX_OK;
 }
 
+// tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
+// 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
+extern "C" int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout) {
+    const long long P = (long long)N * Hout * Wout;
+    const long long b22 = (long long)((Cout + 127) / 128) * ((P + 127) / 128);
+    const long long b12 = (long long)((Cout + 63) / 64) * ((P + 127) / 128);
+    if (Cout > 64 && b22 >= 512) return 0;
+    if (b12 >= 512 || P >= 8192) return 1;
+    return 2;
+}
+
 extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
                               const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
                               int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
@@ -203,10 +214,9 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     a.Mpad = (Cout + 127) / 128 * 128;
     a.P = (long long)N * a.Hout * a.Wout;
     hipStream_t st = rfx_stream(stream);
-    // tile choice: largest tile that still gives >= ~2 workgroups per CU (256 CUs)
-    const long long b22 = (long long)((Cout + 127) / 128) * ((a.P + 127) / 128);
-    const long long b12 = (long long)((Cout + 63) / 64) * ((a.P + 127) / 128);
-    if (Cout > 64 && b22 >= 512) return launch_conv<2, 2>(a, st);
-    if (b12 >= 512 || a.P >= 8192) return launch_conv<1, 2>(a, st);
-    return launch_conv<1, 1>(a, st);
+    switch (rfx_conv2d_tile_variant(N, Cout, a.Hout, a.Wout)) {
+        case 0: return launch_conv<2, 2>(a, st);
+        case 1: return launch_conv<1, 2>(a, st);
+        default: return launch_conv<1, 1>(a, st);
+    }
 }

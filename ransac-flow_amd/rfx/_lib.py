@@ -15,6 +15,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "librfx.so"))
 SIGNATURES = {
     "rfx_version": (c_char_p, []),
     "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
+    "rfx_conv2d_tile_variant": (c_int, [c_int] * 4),
     "rfx_maxpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rfx_blurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_l2norm_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),

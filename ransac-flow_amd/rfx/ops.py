@@ -34,6 +34,9 @@ def _p(t):
 class ConvPlan:
     """Packed weights + folded BatchNorm of one convolution (see rfx_conv2d_f32 in include/rfx_api.h)."""
 
+    # bench.py sets this to a list to collect (variant, flops, start_event, end_event) per launch
+    timer = None
+
     def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5):
         # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None
         w = weight.detach().float().cpu()
@@ -71,10 +74,19 @@ class ConvPlan:
         res = _dev(residual, "residual") if residual is not None else None
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
-        rc = _lib.load().rfx_conv2d_f32(_p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift), _p(res),
-                                        _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
-                                        self.act if act is None else act, _stream())
+        lib = _lib.load()
+        tm = ConvPlan.timer
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = lib.rfx_conv2d_f32(_p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift), _p(res),
+                                _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
+                                self.act if act is None else act, _stream())
         _lib.check(rc, "rfx_conv2d_f32")
+        if tm is not None:
+            e1.record()
+            flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
+            tm.append((lib.rfx_conv2d_tile_variant(N, self.Cout, Ho, Wo), flops, e0, e1))
         return out
 
 
@@ -139,8 +151,18 @@ def corr_neigh(x, y, K=7):
         raise ValueError("corr_neigh: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
     N, C, H, W = x.shape
     out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
+    tm = corr_neigh.timer
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().rfx_corr_neigh_f32(_p(x), _p(y), _p(out), N, C, H, W, K, _stream()), "rfx_corr_neigh_f32")
+    if tm is not None:
+        e1.record()
+        tm.append(((2 * C + K * K) * 4.0 * N * H * W, e0, e1))  # algorithmic bytes, events
     return out
+
+
+corr_neigh.timer = None
 
 
 def warp_grid(Hm, h, w):

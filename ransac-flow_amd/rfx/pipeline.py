@@ -1,0 +1,212 @@
+"""Batched coarse-to-fine alignment of image pairs on one MI355X.
+
+Restructures the reference's per-pair, host-driven flow (quick_start/align2images.py:53-97 on top of
+quick_start/coarseAlignFeatMatch.py:92-173) for throughput: all pairs of a batch go through every
+network layer in ONE launch per layer and pyramid scale (batch dimension = pairs), normalised features
+are written straight into the concatenated (1024, nA) match matrix, and the host synchronises twice per
+batch (match counts -> RANSAC index draw; final results) instead of >= 3 times per 100 RANSAC
+hypotheses.  Semantics per pair are the reference's (variant A: ResizeMaxSize, or B: ResizeMinSize).
+
+Host-side work that stays on the CPU: PIL LANCZOS pyramid + ToTensor/Normalize.
+``prepare()`` does it and uploads; everything after runs on the device.
+"""
+import numpy as np
+import torch
+import PIL.Image as Image
+
+from . import ops
+from .nets import ResNet50Trunk, FeatureExtractorNet, NetFlowCoarseNet, NetMatchabilityNet
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def scale_list(nb_scale, scale_r):
+    """quick_start/coarseAlignFeatMatch.py:70-74."""
+    if nb_scale == 1:
+        return [1]
+    half = nb_scale // 2 + 1
+    return np.linspace(scale_r, 1, half).tolist() + np.linspace(1, 1 / scale_r, half).tolist()[1:]
+
+
+def resize_dims(w, h, min_size, mode, stride=16):
+    """ResizeMaxSize (quick_start/coarseAlignFeatMatch.py:80-90) / ResizeMinSize
+    (evaluation/evalHpatch/coarseAlignFeatMatch.py:90-100)."""
+    f = max if mode == "max" else min
+    ratio = f(w / float(min_size), h / float(min_size))
+    nw, nh = int(round(w / ratio)), int(round(h / ratio))
+    return nw // stride * stride, nh // stride * stride
+
+
+def pil_to_tensor(pil):
+    arr = np.asarray(pil, dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().float().div(255)
+
+
+def cell_coords(n_rows, n_cols, device):
+    """outil.getWHTensor (utils/outil.py:21-24): (W = row coordinate, H = column coordinate)."""
+    r = (torch.arange(n_rows, dtype=torch.float32, device=device) + 0.5) / n_rows
+    c = (torch.arange(n_cols, dtype=torch.float32, device=device) + 0.5) / n_cols
+    W = r.view(-1, 1).expand(n_rows, n_cols).reshape(-1)
+    Hh = c.view(1, -1).expand(n_rows, n_cols).reshape(-1)
+    return (W - 0.5) * 2, (Hh - 0.5) * 2
+
+
+class AlignPipeline:
+    def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
+                 device="cuda", kernelSize=7):
+        self.dev = torch.device(device)
+        self.trunk = ResNet50Trunk(sds["trunk"], self.dev)
+        self.feat = FeatureExtractorNet(sds["feat"], self.dev) if "feat" in sds else None
+        self.flow = NetFlowCoarseNet(sds["flow"], kernelSize, self.dev) if "flow" in sds else None
+        self.match = NetMatchabilityNet(sds["match"], kernelSize, self.dev) if "match" in sds else None
+        self.nbIter, self.tol, self.minSize = nbIter, tolerance, minSize
+        self.variant = variant
+        self.scaleList = scale_list(nbScale, scaleR)
+        self.mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+        self.std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+
+    # ---------------------------------------------------------------- host pre-processing
+    def _resize(self, I, size):
+        w, h = I.size
+        nw, nh = resize_dims(w, h, size, "max" if self.variant == "A" else "min")
+        return I.resize((nw, nh), resample=Image.LANCZOS)
+
+    def prepare(self, pairs):
+        """pairs: list of (Is, It) PIL images, all of one size.  Returns device-resident inputs."""
+        nS = len(self.scaleList)
+        src = [[] for _ in range(nS)]
+        tgt, IsT, ItT = [], [], []
+        for Is_org, It_org in pairs:
+            pyr = [self._resize(Is_org, int(self.minSize * s)) for s in self.scaleList]
+            for i, im in enumerate(pyr):
+                src[i].append(pil_to_tensor(im))
+            IsT.append(src[nS // 2][-1])
+            It = self._resize(It_org, self.minSize)
+            tgt.append(pil_to_tensor(It))
+        norm = lambda lst: ((torch.stack(lst) - self.mean) / self.std).to(self.dev)
+        return dict(src=[norm(s) for s in src], tgt=norm(tgt), IsTensor=torch.stack(IsT).to(self.dev),
+                    ItTensor=torch.stack(tgt).to(self.dev), B=len(pairs))
+
+    # ---------------------------------------------------------------- coarse stage
+    def features(self, prep):
+        """ResNet-50 conv4 features of every pyramid level and of the target, L2-normalised, written into
+        featA (B,1024,nA) / featB (B,1024,nB) (quick_start/coarseAlignFeatMatch.py:92-125)."""
+        B = prep["B"]
+        dims = [(x.shape[2] // 16, x.shape[3] // 16) for x in prep["src"]]
+        nA = sum(r * c for r, c in dims)
+        featA = torch.empty((B, 1024, nA), dtype=torch.float32, device=self.dev)
+        Ws, Hs = [], []
+        off = 0
+        for x, (r, c) in zip(prep["src"], dims):
+            f = self.trunk(x)
+            ops.l2norm(f, out=featA[:, :, off:], out_batch_stride=1024 * nA, out_chan_stride=nA)
+            W, Hh = cell_coords(r, c, self.dev)
+            Ws.append(W)
+            Hs.append(Hh)
+            off += r * c
+        ft = ops.l2norm(self.trunk(prep["tgt"]))
+        rt, ct = ft.shape[2], ft.shape[3]
+        Wt, Ht = cell_coords(rt, ct, self.dev)
+        return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
+                    Wt=Wt, Ht=Ht, rt=rt, ct=ct)
+
+    def coarse(self, prep, feats=None, samples=None, maskB=None):
+        """Per pair: mutual NN -> matches -> RANSAC.  ``samples``: optional list of (nbIter,4) int64 CPU tensors
+        (explicit index draw); default = torch.randint on the CPU generator per pair, in pair order, which is
+        what utils/outil.py:120 draws on a CPU run.  Returns a list of per-pair dicts (device tensors)."""
+        feats = feats or self.features(prep)
+        B = prep["B"]
+        lib_out = []
+        # phase 1: all mutual-NN launches, one sync for the counts
+        pend = []
+        for b in range(B):
+            pend.append(self._mutual_async(feats["featA"][b], feats["featB"][b], feats["nA"], feats["nB"],
+                                           None if maskB is None else maskB[b]))
+        counts = torch.cat([p[2] for p in pend]).cpu().tolist()  # <- sync #1
+        # phase 2: index draw on the host, RANSAC launches
+        for b in range(B):
+            n = counts[b]
+            i1, i2 = pend[b][0][:n], pend[b][1][:n]
+            res = dict(index1=i1, index2=i2, H=None, inlier=None, samples=None, n=n)
+            if n >= 4:
+                ones = torch.ones(n, dtype=torch.float32, device=self.dev)
+                m1 = torch.stack((feats["HA"][i1], feats["WA"][i1], ones), dim=1)
+                m2 = torch.stack((feats["Ht"][i2], feats["Wt"][i2], ones), dim=1)
+                s = samples[b] if samples is not None else torch.randint(n, (self.nbIter, 4))
+                sd = s.to(self.dev)
+                bestH, inl, r = ops.ransac_h4(m1, m2, sd, self.tol)
+                res.update(match1=m1, match2=m2, samples=s, _H=bestH, _inl=inl, _res=r)
+            lib_out.append(res)
+        stat = [r["_res"] for r in lib_out if "_res" in r]
+        if stat:
+            st = torch.stack(stat).cpu().tolist()  # <- sync #2
+            k = 0
+            for r in lib_out:
+                if "_res" in r:
+                    status, cnt, widx, nuniq = st[k]
+                    k += 1
+                    r["status"], r["count"], r["winner"], r["nUnique"] = status, cnt, widx, nuniq
+                    if status == 0:
+                        r["H"], r["inlier"] = r["_H"], r["_inl"]
+        return lib_out
+
+    def _mutual_async(self, fa, fb, nA, nB, mask):
+        from . import _lib
+        lib = _lib.load()
+        ws = torch.empty(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=self.dev)
+        cap = min(nA, nB)
+        idx1 = torch.empty(cap, dtype=torch.int64, device=self.dev)
+        idx2 = torch.empty(cap, dtype=torch.int64, device=self.dev)
+        count = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        rc = lib.rfx_mutual_nn_f32(ops._p(fa), nA, nA, ops._p(fb), nB, nB, 1024, ops._p(mask), ops._p(idx1), ops._p(idx2),
+                                   ops._p(count), ops._p(ws), ops._stream())
+        _lib.check(rc, "rfx_mutual_nn_f32")
+        return idx1, idx2, count, ws
+
+    # ---------------------------------------------------------------- fine stage
+    def fine_quickstart(self, prep, Hs):
+        """quick_start/align2images.py:61-97 for a batch: Hs (B,3,3) device tensor."""
+        B, _, h, w = prep["ItTensor"].shape
+        flowCoarse = ops.warp_grid(Hs, h, w)
+        img1_coarse = ops.grid_sample(prep["IsTensor"], flowCoarse)
+        f = ops.l2norm(self.feat(torch.cat((img1_coarse, prep["ItTensor"]), dim=0)))
+        feat1, feat2 = f[:B], f[B:]
+        corr12 = ops.corr_neigh(feat1, feat2)
+        flowDown = self.flow(corr12, False)
+        flow12, _, _ = ops.compose_flow(flowDown, flowCoarse, clamp=False)
+        img1_fine = ops.grid_sample(prep["IsTensor"], flow12)
+        return dict(flowCoarse=flowCoarse, img1_coarse=img1_coarse, feat1=feat1, feat2=feat2, corr12=corr12,
+                    flowDown=flowDown, flow12=flow12, img1_fine=img1_fine)
+
+    def pred_flow_mask(self, IsTensor, featt, flowCoarse):
+        """evaluation/evalHpatch/evaluation.py:23-55 (PredFlowMask) for a batch."""
+        IsSample = ops.grid_sample(IsTensor, flowCoarse)
+        feats = ops.l2norm(self.feat(IsSample))
+        corr12 = ops.corr_neigh(featt, feats)
+        flowDown8 = self.flow(corr12, False)
+        match12Down8 = self.match(corr12, False)
+        corr21 = ops.corr_neigh(feats, featt)
+        match21Down8 = self.match(corr21, False)
+        H, W = flowCoarse.shape[1], flowCoarse.shape[2]
+        match12 = ops.resize_bilinear(match12Down8, (H, W), align_corners=False)
+        flow12, inb, _ = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True)
+        match = match12 * inb.unsqueeze(1)
+        return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
+                    match21Down8=match21Down8)
+
+    # ---------------------------------------------------------------- whole path
+    def align_prepared(self, prep, fine=True, samples=None):
+        res = self.coarse(prep, samples=samples)
+        if fine:
+            eye = torch.eye(3, device=self.dev)
+            Hs = torch.stack([r["H"] if r["H"] is not None else eye for r in res])
+            f = self.fine_quickstart(prep, Hs)
+            for b, r in enumerate(res):
+                r["flow12"] = f["flow12"][b:b + 1]
+                r["img1_fine"] = f["img1_fine"][b:b + 1]
+                r["flowDown"] = f["flowDown"][b:b + 1]
+        return res
+
+    def align_pairs(self, pairs, fine=True, samples=None):
+        return self.align_prepared(self.prepare(pairs), fine=fine, samples=samples)

@@ -1,0 +1,58 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding + single-gather code of rfx.dist."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
+    import torch.distributed as dist
+    from rfx import dist as rdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_items, h8, w8 = 6, 3, 4
+    mine = rdist.shard_indices(n_items, rank, world)
+    res = []
+    for i in mine:  # fake per-pair results: H = i * ones, flow = i + arange
+        ok = (i != 3)
+        res.append(dict(H=torch.full((3, 3), float(i)) if ok else None,
+                        flowDown=torch.arange(2 * h8 * w8, dtype=torch.float32).view(1, 2, h8, w8) + i))
+    rec = rdist.pack_records(res)
+    assert rec.shape == (len(mine), rdist.record_width(h8, w8))
+    out = rdist.gather_records(rec, dist)
+    q.put((rank, out.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_single_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
+    from rfx import dist as rdist
+    assert torch.equal(outs[0], outs[1])                       # every rank holds the full result set
+    perm = rdist.unshard_order(6, world)
+    assert sorted(perm) == list(range(6))
+    g = outs[0]
+    for k, item in enumerate(perm):
+        if item == 3:
+            assert g[k, 9] == 1 and g[k, :9].abs().sum() == 0   # failed pair: status 1, zero H
+        else:
+            assert g[k, 9] == 0 and (g[k, :9] == item).all()
+        assert g[k, 10] == item                                # first flow element = item id
+    assert rdist.shard_indices(7, 1, 3) == [1, 4]
+    assert torch.equal(rdist.gather_records(g, None), g)       # single process: identity

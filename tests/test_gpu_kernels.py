@@ -1,0 +1,285 @@
+"""Stage-wise parity: every librfx kernel (through the C ABI) against the CPU oracle on the same seeded
+inputs, plus the reference golden vectors.  Needs a real MI355X: run with ``-m gpu``.
+
+Tolerances: integer / index outputs bit exact; float32 outputs within round-off of the value range
+(stated per test).  Where a float near-tie could flip an arg-max the test verifies that every
+disagreement IS such a near-tie (margin check in float64) and bounds their rate."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import restate
+from rfx import ops, nets, weights
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------ conv family
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, bn, res, act
+    (1, 3, 64, 96, 64, 7, 2, 3, True, False, 1),      # ResNet conv1
+    (2, 64, 16, 24, 64, 1, 1, 0, True, False, 1),     # bottleneck 1x1
+    (2, 64, 16, 24, 256, 1, 1, 0, True, True, 1),     # 1x1 + residual
+    (1, 128, 17, 23, 128, 3, 2, 1, True, False, 1),   # strided 3x3, odd sizes
+    (1, 256, 8, 12, 512, 1, 2, 0, True, False, 0),    # strided 1x1 downsample
+    (3, 49, 12, 16, 512, 3, 1, 1, True, False, 1),    # head conv1
+    (1, 128, 12, 16, 49, 3, 1, 1, False, False, 0),   # head conv4 (Cout=49)
+    (1, 128, 12, 16, 1, 3, 1, 1, False, False, 2),    # matchability conv4 + sigmoid
+    (1, 3, 40, 56, 64, 3, 1, 1, True, False, 1),      # FeatureExtractor conv1 (K=27)
+    (4, 256, 30, 40, 256, 3, 1, 1, True, True, 1),    # layer3-like 3x3 (<2,2> / <1,2> tiles)
+    (16, 256, 30, 40, 1024, 1, 1, 0, True, True, 1),  # big enough for the 128x128 tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_cpu(dev, case):
+    N, Cin, H, W, Cout, k, stride, pad, bn, res, act = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bnd = None
+    if bn:
+        bnd = dict(weight=1 + 0.3 * torch.randn(Cout, generator=g), bias=0.2 * torch.randn(Cout, generator=g),
+                   running_mean=0.2 * torch.randn(Cout, generator=g), running_var=0.5 + torch.rand(Cout, generator=g))
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    if bn:
+        ref = F.batch_norm(ref, bnd["running_mean"], bnd["running_var"], bnd["weight"], bnd["bias"], False, 0.0, 1e-5)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = torch.sigmoid(ref)
+    plan = ops.ConvPlan(w, bnd, stride, pad, act, dev)
+    out = plan(x.to(dev), residual=r.to(dev) if res else None)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert relerr(out, ref) < 2e-5, relerr(out, ref)
+
+
+def test_pools_norm_head_resize(dev):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 19, 26, generator=g)
+    xd = x.to(dev)
+    assert torch.equal(ops.maxpool2d(xd, 3, 2, 1).cpu(), F.max_pool2d(x, 3, 2, 1))
+    assert torch.equal(ops.maxpool2d(xd, 2, 1, 0).cpu(), F.max_pool2d(x, 2, 1))
+    for s in (1, 2):
+        assert (ops.blurpool2d(xd, s).cpu() - restate.blur_pool(x, s)).abs().max() < 1e-6
+    f = torch.randn(2, 1024, 3, 5, generator=g)
+    assert (ops.l2norm(f.to(dev)).cpu() - F.normalize(f)).abs().max() < 1e-6
+    z = torch.zeros(1, 8, 2, 2)
+    assert torch.equal(ops.l2norm(z.to(dev)).cpu(), F.normalize(z))        # eps path: 0 / 1e-12
+    # strided scatter into a concatenated (C, nA) matrix
+    buf = torch.zeros(2, 1024, 40, device=dev)
+    ops.l2norm(f.to(dev), out=buf[:, :, 7:], out_batch_stride=1024 * 40, out_chan_stride=40)
+    assert (buf[:, :, 7:22].cpu() - F.normalize(f).view(2, 1024, 15)).abs().max() < 1e-6
+    assert buf[:, :, :7].abs().max() == 0 and buf[:, :, 22:].abs().max() == 0
+    lg = torch.randn(2, 49, 6, 9, generator=g) * 3
+    p = F.softmax(lg, dim=1)
+    off = torch.arange(-3, 4, dtype=torch.float32)
+    fx = (p * off.view(1, 7).expand(7, 7).reshape(1, 49, 1, 1)).sum(1, keepdim=True) / 9 * 2
+    fy = (p * off.view(7, 1).expand(7, 7).reshape(1, 49, 1, 1)).sum(1, keepdim=True) / 6 * 2
+    assert (ops.flow_head(lg.to(dev)).cpu() - torch.cat((fx, fy), 1)).abs().max() < 1e-6
+    assert ops.flow_head(torch.zeros(1, 49, 4, 4, device=dev)).abs().max() < 1e-7      # KAT: uniform logits -> 0
+    m = torch.rand(2, 3, 6, 8, generator=g)
+    for ac, size in ((False, (48, 64)), (False, (41, 67)), (True, (48, 64))):
+        ref = F.interpolate(m, size=size, mode="bilinear", align_corners=ac)
+        assert (ops.resize_bilinear(m.to(dev), size, ac).cpu() - ref).abs().max() < 1e-6
+
+
+# ------------------------------------------------------------------ 7x7 local correlation
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 60, 80), (1, 16, 10, 12), (3, 64, 70, 20), (1, 8, 9, 11), (1, 256, 41, 136)])
+def test_corr_neigh_matches_cpu(dev, shape):
+    g = torch.Generator().manual_seed(shape[2])
+    x = F.normalize(torch.randn(*shape, generator=g), dim=1)
+    y = F.normalize(torch.randn(*shape, generator=g), dim=1)
+    ref = restate.corr_neigh(x, y)
+    out = ops.corr_neigh(x.to(dev), y.to(dev)).cpu()
+    assert (out - ref).abs().max() < 1e-5, (out - ref).abs().max()
+    same = ops.corr_neigh(x.to(dev), x.to(dev)).cpu()
+    assert (same[:, 24] - 1).abs().max() < 1e-5                      # KAT: centre tap of normalised features
+    assert same[0, 0, 0, 0] == 0                                     # zero padding
+
+
+def test_corr_neigh_golden(dev):
+    g = gold("nets.npz")
+    out = ops.corr_neigh(torch.from_numpy(g["fine_fa"]).to(dev), torch.from_numpy(g["fine_fb"]).to(dev)).cpu()
+    assert np.abs(out.numpy() - g["fine_corr"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ warping
+
+
+def test_warp_grid_sample_compose(dev):
+    g = gold("nets.npz")
+    Hm = torch.from_numpy(g["warp_H"])
+    wg = ops.warp_grid(Hm.to(dev), 48, 64)
+    assert np.abs(wg.cpu().numpy() - g["warp_grid"]).max() < 1e-6
+    xa = torch.from_numpy(g["fine_xa"])
+    out = ops.grid_sample(xa.to(dev), wg)
+    assert np.abs(out.cpu().numpy() - g["warp_sample"]).max() < 1e-6
+    # random grids incl. out-of-range coordinates, both align modes, multi-batch
+    gen = torch.Generator().manual_seed(4)
+    img = torch.rand(2, 3, 17, 23, generator=gen)
+    grid = torch.rand(2, 9, 11, 2, generator=gen) * 2.6 - 1.3
+    for ac in (False, True):
+        ref = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=ac)
+        assert (ops.grid_sample(img.to(dev), grid.to(dev), ac).cpu() - ref).abs().max() < 1e-6
+    # fused compose vs the unfused recipe (align2images.py:92-95 and evalHpatch/evaluation.py:40-45,51)
+    flowDown = (torch.rand(2, 2, 6, 8, generator=gen) - 0.5) * 0.3
+    Hb = torch.stack((Hm[0], torch.tensor([[0.9, 0.1, 0.2], [0.05, 1.1, -0.3], [0.02, 0.01, 1.0]])))
+    coarse = restate.warp_grid(Hb, 48, 64)
+    for clamp in (False, True):
+        up = F.interpolate(flowDown, size=(48, 64), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        up = up + restate.identity_grid(48, 64)
+        if clamp:
+            up = torch.clamp(up, -1, 1)
+        ref = restate.grid_sample(coarse.permute(0, 3, 1, 2), up).permute(0, 2, 3, 1)
+        f12, inb, fup = ops.compose_flow(flowDown.to(dev), coarse.to(dev), clamp=clamp, want_inb=True, want_flow_up=True)
+        assert (fup.cpu() - up).abs().max() < 1e-6
+        assert (f12.cpu() - ref).abs().max() < 2e-6
+        refin = ((ref[..., 0] >= -1) & (ref[..., 0] <= 1) & (ref[..., 1] >= -1) & (ref[..., 1] <= 1)).float()
+        # in-bounds flag may only differ where the reference value sits within round-off of +-1
+        diff = inb.cpu() != refin
+        if diff.any():
+            edge = (ref.abs() - 1).abs().min(dim=-1).values
+            assert (edge[diff] < 1e-5).all()
+
+
+# ------------------------------------------------------------------ mutual nearest neighbours
+
+
+def _mnn_check(dev, A, B, mask=None):
+    Bm = B * mask if mask is not None else B
+    r1, r2 = restate.mutual_matching(A, Bm)
+    o1, o2 = ops.mutual_nn(A.to(dev), B.to(dev), None if mask is None else mask.to(dev))
+    o1, o2 = o1.cpu(), o2.cpu()
+    if torch.equal(o1, r1) and torch.equal(o2, r2):
+        return 0
+    # every disagreement must be a float32 near-tie of the arg-max (margin in float64)
+    S = A.double().t() @ Bm.double()
+    ref = set(zip(r1.tolist(), r2.tolist()))
+    got = set(zip(o1.tolist(), o2.tolist()))
+    bad = ref ^ got
+    for i, j in bad:
+        row, col = S[i], S[:, j]
+        top2r = torch.topk(row, 2).values
+        top2c = torch.topk(col, 2).values
+        assert min((top2r[0] - top2r[1]).item(), (top2c[0] - top2c[1]).item()) < 1e-5, (i, j)
+    assert len(bad) <= max(2, len(ref) // 100)
+    assert (o1[1:] > o1[:-1]).all()
+    return len(bad)
+
+
+def test_mutual_nn_golden_and_random(dev):
+    g = gold("mutual.npz")
+    o1, o2 = ops.mutual_nn(torch.from_numpy(g["A"]).to(dev), torch.from_numpy(g["B"]).to(dev))
+    assert np.array_equal(o1.cpu().numpy(), g["index1"]) and np.array_equal(o2.cpu().numpy(), g["index2"])
+    gen = torch.Generator().manual_seed(5)
+    for (C, nA, nB) in ((1024, 2107, 300), (1024, 531, 1200), (40, 130, 129)):
+        A = F.normalize(torch.relu(torch.randn(C, nA, generator=gen)), dim=0)
+        # plant structure: B columns are noisy copies of some A columns -> many mutual matches
+        pick = torch.randint(nA, (nB,), generator=gen)
+        B = F.normalize(torch.relu(A[:, pick] + 0.3 * torch.randn(C, nB, generator=gen)), dim=0)
+        _mnn_check(dev, A, B)
+        mask = (torch.rand(nB, generator=gen) > 0.3).float()
+        _mnn_check(dev, A, B, mask)
+
+
+# ------------------------------------------------------------------ RANSAC
+
+
+def test_dlt_sign_and_value(dev):
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["m1_1"]), torch.from_numpy(g["m2_1"])
+    torch.manual_seed(17)
+    s = restate.filter_samples(torch.randint(len(m1), (4000, 4)))
+    X, Y = m1[s].contiguous(), m2[s].contiguous()
+    ref = restate.homography_svd(X, Y)
+    out = ops.dlt4_homography(X.to(dev), Y.to(dev)).cpu()
+    A = restate.dlt_matrix(X.numpy(), Y.numpy())
+    sv = np.linalg.svd(A, compute_uv=False)
+    good = torch.from_numpy(sv[:, 7] > 1e-9)
+    assert ((out * ref).sum((1, 2))[good] > 0).all()                 # LAPACK's sign on every rank-8 system
+    assert (out - ref)[good].abs().max() <= 1.2e-7
+    assert ((out.view(-1, 9).norm(dim=1) - 1).abs()[good] < 1e-6).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_score_and_ransac_match_reference_golden(dev, seed):
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["m1_%d" % seed]), torch.from_numpy(g["m2_%d" % seed])
+    samples = torch.from_numpy(g["samples_%d" % seed])
+    uniq = restate.filter_samples(samples)[:300]
+    H21, cnt = ops.score_hypotheses(m1.to(dev), m2.to(dev), uniq.to(dev), 0.05)
+    assert np.abs(H21.cpu().numpy() - g["score_H_%d" % seed]).max() <= 1.2e-7
+    assert np.array_equal(cnt.cpu().numpy(), g["score_counts_%d" % seed])          # per-hypothesis counts: exact
+    bestH, inl, res = ops.ransac_h4(m1.to(dev), m2.to(dev), samples.to(dev), 0.05)
+    res = res.cpu().tolist()
+    assert res[0] == 0 and res[1] == int(g["count_%d" % seed])
+    assert res[3] == len(restate.filter_samples(samples))
+    assert np.array_equal(inl.cpu().numpy(), g["inlier_%d" % seed])                # inlier indices: bit exact
+    assert np.abs(bestH.cpu().numpy() - g["H_%d" % seed]).max() <= 1.2e-7
+    assert samples[res[2]].tolist() in restate.filter_samples(samples).tolist()
+
+
+def test_ransac_sentinels_and_many_seeds(dev):
+    g = gold("ransac.npz")
+    m1, m2 = torch.from_numpy(g["abort_m1"]), torch.from_numpy(g["abort_m2"])
+    s = torch.from_numpy(g["abort_samples"])
+    _, inl, res = ops.ransac_h4(m1.to(dev), m2.to(dev), s.to(dev), -1.0)
+    assert res.cpu().tolist()[0] == 1 and not inl.any()                            # zero-chunk abort
+    _, _, res = ops.ransac_h4(m1.to(dev), m2.to(dev), s[:50].to(dev), -1.0)
+    assert res.cpu().tolist()[0] == 2                                              # the reference's TypeError case
+    # fresh seeds against the oracle run on this host
+    m1, m2 = torch.from_numpy(g["m1_2"]), torch.from_numpy(g["m2_2"])
+    mism = 0
+    for seed in range(20):
+        torch.manual_seed(1000 + seed)
+        s = torch.randint(len(m1), (700, 4))
+        Hb, cnt, inl_ref, _ = restate.ransac(m1, m2, 0.05, s)
+        bestH, inl, res = ops.ransac_h4(m1.to(dev), m2.to(dev), s.to(dev), 0.05)
+        ok = np.array_equal(inl.cpu().numpy(), inl_ref) and res.cpu().tolist()[1] == int(cnt)
+        mism += 0 if ok else 1
+        if ok:
+            assert np.abs(bestH.cpu().numpy() - Hb).max() <= 1.2e-7
+    assert mism == 0, "%d / 20 seeds disagree with the oracle" % mism
+    err = ops.prediction(m1.to(dev), m2.to(dev), torch.from_numpy(g["score_H_2"][:7]).to(dev)).cpu()
+    ref = restate.prediction(m1[None], m2[None], torch.from_numpy(g["score_H_2"][:7]))
+    assert (err - ref).abs().max() <= 2.4e-7
+
+
+# ------------------------------------------------------------------ whole networks
+
+
+def test_networks_match_reference_golden(dev):
+    g = gold("nets.npz")
+    trunk = nets.ResNet50Trunk(weights.resnet50_trunk_sd(seed=31, randomize_bn=True), dev)
+    out = trunk(torch.from_numpy(g["trunk_in"]).to(dev)).cpu().numpy()
+    assert np.abs(out - g["trunk_out"]).max() <= 5e-5 * np.abs(g["trunk_out"]).max()
+    fe = nets.FeatureExtractorNet(weights.feature_extractor_sd(seed=32, randomize_bn=True), dev)
+    fa = ops.l2norm(fe(torch.from_numpy(g["fine_xa"]).to(dev))).cpu().numpy()
+    assert np.abs(fa - g["fine_fa"]).max() < 1e-5
+    nf = nets.NetFlowCoarseNet(weights.net_flow_coarse_sd(seed=33, randomize_bn=True), 7, dev)
+    nm = nets.NetMatchabilityNet(weights.net_matchability_sd(seed=34, randomize_bn=True, last_std=0.02), 7, dev)
+    c = torch.from_numpy(g["fine_corr"]).to(dev)
+    assert np.abs(nf(c, False).cpu().numpy() - g["fine_flow"]).max() < 1e-5
+    assert np.abs(nf(c, True).cpu().numpy() - g["fine_flow8"]).max() < 1e-5
+    assert np.abs(nm(c, False).cpu().numpy() - g["fine_match"]).max() < 1e-5

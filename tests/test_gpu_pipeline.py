@@ -1,0 +1,119 @@
+"""End-to-end parity of the HIP pipeline against the reference's golden outputs (BASELINE config 1:
+quick_start path on one 240x320 synthetic pair, nbIter=100) and against the CPU oracle run on this host
+(config 2 shape, reduced), plus size-independent properties at the full 480x640 size.  ``-m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import restate
+from rfx import weights, synth
+from rfx.pipeline import AlignPipeline
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sds():
+    return dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1),
+                flow=weights.net_flow_coarse_sd(2), match=weights.net_matchability_sd(3))
+
+
+def _match_sets(i1a, i2a, i1b, i2b):
+    a, b = set(zip(i1a.tolist(), i2a.tolist())), set(zip(i1b.tolist(), i2b.tolist()))
+    return len(a ^ b), len(a)
+
+
+def test_config1_against_reference_golden(dev):
+    """The reference itself (CPU, /root/reference) produced tests/golden/config1.npz."""
+    g = np.load(os.path.join(GOLD, "config1.npz"))
+    I1, I2 = synth.make_pair(240, 320, seed=0)
+    pipe = AlignPipeline(_sds(), nbScale=7, nbIter=100, tolerance=0.05, minSize=320, scaleR=1.2, device=dev)
+    prep = pipe.prepare([(I1, I2)])
+    feats = pipe.features(prep)
+    assert feats["nA"] == 2107 and feats["nB"] == 300
+    ft = feats["featB"].view(1, 1024, 15, 20)[0, ::64].cpu().numpy()
+    assert np.abs(ft - g["feat_t_sub"]).max() < 2e-5                                  # trunk + L2 norm
+    torch.manual_seed(123)                                                            # same CPU index draw as the reference run
+    r = pipe.align_prepared(prep, fine=True)[0]
+    ndiff, nref = _match_sets(r["index1"].cpu().numpy(), r["index2"].cpu().numpy(), g["index1"], g["index2"])
+    print("config1: %d matches, %d differ from the reference" % (nref, ndiff))
+    assert ndiff <= max(2, nref // 50)
+    if ndiff == 0:
+        # identical match list + identical index draw -> bit-exact inliers, H to float32 round-off
+        assert r["status"] == 0
+        inl = r["inlier"].cpu().numpy()
+        i2 = r["index2"].cpu().numpy()[inl]
+        mask = np.zeros((15, 20), dtype=np.float32)
+        mask[i2 // 20, i2 % 20] = 1
+        assert np.array_equal(mask, g["inlierMask"])
+        assert np.abs(r["H"].cpu().numpy() - g["H"]).max() <= 1e-6
+        assert np.abs(r["flowDown"].cpu().numpy() - g["flowDown"]).max() < 1e-4
+        d = np.abs(r["flow12"][:, ::8, ::8].cpu().numpy() - g["flow12_sub"]).max()
+        print("config1: max-abs flow delta vs reference = %.3e" % d)
+        assert d < 1e-3                                                               # north-star tolerance
+
+
+def test_fine_stage_against_oracle_given_same_homography(dev):
+    """Flow parity isolated from the match list: feed the oracle's H to both fine stages (320x240)."""
+    I1, I2 = synth.make_pair(240, 320, seed=3)
+    sds = _sds()
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=100, tolerance=0.05, minSize=320, scaleR=1.2, device=dev)
+    prep = pipe.prepare([(I1, I2), (I2, I1)])
+    Hs = torch.tensor([[[1.01, 0.02, 0.03], [-0.015, 0.99, -0.02], [0.01, 0.005, 1.0]],
+                       [[0.98, -0.01, -0.04], [0.02, 1.02, 0.01], [-0.004, 0.01, 1.0]]])
+    f = pipe.fine_quickstart(prep, Hs.to(dev))
+    for b in range(2):
+        with torch.no_grad():
+            fc = restate.warp_grid(Hs[b:b + 1], 240, 320)
+            st = restate.fine_step_quickstart(dict(feat=sds["feat"], flow=sds["flow"]), prep["IsTensor"][b:b + 1].cpu(),
+                                              prep["ItTensor"][b:b + 1].cpu(), fc)
+        assert (f["corr12"][b].cpu() - st["corr12"][0]).abs().max() < 2e-5
+        assert (f["flowDown"][b].cpu() - st["flowDown"][0]).abs().max() < 1e-4
+        d = (f["flow12"][b].cpu() - st["flow12"][0]).abs().max().item()
+        assert d < 1e-3, d
+        assert (f["img1_fine"][b].cpu() - st["img1_fine"][0]).abs().max() < 2e-3
+    # PredFlowMask (evalHpatch variant) on the same inputs
+    featt = None
+    from rfx import ops
+    featt = ops.l2norm(pipe.feat(prep["ItTensor"]))
+    fc_d = ops.warp_grid(Hs.to(dev), 240, 320)
+    pm = pipe.pred_flow_mask(prep["IsTensor"], featt, fc_d)
+    with torch.no_grad():
+        import torch.nn.functional as F
+        ft = F.normalize(restate.feature_extractor(sds["feat"], prep["ItTensor"][:1].cpu()))
+        flow12, match, fd8, md8 = restate.pred_flow_mask(dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]),
+                                                         prep["IsTensor"][:1].cpu(), ft, restate.warp_grid(Hs[:1], 240, 320),
+                                                         restate.identity_grid(240, 320))
+    assert (pm["flow12"][0].cpu() - flow12[0]).abs().max() < 1e-3
+    assert np.abs(pm["match"][0, 0].cpu().numpy() - match).max() < 1e-3
+    assert np.abs(pm["match21Down8"][0].cpu().numpy() - md8[0, 1:2]).max() < 1e-4
+
+
+def test_config2_coarse_480x640_properties(dev):
+    """BASELINE config 2 (one 480x640 pair, coarse only, nbIter=1000): shapes, determinism, known answer.
+    The synthetic target is the source shifted by (12, 8) px, so the recovered homography must be close to
+    that translation in normalised coordinates and explain most matches."""
+    I1, I2 = synth.make_pair(480, 640, seed=0)
+    pipe = AlignPipeline(dict(trunk=weights.resnet50_trunk_sd(0)), nbScale=7, nbIter=1000, tolerance=0.05, minSize=640,
+                         scaleR=1.2, device=dev)
+    prep = pipe.prepare([(I1, I2)])
+    feats = pipe.features(prep)
+    assert feats["nA"] == 8531 and feats["nB"] == 1200
+    torch.manual_seed(123)
+    r1 = pipe.coarse(prep, feats=feats)[0]
+    torch.manual_seed(123)
+    r2 = pipe.coarse(prep, feats=feats)[0]
+    assert r1["status"] == 0
+    assert torch.equal(r1["index1"], r2["index1"]) and torch.equal(r1["inlier"], r2["inlier"])   # run-to-run determinism
+    assert torch.equal(r1["H"], r2["H"])
+    H = r1["H"].cpu().numpy()
+    H = H / H[2, 2]
+    assert abs(H[0, 0] - 1) < 0.05 and abs(H[1, 1] - 1) < 0.05
+    assert abs(H[0, 2] - 2 * 12 / 640) < 0.02 and abs(H[1, 2] - 2 * 8 / 480) < 0.02
+    assert r1["count"] >= 0.5 * r1["n"]
+    # oracle RANSAC on the device's match list with the same index draw: bit-exact inliers
+    Hb, cnt, inl, _ = restate.ransac(r1["match1"].cpu(), r1["match2"].cpu(), 0.05, r1["samples"])
+    assert int(cnt) == r1["count"] and np.array_equal(inl, r1["inlier"].cpu().numpy())
+    assert np.abs(Hb - r1["H"].cpu().numpy()).max() <= 1.2e-7
