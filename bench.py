@@ -34,12 +34,46 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (dense f
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak
 
 
+def log(msg):
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
+def cpu_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, os.cpu_count() or 1, 64))
+
+
+def cpu_baseline_subprocess(args):
+    """Runs the CPU leg in a child process with a hard wall-clock limit so that it can never stall the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(args.height), "--width",
+           str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs",
+           str(args.cpu_pairs)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+        for ln in out.stdout.splitlines():
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "port",
+                "sample": "cpu leg failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "port",
+                "sample": "cpu leg exceeded its 150 s limit"}
+
+
 def cpu_baseline(sds, args):
     """Bounded CPU sample: the oracle restatement on `cpu_pairs` pairs of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import restate
     from rfx import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(cpu_threads())
     H, W = args.height, args.width
     ca = restate.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
     nets = dict(feat=sds["feat"], flow=sds["flow"])
@@ -53,13 +87,15 @@ def cpu_baseline(sds, args):
             fc = restate.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
             restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
 
+    t0 = time.perf_counter()
     one(1000)  # warm-up
+    warm = time.perf_counter() - t0
     t0 = time.perf_counter()
     n = 0
     while n < args.cpu_pairs:
         one(2000 + n)
         n += 1
-        if time.perf_counter() - t0 > 25:
+        if time.perf_counter() - t0 > 25 or (n == 1 and warm > 30):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -78,7 +114,15 @@ def main():
     ap.add_argument("--nb-iter", type=int, default=1000)
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        from rfx import weights
+        sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1),
+                   flow=weights.net_flow_coarse_sd(2))
+        print(json.dumps(cpu_baseline(sds, args)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,16 +148,20 @@ def main():
                          variant="A", device=dev)
     # this rank's shard of the synthetic stream: pair i -> rank i mod world
     pairs = [synth.make_pair(H, W, seed=rank + world * i) for i in range(B)]
+    log("weights packed, synthetic pairs made")
     prep = pipe.prepare(pairs)          # host PIL pyramid + upload: outside the timed region (inputs resident in HBM)
     torch.manual_seed(123 + rank)
+    log("inputs resident on %s" % dev)
 
     def step():
         res = pipe.align_prepared(prep, fine=True)
         rec = rdist.pack_records(res)                       # (B, 9 + 1 + 2*h8*w8) float32 on device
         return rdist.gather_records(rec, dist)              # ONE all_gather per step (no-op copy when world == 1)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log("warmup step %d done" % i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -127,6 +175,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    log("%d timed steps: %.3f s" % (args.steps, elapsed))
     conv_t, corr_t = ops.ConvPlan.timer, ops.corr_neigh.timer
     ops.ConvPlan.timer = ops.corr_neigh.timer = None
     if dist is not None:
@@ -171,7 +220,8 @@ def main():
             "roofline": roofline, "roofline_corr": roofline_corr,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sds, args)
+            log("GPU leg done; timing the CPU oracle (bounded sample, child process)")
+            line["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -42,6 +42,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load its bundled HIP runtime first: librfx.so then binds to the SAME libamdhip64 instance
+    # (two runtimes in one process -> hipErrorNoDevice on launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "librfx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
