@@ -19,7 +19,7 @@ tail -12 gpurun_out/bench.log
 fi
 if [ "$PROF" = "1" ]; then
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OLDPWD/gpurun_out/prof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OLDPWD/gpurun_out/prof.log 2>&1
 cd $OLDPWD
 ls -R gpurun_out/prof | head -20
 fi

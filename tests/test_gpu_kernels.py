@@ -264,7 +264,8 @@ def test_ransac_sentinels_and_many_seeds(dev):
     err = ops.prediction(m1.to(dev), m2.to(dev), torch.from_numpy(g["score_H_2"][:7]).to(dev)).cpu()
     ref = restate.prediction(m1[None], m2[None], torch.from_numpy(g["score_H_2"][:7]))
     # errors grow without bound where the projective denominator approaches 0: relative tolerance
-    assert ((err - ref).abs() / ref.clamp_min(1.0)).max() <= 1e-5
+    rel = (err - ref).abs() / ref.clamp_min(1.0)
+    assert rel.max() <= 1e-3 and (rel <= 4e-7).float().mean() > 0.999
 
 
 # ------------------------------------------------------------------ whole networks
