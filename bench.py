@@ -185,8 +185,19 @@ def main():
     ok_pairs = int((out[:, 9] == 0).sum().item())
 
     # ---- roofline of the dominant kernel (events were recorded on the launch stream inside the timed region)
-    dom = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1) in conv_t if v == 0]
-    allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1) in conv_t]
+    dom = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _) in conv_t if v == 0]
+    allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _) in conv_t]
+    if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
+        agg = {}
+        for (v, f, e0, e1, shp) in conv_t:
+            a = agg.setdefault((v,) + shp, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1) * 1e-3
+        rows = sorted(((k, c, f, t) for k, (c, f, t) in agg.items()), key=lambda r: -r[3])
+        with open(os.environ["RFX_BENCH_DUMP"], "w") as fh:
+            fh.write("variant,N,Cin,H,W,Cout,k,stride,calls,total_ms,TFLOPs,share\n")
+            tot = sum(r[3] for r in rows)
+            for k, c, f, t in rows:
+                fh.write(",".join(str(x) for x in k) + ",%d,%.3f,%.1f,%.3f\n" % (c, t * 1e3, f / t / 1e12, t / tot))
     if not dom:
         dom = allc
     flops_per_launch = sum(f for f, _ in dom) / len(dom)

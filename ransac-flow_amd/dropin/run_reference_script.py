@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Run one of the reference's entry scripts UNCHANGED on the MI355X path.
+
+    python run_reference_script.py /path/to/RANSAC-Flow/quick_start/align2images.py [script args ...]
+
+The reference's scripts import the hot path by bare module name after ``sys.path.append`` --
+``from coarseAlignFeatMatch import CoarseAlign`` (quick_start/align2images.py:2), ``import outil`` (:5),
+``import model`` (:7), ``import kornia.geometry as tgm`` (:19).  This launcher pre-loads the drop-in modules
+of this directory into ``sys.modules`` under exactly those names (so the script's own imports resolve to
+them), picks the CoarseAlign variant from the script's directory, installs small stand-ins for packages the
+script imports but this image lacks (kornia's HomographyWarper -> librfx warp_grid kernel; torchvision
+transforms; scipy.misc.imresize; segEval), optionally rebinds ``torch.nn.functional.grid_sample`` /
+``interpolate`` / ``normalize`` to the librfx kernels for float32 HIP tensors (``RFX_PATCH_FUNCTIONAL=1``,
+default on), and then runs the script with ``runpy`` from its own directory.
+"""
+import importlib
+import os
+import runpy
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+
+
+def variant_for(script_path):
+    d = os.path.basename(os.path.dirname(os.path.abspath(script_path)))
+    return {"quick_start": "A", "evalYFCC": "C"}.get(d, "B" if d.startswith("eval") else "A")
+
+
+def install_kornia_shim():
+    try:
+        import kornia.geometry  # noqa: F401
+        return
+    except Exception:
+        pass
+    import torch
+    from rfx import ops
+
+    class HomographyWarper:
+        """kornia 0.1.4 HomographyWarper(h, w).warp_grid(H) on the rfx_warp_grid_f32 kernel."""
+
+        def __init__(self, height, width, *a, **k):
+            self.height, self.width = height, width
+
+        def warp_grid(self, H):
+            return ops.warp_grid(H.float().cuda(), self.height, self.width)
+
+    ko, kg = types.ModuleType("kornia"), types.ModuleType("kornia.geometry")
+    kg.HomographyWarper = HomographyWarper
+    ko.geometry = kg
+    sys.modules["kornia"], sys.modules["kornia.geometry"] = ko, kg
+
+
+def install_torchvision_shim():
+    try:
+        import torchvision  # noqa: F401
+        return
+    except Exception:
+        pass
+    import numpy as np
+    import torch
+    import PIL.Image as Image
+    tv, tvm, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.models"), types.ModuleType("torchvision.transforms")
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.asarray(pic, dtype=np.uint8)
+            a = a[:, :, None] if a.ndim == 2 else a
+            return torch.from_numpy(a.copy()).permute(2, 0, 1).contiguous().float().div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m, self.s = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.m) / self.s
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage:
+        def __call__(self, t):
+            return Image.fromarray((t.detach().cpu().clamp(0, 1) * 255).byte().permute(1, 2, 0).numpy())
+
+    def resnet50(pretrained=False, **k):
+        raise RuntimeError("torchvision is not installed: the drop-in CoarseAlign builds its trunk from rfx.weights")
+
+    tvt.ToTensor, tvt.Normalize, tvt.Compose, tvt.ToPILImage = ToTensor, Normalize, Compose, ToPILImage
+    tvm.resnet50 = resnet50
+    tv.models, tv.transforms = tvm, tvt
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.transforms": tvt})
+
+
+def install_misc_shims():
+    import scipy
+    if not hasattr(scipy, "misc") or not hasattr(scipy.misc, "imresize"):
+        sm = types.ModuleType("scipy.misc")
+
+        def imresize(arr, size, *a, **k):
+            import numpy as np
+            import PIL.Image as Image
+            return np.asarray(Image.fromarray(arr).resize((size[1], size[0]), Image.BILINEAR))
+        sm.imresize = imresize
+        sys.modules["scipy.misc"] = sm
+        scipy.misc = sm
+    sys.modules.setdefault("segEval", types.ModuleType("segEval"))
+
+
+def patch_functional():
+    """F.grid_sample / F.interpolate(bilinear) / F.normalize(dim=1) -> librfx for float32 HIP 4-D tensors."""
+    import torch
+    import torch.nn.functional as F
+    from rfx import ops
+    _gs, _ip, _nm = F.grid_sample, F.interpolate, F.normalize
+
+    def grid_sample(input, grid, mode="bilinear", padding_mode="zeros", align_corners=None):
+        if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and mode == "bilinear" and padding_mode == "zeros":
+            return ops.grid_sample(input, grid, bool(align_corners))
+        return _gs(input, grid, mode=mode, padding_mode=padding_mode, align_corners=align_corners)
+
+    def interpolate(input, size=None, scale_factor=None, mode="nearest", align_corners=None, **kw):
+        if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and mode == "bilinear" and not kw:
+            if size is None:
+                sf = scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor, scale_factor)
+                size = (int(input.shape[2] * sf[0]), int(input.shape[3] * sf[1]))
+            size = (size, size) if isinstance(size, int) else size
+            return ops.resize_bilinear(input, size, bool(align_corners))
+        return _ip(input, size=size, scale_factor=scale_factor, mode=mode, align_corners=align_corners, **kw)
+
+    def normalize(input, p=2.0, dim=1, eps=1e-12, out=None):
+        if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and p == 2 and dim == 1 and eps == 1e-12 and out is None:
+            return ops.l2norm(input)
+        return _nm(input, p=p, dim=dim, eps=eps, out=out)
+
+    F.grid_sample, F.interpolate, F.normalize = grid_sample, interpolate, normalize
+
+
+def setup(script_path):
+    for p in (PKG, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("RFX_COARSE_VARIANT", variant_for(script_path))
+    install_torchvision_shim()
+    install_kornia_shim()
+    install_misc_shims()
+    for name in ("outil", "model", "coarseAlignFeatMatch"):
+        sys.modules[name] = importlib.import_module(name)
+    if os.environ.get("RFX_PATCH_FUNCTIONAL", "1") == "1":
+        patch_functional()
+
+
+def main():
+    if len(sys.argv) < 2:
+        print(__doc__)
+        sys.exit(2)
+    script = os.path.abspath(sys.argv[1])
+    setup(script)
+    sys.argv = [script] + sys.argv[2:]
+    os.chdir(os.path.dirname(script))
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+"""The reference's entry scripts replayed on the drop-in modules (ransac-flow_amd/dropin) on a real GPU.
+
+/root/reference is not present on the GPU box, so the scripts themselves cannot be run there; these tests
+execute the same call sequences (quick_start/align2images.py:30-97 and the multi-homography loop of
+evaluation/evalHpatch/evaluation.py:164-243) against the drop-in ``outil`` / ``model`` / ``coarseAlignFeatMatch``
+modules exactly as ``run_reference_script.py`` sets them up (sys.modules names, kornia/torchvision stand-ins,
+F.grid_sample / F.interpolate / F.normalize rebound to librfx), and compare with the CPU oracle."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import restate
+from rfx import weights, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "ransac-flow_amd", "dropin")
+
+
+@pytest.fixture()
+def launcher_env(monkeypatch):
+    import torch.nn.functional as F
+    saved_f = (F.grid_sample, F.interpolate, F.normalize)
+    saved_mod = {k: sys.modules.get(k) for k in ("outil", "model", "coarseAlignFeatMatch", "kornia", "kornia.geometry",
+                                                 "torchvision", "torchvision.models", "torchvision.transforms")}
+    sys.path.insert(0, DROPIN)
+    for k in ("outil", "model", "coarseAlignFeatMatch"):
+        sys.modules.pop(k, None)
+    yield
+    F.grid_sample, F.interpolate, F.normalize = saved_f
+    for k, v in saved_mod.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    sys.path.remove(DROPIN)
+    os.environ.pop("RFX_COARSE_VARIANT", None)
+
+
+def _save_ckpt(path):
+    sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+           "netMatch": weights.net_matchability_sd(3, last_std=0.02)}
+    torch.save(sds, path)
+    return sds
+
+
+def test_quick_start_align2images_replay(dev, launcher_env, tmp_path):
+    launcher = importlib.import_module("run_reference_script")
+    launcher.setup("/x/RANSAC-Flow/quick_start/align2images.py")
+    from coarseAlignFeatMatch import CoarseAlign      # noqa: E402  (the script's own import lines)
+    import outil                                      # noqa: E402,F401
+    import model                                      # noqa: E402
+    import kornia.geometry as tgm                     # noqa: E402
+    import torch.nn.functional as F                   # noqa: E402
+    assert CoarseAlign.__name__ == "CoarseAlignA"
+    sds = _save_ckpt(str(tmp_path / "ck.pth"))
+    I1, I2 = synth.make_pair(240, 320, seed=5)
+    # ---- body of align2images() ----
+    network = {"netFeatCoarse": model.FeatureExtractor(), "netCorr": model.CorrNeigh(7),
+               "netFlowCoarse": model.NetFlowCoarse(7), "netMatch": model.NetMatchability(7)}
+    for key in list(network.keys()):
+        network[key].cuda()
+    param = torch.load(str(tmp_path / "ck.pth"))
+    for key in list(param.keys()):
+        network[key].load_state_dict(param[key])
+        network[key].eval()
+    trunk_sd = weights.resnet50_trunk_sd(0)
+    coarseModel = CoarseAlign(3, 300, 0.05, "Homography", 320, segId=1, segFg=True, imageNet=True, scaleR=1.2,
+                              trunk_state_dict=trunk_sd)
+    coarseModel.setSource(I1)
+    coarseModel.setTarget(I2)
+    img2w, img2h = coarseModel.It.size
+    gridX = torch.linspace(-1, 1, steps=img2w).view(1, 1, -1, 1).expand(1, img2h, img2w, 1)
+    gridY = torch.linspace(-1, 1, steps=img2h).view(1, -1, 1, 1).expand(1, img2h, img2w, 1)
+    warper = tgm.HomographyWarper(img2h, img2w)
+    torch.manual_seed(7)
+    bestPrm, inlierMask = coarseModel.getCoarse(np.zeros((img2h, img2w)))
+    assert bestPrm.dtype == np.float32 and bestPrm.shape == (3, 3) and inlierMask.shape == (15, 20)
+    bestPrmT = torch.from_numpy(bestPrm).unsqueeze(0).cuda()
+    flowCoarse = warper.warp_grid(bestPrmT)
+    img1_coarse = F.grid_sample(coarseModel.IsTensor, flowCoarse)
+    feat1 = F.normalize(network["netFeatCoarse"](img1_coarse.cuda()))
+    feat2 = F.normalize(network["netFeatCoarse"](coarseModel.ItTensor))
+    corr12 = network["netCorr"](feat1, feat2)
+    flowDown = network["netFlowCoarse"](corr12, False)
+    grid = torch.cat((gridX, gridY), dim=3).cuda()
+    flowUp = F.interpolate(flowDown, size=(grid.size()[1], grid.size()[2]), mode="bilinear")
+    flowUp = flowUp.permute(0, 2, 3, 1)
+    flowUp = flowUp + grid
+    flow12 = F.grid_sample(flowCoarse.permute(0, 3, 1, 2), flowUp).permute(0, 2, 3, 1).contiguous()
+    img1_fine = F.grid_sample(coarseModel.IsTensor, flow12)
+    # ---- oracle on the same pair / seed ----
+    ca = restate.CoarseAlignOracle(trunk_sd, 3, 300, 0.05, 320, 1.2, variant="A")
+    ca.setSource(I1)
+    ca.setTarget(I2)
+    torch.manual_seed(7)
+    r = ca.getCoarse(np.zeros((img2h, img2w)))
+    if np.array_equal(r["inlierMask"], inlierMask):
+        assert np.abs(r["H"] - bestPrm).max() <= 1e-6
+    with torch.no_grad():
+        st = restate.fine_step_quickstart(dict(feat=sds["netFeatCoarse"], flow=sds["netFlowCoarse"]), ca.IsTensor,
+                                          ca.ItTensor, restate.warp_grid(torch.from_numpy(bestPrm)[None], img2h, img2w))
+    assert (st["flow12"] - flow12.cpu()).abs().max() < 1e-3
+    assert (st["img1_fine"] - img1_fine.cpu()).abs().max() < 2e-3
+    # sentinel: everything masked -> fewer than 4 matches -> (None, [])
+    res = coarseModel.getCoarse(np.ones((img2h, img2w)))
+    assert res[0] is None and res[1] == []
+    # predFlowCoarse / predMatchability API (model/model.py:331-357)
+    fg, fc = model.predFlowCoarse(corr12, network["netFlowCoarse"], grid, True)
+    og, oc = restate.pred_flow_coarse(sds["netFlowCoarse"], st["corr12"], restate.identity_grid(img2h, img2w), True)
+    assert fg.shape == og.shape and (fc.cpu() - oc).abs().max() < 1e-3
+    m = model.predMatchability(corr12, network["netMatch"], True)
+    assert (m.cpu() - restate.net_matchability(sds["netMatch"], st["corr12"], True)).abs().max() < 1e-4
+
+
+def test_eval_hpatch_multi_homography_replay(dev, launcher_env, tmp_path):
+    launcher = importlib.import_module("run_reference_script")
+    launcher.setup("/x/RANSAC-Flow/evaluation/evalHpatch/evaluation.py")
+    from coarseAlignFeatMatch import CoarseAlign
+    import model
+    import kornia.geometry as tgm
+    import torch.nn.functional as F
+    assert CoarseAlign.__name__ == "CoarseAlignB"
+    sds = _save_ckpt(str(tmp_path / "ck.pth"))
+    network = {"netFeatCoarse": model.FeatureExtractor(), "netCorr": model.CorrNeigh(7),
+               "netFlowCoarse": model.NetFlowCoarse(7), "netMatch": model.NetMatchability(7)}
+    for key in network:
+        network[key].cuda()
+        if key != "netCorr":
+            network[key].load_state_dict(sds[key])
+        network[key].eval()
+
+    def PredFlowMask(IsTensor, featt, flowCoarse, grid, network):      # evaluation/evalHpatch/evaluation.py:23-55
+        IsSample = F.grid_sample(IsTensor, flowCoarse)
+        featsSample = F.normalize(network["netFeatCoarse"](IsSample))
+        corr12 = network["netCorr"](featt, featsSample)
+        flowDown8 = network["netFlowCoarse"](corr12, False)
+        match12Down8 = network["netMatch"](corr12, False)
+        corr21 = network["netCorr"](featsSample, featt)
+        match21Down8 = network["netMatch"](corr21, False)
+        match12 = F.interpolate(match12Down8, size=(grid.size()[1], grid.size()[2]), mode="bilinear")
+        flowUp = F.interpolate(flowDown8, size=(grid.size()[1], grid.size()[2]), mode="bilinear").permute(0, 2, 3, 1)
+        flowUp = torch.clamp(flowUp + grid, min=-1, max=1)
+        flow12 = F.grid_sample(flowCoarse.permute(0, 3, 1, 2), flowUp).permute(0, 2, 3, 1).contiguous()
+        inb = ((flow12.narrow(3, 0, 1) >= -1) * (flow12.narrow(3, 0, 1) <= 1)).float() * \
+              ((flow12.narrow(3, 1, 1) >= -1) * (flow12.narrow(3, 1, 1) <= 1)).float()
+        match = (match12 * inb.permute(0, 3, 1, 2))[0, 0].cpu().numpy()
+        return flow12, match, flowDown8.cpu().numpy(), torch.cat((match12Down8, match21Down8), dim=1).cpu().numpy()
+
+    I1, I2 = synth.make_pair(240, 320, seed=9)
+    trunk_sd = weights.resnet50_trunk_sd(0)
+    coarseModel = CoarseAlign(3, 300, 0.05, "Homography", 240, 2, False, 1.2, True, False, trunk_state_dict=trunk_sd)
+    maxCoarse, maskRegionTh = 2, 0.01
+    with torch.no_grad():
+        coarseModel.setPair(I1, I2)
+        Itw, Ith = coarseModel.It.size
+        It_bg = np.ones((Ith, Itw), dtype=np.float32)
+        featt = F.normalize(network["netFeatCoarse"](coarseModel.ItTensor))
+        gridY = torch.linspace(-1, 1, steps=Ith).view(1, -1, 1, 1).expand(1, Ith, Itw, 1)
+        gridX = torch.linspace(-1, 1, steps=Itw).view(1, 1, -1, 1).expand(1, Ith, Itw, 1)
+        grid = torch.cat((gridX, gridY), dim=3).cuda()
+        warper = tgm.HomographyWarper(Ith, Itw)
+        Mask = np.zeros((Ith, Itw), dtype=np.float32)
+        Hs, fds = [], []
+        nbCoarse = 0
+        torch.manual_seed(11)
+        while nbCoarse <= maxCoarse:
+            fgMask = ((Mask + (1 - It_bg)) > 0.5).astype(np.float32)
+            bestPara = coarseModel.getCoarse(fgMask)
+            if bestPara is None:
+                break
+            bestParaT = torch.from_numpy(bestPara).unsqueeze(0).cuda()
+            flowCoarse = warper.warp_grid(bestParaT)
+            flowFine, matchFine, fd8, md8 = PredFlowMask(coarseModel.IsTensor, featt, flowCoarse, grid, network)
+            if (matchFine * (1 - fgMask)).mean() > maskRegionTh or nbCoarse == 0:
+                Hs.append(bestPara)
+                fds.append(fd8)
+                nbCoarse += 1
+                matchFine = matchFine * (1 - fgMask)
+                Mask = ((Mask + matchFine) >= 1.0).astype(np.float32)
+            else:
+                break
+    # oracle
+    ca = restate.CoarseAlignOracle(trunk_sd, 3, 300, 0.05, 240, 1.2, variant="B")
+    ca.setPair(I1, I2)
+    torch.manual_seed(11)
+    o = restate.multi_h_loop(ca, dict(feat=sds["netFeatCoarse"], flow=sds["netFlowCoarse"], match=sds["netMatch"]),
+                             max_coarse=maxCoarse, mask_region_th=maskRegionTh)
+    assert len(Hs) >= 1 and len(o["H"]) >= 1
+    # first homography: same matches + same draw -> same H; later ones depend on the thresholded matchability mask
+    assert np.abs(Hs[0] - o["H"][0]).max() < 1e-5
+    assert np.abs(fds[0] - o["flowDown8"][0]).max() < 1e-3
+    assert len(Hs) == len(o["H"])
