@@ -49,8 +49,9 @@ const char* rfx_version(void);
  *     out[n,m,oh,ow] = act( scale[m] * sum_{c,kh,kw} in[n,c,oh*s-p+kh,ow*s-p+kw] * w[m,c,kh,kw]
  *                           + shift[m] + residual[n,m,oh,ow] )
  * wT    : packed weights [Kpad][Mpad], wT[k*Mpad+m] = w[m,c,kh,kw] with k=(c*KH+kh)*KW+kw,
- *         Kpad = roundup(Cin*KH*KW,16), Mpad = roundup(Cout,128), zero padded.
- * ktab  : int32[Kpad], (c<<8)|(kh<<4)|kw for k < K and -1 for the padding rows.
+ *         Kpad = roundup(Cin*KH*KW,32), Mpad = roundup(Cout,128), zero padded.
+ * ktab  : int32[Kpad], (c<<8)|(kh<<4)|kw for k < K and -1 for the padding rows, stored per block of 32
+ *         consecutive k as [16 even k | 16 odd k].
  * scale/shift may be NULL (treated as 1 / 0); residual may be NULL.
  * ------------------------------------------------------------------------------------------ */
 int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,

@@ -9,13 +9,15 @@
 //     D[m][p] = sum_k  W^T[k][m] * im2col[k][p]      m = output channel, p = (n,oh,ow), k = (c,kh,kw)
 // A operand = packed weights [Kpad][Mpad] (k-major, zero padded, so tile loads need no guards),
 // B operand = input patches gathered on the fly (coalesced along ow), both staged through LDS as
-// [BK][tile] so that a 32x32x2 MFMA lane reads one float per operand: lane l supplies
-// A[m = l&31][k = l>>5] and B[k = l>>5][p = l&31]; conflict-free ds_read_b32.
+// through LDS; a 32x32x2 MFMA lane supplies one float per operand: lane l holds
+// A[m = l&31][k = l>>5] and B[k = l>>5][p = l&31].
 // The fp32 MFMA is bit-for-bit a k-ordered fmaf chain, so results are deterministic and within
 // fp32 round-off of the reference's cuDNN/oneDNN sums.
 //
-// Block = 256 threads = 2x2 waves; wave tile = (32*TM) x (32*TN); BK = 16; register-prefetch double
-// buffering (global loads of step s+1 are in flight while step s runs on the matrix pipe).
+// Block = 256 threads = 2x2 waves; wave tile = (32*TM) x (32*TN); BK = 32; register-prefetch double
+// buffering (global loads of step s+1 are in flight while step s runs on the matrix pipe).  LDS holds each
+// operand as [k&1][row][k>>1] so that a lane reads its 16 k-pairs of a step with four ds_read_b128
+// (XOR-swizzled 16-byte chunks: conflict free) instead of sixteen ds_read_b32.
 // Epilogue fused: y = fma(acc, scale[m], shift[m]) (+ residual) -> ReLU / sigmoid; stores coalesced
 // along the pixel dimension (the MFMA C/D column index is the pixel).
 #include "common.h"
@@ -35,12 +37,15 @@ struct ConvArgs {
 };
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs a) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
-    constexpr int B_RPT = 256 / BN;   // k-rows covered by one pass of the block
-    constexpr int B_NP = BK / B_RPT;  // passes per K step
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
+    constexpr int A_NI = BM / 8, B_NI = BN / 8;                        // values per thread per step
+    // LDS image per operand: [h = k&1][row (m or pixel)][kk = k>>1], 16 consecutive k-pairs per row, so that a
+    // lane fetches its operands for a whole K step with four ds_read_b128.  16-byte chunk q of row r is stored
+    // at chunk q ^ ((r>>2)&3): the 16-lane ds_read_b128 service groups then touch 16 distinct bank quads.
+    __shared__ __attribute__((aligned(16))) float As[2][2][BM][KK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KK];
+    __shared__ float s_scale[BM], s_shift[BM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -58,10 +63,20 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs a) {
     const int m0 = tm_idx * BM;
     const long long n0 = (long long)tp_idx * BN;
 
+    if (t < BM) {  // folded BatchNorm of this block's output channels -> LDS (visible after the first barrier)
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
     const int HWo = a.Hout * a.Wout;
-    // this thread's im2col column (fixed for the whole K loop)
+    // staging roles: this thread owns row mc of the A image and row pc of the B image, parity hA / hB of k,
+    // k-pairs [iA0, iA0+A_NI) / [iB0, iB0+B_NI): exactly the values one MFMA lane will read back.
+    const int mc = t % BM;
+    const int gA = __builtin_amdgcn_readfirstlane(t / BM);
+    const int hA = gA & 1, iA0 = (gA >> 1) * A_NI;
     const int pc = t % BN;
-    const int krow0 = __builtin_amdgcn_readfirstlane(t / BN);
+    const int gB = __builtin_amdgcn_readfirstlane(t / BN);
+    const int hB = gB & 1, iB0 = (gB >> 1) * B_NI;
     const long long p = n0 + pc;
     const bool pvalid = p < a.P;
     int ih0 = 0, iw0 = 0;
@@ -74,38 +89,43 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs a) {
         iw0 = ow * a.stride - a.pad;
         inb = a.in + (size_t)n * a.Cin * a.Hin * a.Win;
     }
+    const float* wcol = a.wT + m0 + mc;
 
-    f32x4 ra[TM];
-    float rb[B_NP];
+    float ra[A_NI], rb[B_NI];
 
     auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int idx = t + 256 * i;
-            const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-            ra[i] = *reinterpret_cast<const f32x4*>(a.wT + (size_t)(k0 + row) * a.Mpad + m0 + c4 * 4);
-        }
+        for (int i = 0; i < A_NI; ++i) ra[i] = wcol[(size_t)(k0 + hA + 2 * (iA0 + i)) * a.Mpad];
+        // ktab is stored per 32-k block as [16 even k | 16 odd k]: this wave's B_NI entries are contiguous
+        // -> one wide scalar load and a single wait instead of a dependent s_load per element
+        const int32_t* kt = a.ktab + k0 + hB * KK + iB0;
+        int ev[B_NI];
 #pragma unroll
-        for (int i = 0; i < B_NP; ++i) {
-            const int kr = krow0 + B_RPT * i;
-            const int e = a.ktab[k0 + kr];  // wave-uniform -> scalar load
+        for (int i = 0; i < B_NI; ++i) ev[i] = kt[i];
+#pragma unroll
+        for (int i = 0; i < B_NI; ++i) {
+            const int e = ev[i];
             const int cin = e >> 8, kh = (e >> 4) & 15, kw = e & 15;
             const int ih = ih0 + kh, iw = iw0 + kw;
-            const bool ok = pvalid && (e >= 0) && ((unsigned)ih < (unsigned)a.Hin) && ((unsigned)iw < (unsigned)a.Win);
-            const int off = ok ? ((cin * a.Hin + ih) * a.Win + iw) : 0;
-            const float v = inb[off];  // always a valid address; selected below (no branch around the load)
+            // bitwise & (no short-circuit): keeps the gather branch-free (v_cndmask, not exec-mask branches)
+            const bool ok = pvalid & (e >= 0) & ((unsigned)ih < (unsigned)a.Hin) & ((unsigned)iw < (unsigned)a.Win);
+            const int off = (cin * a.Hin + ih) * a.Win + iw;
+            const float v = inb[ok ? off : 0];  // always a valid address; selected below
             rb[i] = ok ? v : 0.0f;
         }
     };
     auto store_lds = [&](int buf) {
+        const int swa = (mc >> 2) & 3, swb = (pc >> 2) & 3;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int idx = t + 256 * i;
-            const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-            *reinterpret_cast<f32x4*>(&As[buf][row][c4 * 4]) = ra[i];
+        for (int q = 0; q < A_NI / 4; ++q) {
+            f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(&As[buf][hA][mc][((iA0 / 4 + q) ^ swa) * 4]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_NP; ++i) Bs[buf][krow0 + B_RPT * i][pc] = rb[i];
+        for (int q = 0; q < B_NI / 4; ++q) {
+            f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(&Bs[buf][hB][pc][((iB0 / 4 + q) ^ swb) * 4]) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -126,47 +146,70 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_global((kt + 1) * BK);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[TM], bv[TN];
+        for (int half = 0; half < 2; ++half) {  // two halves of 8 k-pairs keep the fragment registers at 32
+            f32x4 af[TM][2], bf[TN][2];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[cur][kk * 2 + lrow][(wm * TM + i) * 32 + lcol];
+            for (int i = 0; i < TM; ++i) {
+                const int m = (wm * TM + i) * 32 + lcol;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[cur][kk * 2 + lrow][(wn * TN + j) * 32 + lcol];
+                for (int q = 0; q < 2; ++q)
+                    af[i][q] = *reinterpret_cast<const f32x4*>(&As[cur][lrow][m][((half * 2 + q) ^ ((m >> 2) & 3)) * 4]);
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int pl = (wn * TN + j) * 32 + lcol;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < 2; ++q)
+                    bf[j][q] = *reinterpret_cast<const f32x4*>(&Bs[cur][lrow][pl][((half * 2 + q) ^ ((pl >> 2) & 3)) * 4]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // scale/shift come from LDS and the residual values of one 32x32 sub-tile are fetched as a batch of 16
+    // independent loads BEFORE its stores: out/res/scale may alias as far as the compiler knows, so a
+    // load placed after a store would otherwise serialise the whole epilogue on memory latency.
+    const bool has_res = a.res != nullptr;
+    const float* __restrict__ resp = a.res;
+    float* __restrict__ outp = a.out;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const long long pp = n0 + (wn * TN + j) * 32 + lcol;
-        if (pp >= a.P) continue;
+        long long pp = n0 + (wn * TN + j) * 32 + lcol;
+        const bool pv = pp < a.P;
+        if (!pv) pp = a.P - 1;
         const int n = (int)(pp / HWo);
         const int rem = (int)(pp - (long long)n * HWo);
         const size_t obase = (size_t)n * a.Cout * HWo + rem;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                if (m < a.Cout) {
-                    float v = acc[i][j][r];
-                    const float sc = a.scale ? a.scale[m] : 1.0f;
-                    const float sh = a.shift ? a.shift[m] : 0.0f;
-                    v = fmaf(v, sc, sh);
-                    const size_t o = obase + (size_t)m * HWo;
-                    if (a.res) v += a.res[o];
-                    if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
-                    else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                    a.out[o] = v;
-                }
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const int mc = (m0 + ml < a.Cout) ? (m0 + ml) : (a.Cout - 1);
+                rv[r] = has_res ? resp[obase + (size_t)mc * HWo] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const int m = m0 + ml;
+                float v = fmaf(acc[i][j][r], s_scale[ml], s_shift[ml]);
+                if (has_res) v += rv[r];
+                if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
+                else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                if (pv && m < a.Cout) outp[obase + (size_t)m * HWo] = v;
             }
         }
     }
@@ -210,7 +253,7 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     if (a.Hout <= 0 || a.Wout <= 0) return RFX_E_ARG;
     if ((long long)Cin * Hin * Win > 0x7fffffffLL) return RFX_E_LIMIT;
     const int K = Cin * KH * KW;
-    a.Kpad = (K + 15) / 16 * 16;
+    a.Kpad = (K + 31) / 32 * 32;
     a.Mpad = (Cout + 127) / 128 * 128;
     a.P = (long long)N * a.Hout * a.Wout;
     hipStream_t st = rfx_stream(stream);

@@ -43,13 +43,15 @@ class ConvPlan:
         self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.stride, self.pad, self.act = stride, pad, act
         K = self.Cin * self.KH * self.KW
-        Kpad, Mpad = (K + 15) // 16 * 16, (self.Cout + 127) // 128 * 128
+        Kpad, Mpad = (K + 31) // 32 * 32, (self.Cout + 127) // 128 * 128
         wT = torch.zeros(Kpad, Mpad, dtype=torch.float32)
         wT[:K, :self.Cout] = w.reshape(self.Cout, K).t()
         k = torch.arange(K)
         c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)
         ktab = torch.full((Kpad,), -1, dtype=torch.int32)
         ktab[:K] = ((c << 8) | ((r // self.KW) << 4) | (r % self.KW)).int()
+        # per 32-k block: [16 even k | 16 odd k] (the order in which one MFMA lane-half consumes them)
+        ktab = ktab.view(-1, 16, 2).permute(0, 2, 1).reshape(-1).contiguous()
         dev = device or "cuda"
         self.wT, self.ktab = wT.to(dev), ktab.to(dev)
         if bn is not None:
