@@ -133,6 +133,12 @@ int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, i
                       const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
                       void* stream);
 
+/* The same for `batch` independent pairs in one launch (blockIdx.y = pair): pair b reads featA + b*strideA,
+ * featB + b*strideB, maskB + b*nB, writes idx1/idx2 + b*min(nA,nB), count[b], and uses ws + b*ws_bytes(nA,nB). */
+int rfx_mutual_nn_batched_f32(const float* featA, int ldA, int nA, long long strideA, const float* featB, int ldB,
+                              int nB, long long strideB, int C, const float* maskB, int64_t* idx1, int64_t* idx2,
+                              int32_t* count, void* ws, int batch, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * RANSAC over 4-point DLT homographies (utils/outil.py:68-164).
  * match1/match2: (n,3) source / target points (x,y,1); samples: (N,4) int64 indices into them.

@@ -17,27 +17,42 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 32;
 
 struct MnnArgs {
     const float* A; const float* B; const float* maskB;
     int ldA, ldB, nA, nB, C;
     int tilesA, tilesB;
-    float* rowPartVal; int* rowPartIdx;   // [tilesB][nA]
-    float* colPartVal; int* colPartIdx;   // [tilesA][nB]
+    long long strideA, strideB, strideMask;   // element strides between the pairs of a batch (blockIdx.y)
+    size_t wsStride;                           // byte stride of the per-pair workspace
+    size_t oRowPartVal, oRowPartIdx, oColPartVal, oColPartIdx, oRowVal, oRowIdx, oColIdx;  // offsets inside it
+    char* ws;
+    int64_t* idx1; int64_t* idx2; int32_t* count; long long idxStride;
 };
 
 __device__ __forceinline__ void take_min_idx(float& bv, int& bi, float ov, int oi) {
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
 
-__global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+__global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
+    constexpr int KK = BK / 2;
+    // LDS image per operand: [h = k&1][cell][kk = k>>1] (16 k-pairs per row, XOR-swizzled 16-byte chunks): a lane
+    // fetches its operands for a whole BK=32 step with four conflict-free ds_read_b128 (same scheme as conv.hip)
+    __shared__ __attribute__((aligned(16))) float As[2][2][BM][KK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KK];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
+
+    const int pair = blockIdx.y;
+    const float* Ab = a.A + (size_t)pair * a.strideA;
+    const float* Bb = a.B + (size_t)pair * a.strideB;
+    char* ws = a.ws + (size_t)pair * a.wsStride;
+    float* rowPartVal = reinterpret_cast<float*>(ws + a.oRowPartVal);
+    int* rowPartIdx = reinterpret_cast<int*>(ws + a.oRowPartIdx);
+    float* colPartVal = reinterpret_cast<float*>(ws + a.oColPartVal);
+    int* colPartIdx = reinterpret_cast<int*>(ws + a.oColPartIdx);
 
     const int nwg = a.tilesA * a.tilesB;
     int bid = blockIdx.x;
@@ -48,30 +63,34 @@ __global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
     const int tb = bid % a.tilesB, ta = bid / a.tilesB;
     const int i0 = ta * BM, j0 = tb * BN;
 
+    // staging roles: cell `col` of both tiles, parity h of k, all 16 k-pairs of the step
     const int col = t % 128;
-    const int krow0 = __builtin_amdgcn_readfirstlane(t / 128);
+    const int h = __builtin_amdgcn_readfirstlane(t / 128);
     const bool aval = (i0 + col) < a.nA, bval = (j0 + col) < a.nB;
-    const float* Ap = a.A + (aval ? i0 + col : 0);
-    const float* Bp = a.B + (bval ? j0 + col : 0);
-    const float mk = (bval && a.maskB) ? a.maskB[j0 + col] : 1.0f;
+    const float* Ap = Ab + (aval ? i0 + col : 0);
+    const float* Bp = Bb + (bval ? j0 + col : 0);
+    const float mk = (bval && a.maskB) ? a.maskB[(size_t)pair * a.strideMask + j0 + col] : 1.0f;
 
-    float ra[8], rb[8];
+    float ra[KK], rb[KK];
     auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = k0 + krow0 + 2 * i;
+        for (int i = 0; i < KK; ++i) {
+            const int k = k0 + h + 2 * i;
             const bool kin = k < a.C;
             const float va = Ap[(size_t)(kin ? k : 0) * a.ldA];
             const float vb = Bp[(size_t)(kin ? k : 0) * a.ldB];
-            ra[i] = (kin && aval) ? va : 0.0f;
-            rb[i] = (kin && bval) ? vb * mk : 0.0f;
+            ra[i] = (kin & aval) ? va : 0.0f;
+            rb[i] = (kin & bval) ? vb * mk : 0.0f;
         }
     };
     auto store_lds = [&](int buf) {
+        const int sw = (col >> 2) & 3;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            As[buf][krow0 + 2 * i][col] = ra[i];
-            Bs[buf][krow0 + 2 * i][col] = rb[i];
+        for (int q = 0; q < KK / 4; ++q) {
+            f32x4 va = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
+            f32x4 vb = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(&As[buf][h][col][(q ^ sw) * 4]) = va;
+            *reinterpret_cast<f32x4*>(&Bs[buf][h][col][(q ^ sw) * 4]) = vb;
         }
     };
 
@@ -91,25 +110,39 @@ __global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_global((kt + 1) * BK);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[2], bv[2];
+        for (int half = 0; half < 2; ++half) {
+            f32x4 af[2][2], bf[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[cur][kk * 2 + lrow][(wm * 2 + i) * 32 + lcol];
+            for (int i = 0; i < 2; ++i) {
+                const int m = (wm * 2 + i) * 32 + lcol;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bs[cur][kk * 2 + lrow][(wn * 2 + j) * 32 + lcol];
+                for (int q = 0; q < 2; ++q)
+                    af[i][q] = *reinterpret_cast<const f32x4*>(&As[cur][lrow][m][((half * 2 + q) ^ ((m >> 2) & 3)) * 4]);
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const int pl = (wn * 2 + j) * 32 + lcol;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < 2; ++q)
+                    bf[j][q] = *reinterpret_cast<const f32x4*>(&Bs[cur][lrow][pl][((half * 2 + q) ^ ((pl >> 2) & 3)) * 4]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
     // all waves are past the last barrier: the staging buffers are free for the exchange below
-    float* xval = &As[0][0][0];                        // [2][128] values
-    int* xidx = reinterpret_cast<int*>(&Bs[0][0][0]);  // [2][128] indices
+    float* xval = &As[0][0][0][0];                        // [2][128] values
+    int* xidx = reinterpret_cast<int*>(&Bs[0][0][0][0]);  // [2][128] indices
 
     // ---- column arg-max over this tile's rows (C/D: col = lcol, row = (r&3) + 8*(r>>2) + 4*lrow) ----
 #pragma unroll
@@ -137,8 +170,8 @@ __global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
         float bv = xval[t];
         int bi = xidx[t];
         take_min_idx(bv, bi, xval[128 + t], xidx[128 + t]);
-        a.colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
-        a.colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
+        colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
+        colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
     }
     __syncthreads();
 
@@ -172,18 +205,26 @@ __global__ __launch_bounds__(256) void mnn_tile_kernel(MnnArgs a) {
         float bv = xval[t];
         int bj = xidx[t];
         take_min_idx(bv, bj, xval[128 + t], xidx[128 + t]);
-        a.rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
-        a.rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
+        rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
+        rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
     }
 }
 
-__global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a, float* rowVal, int* rowIdx, int* colIdx) {
+__global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a) {
+    char* ws = a.ws + (size_t)blockIdx.y * a.wsStride;
+    const float* rowPartVal = reinterpret_cast<const float*>(ws + a.oRowPartVal);
+    const int* rowPartIdx = reinterpret_cast<const int*>(ws + a.oRowPartIdx);
+    const float* colPartVal = reinterpret_cast<const float*>(ws + a.oColPartVal);
+    const int* colPartIdx = reinterpret_cast<const int*>(ws + a.oColPartIdx);
+    float* rowVal = reinterpret_cast<float*>(ws + a.oRowVal);
+    int* rowIdx = reinterpret_cast<int*>(ws + a.oRowIdx);
+    int* colIdx = reinterpret_cast<int*>(ws + a.oColIdx);
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < a.nA) {
         float bv = -INFINITY;
         int bj = 0x7fffffff;
         for (int tb = 0; tb < a.tilesB; ++tb)
-            take_min_idx(bv, bj, a.rowPartVal[(size_t)tb * a.nA + g], a.rowPartIdx[(size_t)tb * a.nA + g]);
+            take_min_idx(bv, bj, rowPartVal[(size_t)tb * a.nA + g], rowPartIdx[(size_t)tb * a.nA + g]);
         rowVal[g] = bv;
         rowIdx[g] = bj;
     } else if (g - a.nA < a.nB) {
@@ -191,14 +232,21 @@ __global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a, float* rowVa
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int ta = 0; ta < a.tilesA; ++ta)
-            take_min_idx(bv, bi, a.colPartVal[(size_t)ta * a.nB + j], a.colPartIdx[(size_t)ta * a.nB + j]);
+            take_min_idx(bv, bi, colPartVal[(size_t)ta * a.nB + j], colPartIdx[(size_t)ta * a.nB + j]);
         colIdx[j] = bi;
     }
 }
 
 // single workgroup, ordered compaction by ascending source index
-__global__ __launch_bounds__(1024) void mnn_compact_kernel(const float* rowVal, const int* rowIdx, const int* colIdx,
-                                                           int nA, int nB, int64_t* idx1, int64_t* idx2, int32_t* count) {
+__global__ __launch_bounds__(1024) void mnn_compact_kernel(MnnArgs a) {
+    char* ws = a.ws + (size_t)blockIdx.x * a.wsStride;
+    const float* rowVal = reinterpret_cast<const float*>(ws + a.oRowVal);
+    const int* rowIdx = reinterpret_cast<const int*>(ws + a.oRowIdx);
+    const int* colIdx = reinterpret_cast<const int*>(ws + a.oColIdx);
+    const int nA = a.nA, nB = a.nB;
+    int64_t* idx1 = a.idx1 + (size_t)blockIdx.x * a.idxStride;
+    int64_t* idx2 = a.idx2 + (size_t)blockIdx.x * a.idxStride;
+    int32_t* count = a.count + blockIdx.x;
     __shared__ int wsum[16];
     __shared__ int base;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -261,31 +309,43 @@ extern "C" size_t rfx_mutual_nn_ws_bytes(int nA, int nB) {
     return layout(nA, nB).total;
 }
 
+static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
+    const WsLayout L = layout(a.nA, a.nB);
+    a.tilesA = (a.nA + BM - 1) / BM; a.tilesB = (a.nB + BN - 1) / BN;
+    a.wsStride = L.total;
+    a.oRowPartVal = L.rowPartVal; a.oRowPartIdx = L.rowPartIdx; a.oColPartVal = L.colPartVal; a.oColPartIdx = L.colPartIdx;
+    a.oRowVal = L.rowVal; a.oRowIdx = L.rowIdx; a.oColIdx = L.colIdx;
+    const long long nwg = (long long)a.tilesA * a.tilesB;
+    if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
+    hipLaunchKernelGGL(mnn_tile_kernel, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mnn_reduce_kernel, dim3((a.nA + a.nB + 255) / 256, batch), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mnn_compact_kernel, dim3(batch), dim3(1024), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 extern "C" int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
                                  const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
                                  void* stream) {
     if (!featA || !featB || !idx1 || !idx2 || !count || !ws) return RFX_E_ARG;
     if (nA <= 0 || nB <= 0 || C <= 0 || ldA < nA || ldB < nB) return RFX_E_ARG;
-    const WsLayout L = layout(nA, nB);
-    char* w = static_cast<char*>(ws);
     MnnArgs a;
     a.A = featA; a.B = featB; a.maskB = maskB; a.ldA = ldA; a.ldB = ldB; a.nA = nA; a.nB = nB; a.C = C;
-    a.tilesA = (nA + BM - 1) / BM; a.tilesB = (nB + BN - 1) / BN;
-    a.rowPartVal = reinterpret_cast<float*>(w + L.rowPartVal);
-    a.rowPartIdx = reinterpret_cast<int*>(w + L.rowPartIdx);
-    a.colPartVal = reinterpret_cast<float*>(w + L.colPartVal);
-    a.colPartIdx = reinterpret_cast<int*>(w + L.colPartIdx);
-    float* rowVal = reinterpret_cast<float*>(w + L.rowVal);
-    int* rowIdx = reinterpret_cast<int*>(w + L.rowIdx);
-    int* colIdx = reinterpret_cast<int*>(w + L.colIdx);
-    hipStream_t st = rfx_stream(stream);
-    const long long nwg = (long long)a.tilesA * a.tilesB;
-    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL(mnn_tile_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
-    RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mnn_reduce_kernel, dim3((nA + nB + 255) / 256), dim3(256), 0, st, a, rowVal, rowIdx, colIdx);
-    RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mnn_compact_kernel, dim3(1), dim3(1024), 0, st, rowVal, rowIdx, colIdx, nA, nB, idx1, idx2, count);
-    RFX_LAUNCH_CHECK();
-    return RFX_OK;
+    a.strideA = a.strideB = a.strideMask = 0; a.ws = static_cast<char*>(ws);
+    a.idx1 = idx1; a.idx2 = idx2; a.count = count; a.idxStride = 0;
+    return mnn_launch(a, 1, rfx_stream(stream));
+}
+
+extern "C" int rfx_mutual_nn_batched_f32(const float* featA, int ldA, int nA, long long strideA, const float* featB, int ldB,
+                                         int nB, long long strideB, int C, const float* maskB, int64_t* idx1, int64_t* idx2,
+                                         int32_t* count, void* ws, int batch, void* stream) {
+    if (!featA || !featB || !idx1 || !idx2 || !count || !ws || batch <= 0) return RFX_E_ARG;
+    if (nA <= 0 || nB <= 0 || C <= 0 || ldA < nA || ldB < nB) return RFX_E_ARG;
+    MnnArgs a;
+    a.A = featA; a.B = featB; a.maskB = maskB; a.ldA = ldA; a.ldB = ldB; a.nA = nA; a.nB = nB; a.C = C;
+    a.strideA = strideA; a.strideB = strideB; a.strideMask = nB; a.ws = static_cast<char*>(ws);
+    a.idx1 = idx1; a.idx2 = idx2; a.count = count; a.idxStride = nA < nB ? nA : nB;
+    return mnn_launch(a, batch, rfx_stream(stream));
 }

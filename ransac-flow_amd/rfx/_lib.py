@@ -27,6 +27,8 @@ SIGNATURES = {
     "rfx_compose_flow_f32": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_void_p]),
     "rfx_mutual_nn_ws_bytes": (c_size_t, [c_int, c_int]),
     "rfx_mutual_nn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "rfx_mutual_nn_batched_f32": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_int, c_longlong, c_int]
+                                  + [c_void_p] * 5 + [c_int, c_void_p]),
     "rfx_dlt4_homography": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rfx_prediction_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "rfx_score_hypotheses": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4),

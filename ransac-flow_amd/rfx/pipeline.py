@@ -118,12 +118,10 @@ class AlignPipeline:
         feats = feats or self.features(prep)
         B = prep["B"]
         lib_out = []
-        # phase 1: all mutual-NN launches, one sync for the counts
-        pend = []
-        for b in range(B):
-            pend.append(self._mutual_async(feats["featA"][b], feats["featB"][b], feats["nA"], feats["nB"],
-                                           None if maskB is None else maskB[b]))
-        counts = torch.cat([p[2] for p in pend]).cpu().tolist()  # <- sync #1
+        # phase 1: ONE batched mutual-NN launch chain for all pairs, one sync for the counts
+        idx1, idx2, cnt = self._mutual_batched(feats, B, maskB)
+        counts = cnt.cpu().tolist()  # <- sync #1
+        pend = [(idx1[b], idx2[b]) for b in range(B)]
         # phase 2: index draw on the host, RANSAC launches
         for b in range(B):
             n = counts[b]
@@ -151,18 +149,23 @@ class AlignPipeline:
                         r["H"], r["inlier"] = r["_H"], r["_inl"]
         return lib_out
 
-    def _mutual_async(self, fa, fb, nA, nB, mask):
+    def _mutual_batched(self, feats, B, maskB=None):
         from . import _lib
         lib = _lib.load()
-        ws = torch.empty(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=self.dev)
+        nA, nB = feats["nA"], feats["nB"]
+        ws = torch.empty(B * lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=self.dev)
         cap = min(nA, nB)
-        idx1 = torch.empty(cap, dtype=torch.int64, device=self.dev)
-        idx2 = torch.empty(cap, dtype=torch.int64, device=self.dev)
-        count = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        rc = lib.rfx_mutual_nn_f32(ops._p(fa), nA, nA, ops._p(fb), nB, nB, 1024, ops._p(mask), ops._p(idx1), ops._p(idx2),
-                                   ops._p(count), ops._p(ws), ops._stream())
-        _lib.check(rc, "rfx_mutual_nn_f32")
-        return idx1, idx2, count, ws
+        idx1 = torch.empty((B, cap), dtype=torch.int64, device=self.dev)
+        idx2 = torch.empty((B, cap), dtype=torch.int64, device=self.dev)
+        count = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        mask = None
+        if maskB is not None:
+            mask = (torch.stack(list(maskB)) if not isinstance(maskB, torch.Tensor) else maskB).float().contiguous()
+        rc = lib.rfx_mutual_nn_batched_f32(ops._p(feats["featA"]), nA, nA, 1024 * nA, ops._p(feats["featB"]), nB, nB,
+                                           1024 * nB, 1024, ops._p(mask), ops._p(idx1), ops._p(idx2), ops._p(count),
+                                           ops._p(ws), B, ops._stream())
+        _lib.check(rc, "rfx_mutual_nn_batched_f32")
+        return idx1, idx2, count
 
     # ---------------------------------------------------------------- fine stage
     def fine_quickstart(self, prep, Hs):
@@ -194,6 +197,56 @@ class AlignPipeline:
         match = match12 * inb.unsqueeze(1)
         return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
                     match21Down8=match21Down8)
+
+    # ---------------------------------------------------------------- multi-homography driver
+    def multi_h(self, prep, b=0, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None):
+        """The per-pair multi-homography loop of evaluation/evalHpatch/evaluation.py:184-243 (variant B: matches
+        computed once, filtered by the explained-region mask) with every mask kept on the device: per accepted
+        homography the host reads back two scalars (surviving-match count for the index draw, acceptance
+        statistic) instead of round-tripping h x w masks through numpy as the reference does (:53,212,225,238).
+        Returns dict(H=[(3,3)...], flowDown8=[...], matchDown8=[...], mask=final explained mask (h,w))."""
+        feats = feats or self.features(prep)
+        dev = self.dev
+        h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
+        IsT, ItT = prep["IsTensor"][b:b + 1], prep["ItTensor"][b:b + 1]
+        i1, i2 = ops.mutual_nn(feats["featA"][b], feats["featB"][b])
+        W1, H1 = feats["WA"][i1], feats["HA"][i1]
+        W2, H2 = feats["Wt"][i2], feats["Ht"][i2]
+        rt, ct = feats["rt"], feats["ct"]
+        r2, c2 = i2 // ct, i2 % ct                       # integer cell coordinates (getWHTensor_Int)
+        featt = ops.l2norm(self.feat(ItT))
+        bg = torch.ones((h, w), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        Mask = torch.zeros((h, w), dtype=torch.float32, device=dev)
+        out = dict(H=[], flowDown8=[], matchDown8=[])
+        draw = sample_fn or (lambda n, it: torch.randint(n, (it, 4)))
+        nb = 0
+        while nb <= maxCoarse:
+            fg = ((Mask + (1 - bg)) > 0.5).float()
+            keep = ops.resize_bilinear((1 - fg)[None, None], (rt, ct), align_corners=False)[0, 0] > 0.5
+            valid = keep[r2, c2]
+            n = int(valid.sum().item())                                       # sync: size of the index draw
+            if n < 4:
+                break
+            ones = torch.ones(n, dtype=torch.float32, device=dev)
+            m1 = torch.stack((H1[valid], W1[valid], ones), dim=1)
+            m2 = torch.stack((H2[valid], W2[valid], ones), dim=1)
+            bestH, inl, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol)
+            flowCoarse = ops.warp_grid(bestH[None], h, w)
+            pm = self.pred_flow_mask(IsT, featt, flowCoarse)
+            stat = torch.stack(((pm["match"][0, 0] * (1 - fg)).mean(), res[0].float()))
+            gain, status = stat.cpu().tolist()                                # sync: acceptance statistic + status
+            if status != 0:
+                break
+            if gain > maskRegionTh or nb == 0:
+                out["H"].append(bestH)
+                out["flowDown8"].append(pm["flowDown8"])
+                out["matchDown8"].append(torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1))
+                nb += 1
+                Mask = ((Mask + pm["match"][0, 0] * (1 - fg)) >= 1.0).float()
+            else:
+                break
+        out["mask"] = Mask
+        return out
 
     # ---------------------------------------------------------------- whole path
     def align_prepared(self, prep, fine=True, samples=None):

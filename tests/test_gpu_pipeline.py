@@ -117,3 +117,27 @@ def test_config2_coarse_480x640_properties(dev):
     Hb, cnt, inl, _ = restate.ransac(r1["match1"].cpu(), r1["match2"].cpu(), 0.05, r1["samples"])
     assert int(cnt) == r1["count"] and np.array_equal(inl, r1["inlier"].cpu().numpy())
     assert np.abs(Hb - r1["H"].cpu().numpy()).max() <= 1.2e-7
+
+
+def test_multi_homography_driver_matches_oracle(dev):
+    """Device-resident multi-H loop (pipeline.multi_h) vs the oracle's restatement of
+    evaluation/evalHpatch/evaluation.py:184-243 on the same pair and the same index draws."""
+    I1, I2 = synth.make_pair(240, 320, seed=9)
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=0.02)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev)
+    prep = pipe.prepare([(I1, I2)])
+    torch.manual_seed(11)
+    out = pipe.multi_h(prep, 0, maxCoarse=2, maskRegionTh=0.01)
+    ca = restate.CoarseAlignOracle(sds["trunk"], 3, 300, 0.05, 240, 1.2, variant="B")
+    ca.setPair(I1, I2)
+    torch.manual_seed(11)
+    o = restate.multi_h_loop(ca, dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]), max_coarse=2,
+                             mask_region_th=0.01)
+    assert len(out["H"]) == len(o["H"]) >= 1
+    assert np.abs(out["H"][0].cpu().numpy() - o["H"][0]).max() < 1e-5
+    assert np.abs(out["flowDown8"][0].cpu().numpy() - o["flowDown8"][0]).max() < 1e-3
+    assert np.abs(out["matchDown8"][0].cpu().numpy() - o["matchDown8"][0]).max() < 1e-3
+    # explained-region mask: thresholded matchability -> identical except where the value sits at the threshold
+    diff = (out["mask"].cpu().numpy() != o["masks"][-1]).mean()
+    assert diff < 1e-3
