@@ -56,6 +56,8 @@ def cpu_baseline_subprocess(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(args.height), "--width",
            str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs",
            str(args.cpu_pairs)]
+    if getattr(args, "parity_file", None):
+        cmd += ["--parity-file", args.parity_file]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
         for ln in out.stdout.splitlines():
@@ -98,8 +100,36 @@ def cpu_baseline(sds, args):
         if time.perf_counter() - t0 > 25 or (n == 1 and warm > 30):
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d synthetic %dx%d pairs, full coarse+fine path (oracle/restate.py), %.1f s" % (n, H, W, dt)}
+    out = {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d synthetic %dx%d pairs, full coarse+fine path (oracle/restate.py), %.1f s" % (n, H, W, dt)}
+    if getattr(args, "parity_file", None) and os.path.exists(args.parity_file):
+        out["parity"] = parity_vs_oracle(ca, nets, args)
+    return out
+
+
+def parity_vs_oracle(ca, nets, args):
+    """Full-size parity of ONE pair of the timed workload: the GPU leg left its results for pair 0 in an npz; the
+    oracle aligns the same synthetic pair with the same RANSAC index draw (checker only, never timed)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import restate
+    from rfx import synth
+    g = np.load(args.parity_file)
+    I1, I2 = synth.make_pair(args.height, args.width, seed=int(g["seed"]))
+    ca.sample_fn = lambda n, it: torch.from_numpy(g["samples"])
+    ca.setSource(I1)
+    ca.setTarget(I2)
+    r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
+    same = bool(np.array_equal(r["index1"], g["index1"]) and np.array_equal(r["index2"], g["index2"]))
+    res = {"pair": "synthetic %dx%d seed %d" % (args.height, args.width, int(g["seed"])), "n_matches": int(len(r["index1"])),
+           "match_list_identical": same}
+    if same:
+        res["inlier_indices_bit_exact"] = bool(np.array_equal(r["inlier"], g["inlier"]))
+        res["max_abs_H_delta"] = float(np.abs(r["H"] - g["H"]).max())
+    with torch.no_grad():
+        h, w = ca.It.size[1], ca.It.size[0]
+        st = restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, restate.warp_grid(torch.from_numpy(g["H"])[None], h, w))
+    res["max_abs_flow_delta"] = float((st["flow12"].numpy() - g["flow12"]).__abs__().max())
+    return res
 
 
 def main():
@@ -107,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per step per GPU (BASELINE config 3: batch of 64)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--nb-scale", type=int, default=7)
@@ -115,6 +145,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-file", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -218,7 +249,7 @@ def main():
     if rank == 0:
         total_pairs = B * args.steps * world
         line = {
-            "metric": "aligned image-pairs/sec @480x640", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
+            "metric": "aligned image-pairs/sec @480\u00d7640, 1/2/4/8 MI355X; max-abs flow \u0394 vs ref", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -231,8 +262,19 @@ def main():
             "roofline": roofline, "roofline_corr": roofline_corr,
         }
         if world == 1 and not args.no_cpu_baseline:
+            # leave pair 0's GPU result for the checker (one extra, untimed pass with a recorded index draw)
+            import tempfile
+            r0 = pipe.align_prepared(prep, fine=True)[0]
+            if r0["H"] is not None:
+                args.parity_file = os.path.join(tempfile.mkdtemp(prefix="rfx_parity_"), "pair0.npz")
+                np.savez(args.parity_file, seed=rank, samples=r0["samples"].numpy(), index1=r0["index1"].cpu().numpy(),
+                         index2=r0["index2"].cpu().numpy(), inlier=r0["inlier"].cpu().numpy(), H=r0["H"].cpu().numpy(),
+                         flow12=r0["flow12"].cpu().numpy())
             log("GPU leg done; timing the CPU oracle (bounded sample, child process)")
-            line["cpu_baseline"] = cpu_baseline_subprocess(args)
+            cb = cpu_baseline_subprocess(args)
+            if "parity" in cb:
+                line["parity"] = cb.pop("parity")
+            line["cpu_baseline"] = cb
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

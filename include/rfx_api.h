@@ -72,6 +72,10 @@ int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int
  * [1 2 1]x[1 2 1]/16, stride.  Hout = (Hin-1)/stride+1. */
 int rfx_blurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream);
 
+/* Fused MaxPool2d(kernel 2, stride 1) + BlurPool(stride): the FeatureExtractor stem `self.maxpool`
+ * (model/model.py:71-72).  Hout = (Hin-2)/stride+1.  Bit-identical to the two separate calls. */
+int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream);
+
 /* F.normalize(x, p=2, dim=1, eps=1e-12) on NCHW (quick_start/coarseAlignFeatMatch.py:106,124;
  * quick_start/align2images.py:87-88).  `in` is dense; element (n,c,p) of the result goes to
  * out[n*out_batch_stride + c*out_chan_stride + p] (0 = dense defaults C*HW / HW), which lets the coarse

@@ -36,7 +36,9 @@ struct ConvArgs {
     int tilesM, tilesP;
 };
 
-template <int TM, int TN>
+// ONE = 1x1 kernel with pad 0 (any stride): k IS the input channel and every tap is in bounds, so the im2col
+// gather needs no ktab decode and no bounds logic (address = pixel base + k * Hin*Win).
+template <int TM, int TN, bool ONE>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
     constexpr int A_NI = BM / 8, B_NI = BN / 8;                        // values per thread per step
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
         ih0 = oh * a.stride - a.pad;
         iw0 = ow * a.stride - a.pad;
         inb = a.in + (size_t)n * a.Cin * a.Hin * a.Win;
+        if (ONE) inb += (size_t)ih0 * a.Win + iw0;
     }
+    const size_t HWin = (size_t)a.Hin * a.Win;
     const float* wcol = a.wT + m0 + mc;
 
     float ra[A_NI], rb[B_NI];
@@ -96,6 +100,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     auto load_global = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_NI; ++i) ra[i] = wcol[(size_t)(k0 + hA + 2 * (iA0 + i)) * a.Mpad];
+        if (ONE) {
+#pragma unroll
+            for (int i = 0; i < B_NI; ++i) {
+                const int k = k0 + hB + 2 * (iB0 + i);
+                const bool ok = pvalid & (k < a.Cin);
+                const float v = inb[(size_t)(ok ? k : 0) * HWin];
+                rb[i] = ok ? v : 0.0f;
+            }
+            return;
+        }
         // ktab is stored per 32-k block as [16 even k | 16 odd k]: this wave's B_NI entries are contiguous
         // -> one wide scalar load and a single wait instead of a dependent s_load per element
         const int32_t* kt = a.ktab + k0 + hB * KK + iB0;
@@ -215,14 +229,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool ONE>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     a.tilesM = (a.Cout + BM - 1) / BM;
     a.tilesP = (int)((a.P + BN - 1) / BN);
     const long long nwg = (long long)a.tilesM * a.tilesP;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -257,9 +271,10 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     a.Mpad = (Cout + 127) / 128 * 128;
     a.P = (long long)N * a.Hout * a.Wout;
     hipStream_t st = rfx_stream(stream);
+    const bool one = (KH == 1 && KW == 1 && pad == 0);
     switch (rfx_conv2d_tile_variant(N, Cout, a.Hout, a.Wout)) {
-        case 0: return launch_conv<2, 2>(a, st);
-        case 1: return launch_conv<1, 2>(a, st);
-        default: return launch_conv<1, 1>(a, st);
+        case 0: return one ? launch_conv<2, 2, true>(a, st) : launch_conv<2, 2, false>(a, st);
+        case 1: return one ? launch_conv<1, 2, true>(a, st) : launch_conv<1, 2, false>(a, st);
+        default: return one ? launch_conv<1, 1, true>(a, st) : launch_conv<1, 1, false>(a, st);
     }
 }

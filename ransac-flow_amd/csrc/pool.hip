@@ -94,6 +94,53 @@ extern "C" int rfx_blurpool2d_f32(const float* in, float* out, int NC, int Hin, 
     return RFX_OK;
 }
 
+// Fused nn.MaxPool2d(kernel 2, stride 1) + BlurPool(stride): the FeatureExtractor stem (model/model.py:71-72).
+// The un-fused pair writes and re-reads a full-resolution 64-channel map (the largest tensor of the whole
+// pipeline); fused, every input element is fetched once from HBM (the 4x4 input windows of neighbouring outputs
+// overlap in L1/L2) and only the /2 map is written.  Same operations in the same order -> bit-identical.
+__global__ __launch_bounds__(256) void maxblurpool2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            long long total, int Hin, int Win, int Hout, int Wout,
+                                                            int stride) {
+    const float w[3] = {0.25f, 0.5f, 0.25f};
+    const int Hm = Hin - 1, Wm = Win - 1;  // size of the max-pooled map
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ow = (int)(idx % Wout);
+        const long long r = idx / Wout;
+        const int oh = (int)(r % Hout);
+        const long long nc = r / Hout;
+        const float* src = in + nc * Hin * Win;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int my = reflect1(oh * stride - 1 + i, Hm);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int mx = reflect1(ow * stride - 1 + j, Wm);
+                const float* q = src + (size_t)my * Win + mx;
+                const float a = q[0], b = q[1], c = q[Win], d = q[Win + 1];
+                float m = a;
+                m = (b > m || b != b) ? b : m;
+                m = (c > m || c != c) ? c : m;
+                m = (d > m || d != d) ? d : m;
+                acc = fmaf(m, w[i] * w[j], acc);
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
+extern "C" int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream) {
+    if (!in || !out || NC <= 0 || Hin < 3 || Win < 3 || stride <= 0) return RFX_E_ARG;
+    const int Hm = Hin - 1, Wm = Win - 1;
+    const int Hout = (Hm - 1) / stride + 1, Wout = (Wm - 1) / stride + 1;
+    const long long total = (long long)NC * Hout * Wout;
+    hipLaunchKernelGGL(maxblurpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), in, out,
+                       total, Hin, Win, Hout, Wout, stride);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 // One thread per pixel; the channel loop strides by HW so that a wave reads 64 consecutive floats per
 // channel (coalesced).  Two passes over C (the second one hits L2).
 __global__ __launch_bounds__(256) void l2norm_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,

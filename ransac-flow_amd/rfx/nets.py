@@ -71,7 +71,7 @@ class FeatureExtractorNet:
 
     def __call__(self, x):
         x = self.conv1(x)
-        x = ops.blurpool2d(ops.maxpool2d(x, 2, 1, 0), 2)
+        x = ops.maxblurpool2d(x, 2)  # MaxPool2d(2, stride 1) + BlurPool/2 fused
         for blk in self.blocks:
             o = blk["c1"](x)
             r = blk["ds"](ops.blurpool2d(x, blk["stride"])) if blk["ds"] is not None else x

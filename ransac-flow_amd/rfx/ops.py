@@ -111,6 +111,16 @@ def blurpool2d(x, stride=2):
     return out
 
 
+def maxblurpool2d(x, stride=2):
+    """MaxPool2d(2, stride 1) + BlurPool(stride) fused (FeatureExtractor stem)."""
+    x = _dev(x, "maxblurpool input")
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rfx_maxblurpool2d_f32(_p(x), _p(out), N * C, H, W, stride, _stream()), "rfx_maxblurpool2d_f32")
+    return out
+
+
 def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):
     """F.normalize(x, dim=1) for (N,C,H,W) or (N,C,L).  With ``out`` (a float32 device tensor/view start) the
     result is scattered with the given strides (elements)."""

@@ -80,6 +80,9 @@ def test_pools_norm_head_resize(dev):
     assert torch.equal(ops.maxpool2d(xd, 2, 1, 0).cpu(), F.max_pool2d(x, 2, 1))
     for s in (1, 2):
         assert (ops.blurpool2d(xd, s).cpu() - restate.blur_pool(x, s)).abs().max() < 1e-6
+    for s in (1, 2):   # fused stem == the two separate kernels, bit for bit
+        assert torch.equal(ops.maxblurpool2d(xd, s), ops.blurpool2d(ops.maxpool2d(xd, 2, 1, 0), s))
+    assert (ops.maxblurpool2d(xd, 2).cpu() - restate.blur_pool(F.max_pool2d(x, 2, 1), 2)).abs().max() < 1e-6
     f = torch.randn(2, 1024, 3, 5, generator=g)
     assert (ops.l2norm(f.to(dev)).cpu() - F.normalize(f)).abs().max() < 1e-6
     z = torch.zeros(1, 8, 2, 2)
