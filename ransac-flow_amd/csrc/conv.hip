@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     const int lrow = lane >> 5, lcol = lane & 31;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_global((kt + 1) * BK);
+        // branch-free body (the last step re-loads its own tile into the unused buffer): one basic block, so the
+        // scheduler is free to interleave the gather of step kt+1 with the MFMAs of step kt
+        load_global((kt + 1 < nk ? kt + 1 : kt) * BK);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {  // two halves of 8 k-pairs keep the fragment registers at 32
             f32x4 af[TM][2], bf[TN][2];
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_lds(cur ^ 1);
+        store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
