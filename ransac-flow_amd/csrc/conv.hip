@@ -41,7 +41,10 @@ struct ConvArgs {
 template <int TM, int TN, bool ONE>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
-    constexpr int A_NI = BM / 8, B_NI = BN / 8;                        // values per thread per step
+    constexpr int B_NI = BN / 8;                                      // gathered values per thread per step
+    constexpr int A_MG = BM / 4;                                        // groups of 4 consecutive m per tile
+    constexpr int A_KQ = 256 / A_MG;                                    // k-roles per m-group (8 or 16)
+    constexpr int A_NJ = 32 / A_KQ;                                     // k rows (float4 loads) per thread: 4 or 2
     // LDS image per operand: [h = k&1][row (m or pixel)][kk = k>>1], 16 consecutive k-pairs per row, so that a
     // lane fetches its operands for a whole K step with four ds_read_b128.  16-byte chunk q of row r is stored
     // at chunk q ^ ((r>>2)&3): the 16-lane ds_read_b128 service groups then touch 16 distinct bank quads.
@@ -73,9 +76,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     const int HWo = a.Hout * a.Wout;
     // staging roles: this thread owns row mc of the A image and row pc of the B image, parity hA / hB of k,
     // k-pairs [iA0, iA0+A_NI) / [iB0, iB0+B_NI): exactly the values one MFMA lane will read back.
-    const int mc = t % BM;
-    const int gA = __builtin_amdgcn_readfirstlane(t / BM);
-    const int hA = gA & 1, iA0 = (gA >> 1) * A_NI;
+    // A: thread owns 4 consecutive output channels (one float4 per k row) and A_NJ k rows of one parity
+    const int mg = t % A_MG;                 // m = mg*4 .. mg*4+3
+    const int kqA = t / A_MG;                // 0 .. A_KQ-1
+    const int hA = kqA & 1, iA0 = (kqA >> 1) * A_NJ;
     const int pc = t % BN;
     const int gB = __builtin_amdgcn_readfirstlane(t / BN);
     const int hB = gB & 1, iB0 = (gB >> 1) * B_NI;
@@ -93,13 +97,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
         if (ONE) inb += (size_t)ih0 * a.Win + iw0;
     }
     const size_t HWin = (size_t)a.Hin * a.Win;
-    const float* wcol = a.wT + m0 + mc;
+    const float* wcol = a.wT + m0 + mg * 4;
 
-    float ra[A_NI], rb[B_NI];
+    f32x4 ra[A_NJ];
+    float rb[B_NI];
 
     auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < A_NI; ++i) ra[i] = wcol[(size_t)(k0 + hA + 2 * (iA0 + i)) * a.Mpad];
+        for (int j = 0; j < A_NJ; ++j)
+            ra[j] = *reinterpret_cast<const f32x4*>(wcol + (size_t)(k0 + hA + 2 * (iA0 + j)) * a.Mpad);
         if (ONE) {
 #pragma unroll
             for (int i = 0; i < B_NI; ++i) {
@@ -129,11 +135,20 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
         }
     };
     auto store_lds = [&](int buf) {
-        const int swa = (mc >> 2) & 3, swb = (pc >> 2) & 3;
+        const int swb = (pc >> 2) & 3;
+        // 4x(A_NJ) register transpose: element (j, e) of the loaded rows is k-pair iA0+j of channel mg*4+e
 #pragma unroll
-        for (int q = 0; q < A_NI / 4; ++q) {
-            f32x4 v = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(&As[buf][hA][mc][((iA0 / 4 + q) ^ swa) * 4]) = v;
+        for (int e = 0; e < 4; ++e) {
+            const int m = mg * 4 + e;
+            float* dst = &As[buf][hA][m][0];
+            if (A_NJ == 4) {
+                f32x4 v = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+                *reinterpret_cast<f32x4*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2)) = v;   // (m>>2)&3 == mg&3
+            } else {
+                float2 v;
+                v.x = ra[0][e]; v.y = ra[1][e];
+                *reinterpret_cast<float2*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2) + (iA0 & 3)) = v;
+            }
         }
 #pragma unroll
         for (int q = 0; q < B_NI / 4; ++q) {
