@@ -120,8 +120,10 @@ def parity_vs_oracle(ca, nets, args):
     ca.setTarget(I2)
     r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
     same = bool(np.array_equal(r["index1"], g["index1"]) and np.array_equal(r["index2"], g["index2"]))
+    ref_set = set(zip(r["index1"].tolist(), r["index2"].tolist()))
+    got_set = set(zip(g["index1"].tolist(), g["index2"].tolist()))
     res = {"pair": "synthetic %dx%d seed %d" % (args.height, args.width, int(g["seed"])), "n_matches": int(len(r["index1"])),
-           "match_list_identical": same}
+           "match_list_identical": same, "n_matches_differing": len(ref_set ^ got_set)}
     if same:
         res["inlier_indices_bit_exact"] = bool(np.array_equal(r["inlier"], g["inlier"]))
         res["max_abs_H_delta"] = float(np.abs(r["H"] - g["H"]).max())

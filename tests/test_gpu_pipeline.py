@@ -141,3 +141,33 @@ def test_multi_homography_driver_matches_oracle(dev):
     # explained-region mask: thresholded matchability -> identical except where the value sits at the threshold
     diff = (out["mask"].cpu().numpy() != o["masks"][-1]).mean()
     assert diff < 1e-3
+
+
+@pytest.mark.parametrize("cfg", ["config4", "config5"])
+def test_large_configs_shapes_and_invariants(dev, cfg):
+    """BASELINE configs 4 (960x720, 5 scales x2, minSize 720, variant B) and 5 (KITTI 1242x376, 3 scales x1.2,
+    coarseSize 800): the cell counts of SURVEY Appendix C, a valid run of the coarse stage at those sizes (the
+    850 MB score matrix of config 5 is never materialised), run-to-run determinism and oracle-exact RANSAC on the
+    device's own match list."""
+    if cfg == "config4":
+        H, W, nbScale, scaleR, minSize, nA, nB = 720, 960, 5, 2.0, 720, 21675, 2700
+    else:
+        H, W, nbScale, scaleR, minSize, nA, nB = 376, 1242, 3, 1.2, 800, 25747, 8250
+    I1, I2 = synth.make_pair(H, W, seed=4)
+    pipe = AlignPipeline(dict(trunk=weights.resnet50_trunk_sd(0)), nbScale=nbScale, nbIter=500, tolerance=0.05,
+                         minSize=minSize, scaleR=scaleR, variant="B", device=dev)
+    prep = pipe.prepare([(I1, I2)])
+    feats = pipe.features(prep)
+    assert feats["nA"] == nA and feats["nB"] == nB
+    torch.manual_seed(5)
+    r1 = pipe.coarse(prep, feats=feats)[0]
+    torch.manual_seed(5)
+    r2 = pipe.coarse(prep, feats=feats)[0]
+    assert r1["n"] >= 4 and r1["status"] == 0
+    assert torch.equal(r1["index1"], r2["index1"]) and torch.equal(r1["index2"], r2["index2"])
+    assert torch.equal(r1["inlier"], r2["inlier"]) and torch.equal(r1["H"], r2["H"])
+    i1 = r1["index1"].cpu()
+    assert (i1[1:] > i1[:-1]).all() and int(r1["index2"].max()) < nB          # ordered, in range, one match per source cell
+    assert len(torch.unique(r1["index2"])) == r1["n"]                          # mutual => target cells unique too
+    Hb, cnt, inl, _ = restate.ransac(r1["match1"].cpu(), r1["match2"].cpu(), 0.05, r1["samples"])
+    assert int(cnt) == r1["count"] and np.array_equal(inl, r1["inlier"].cpu().numpy())
