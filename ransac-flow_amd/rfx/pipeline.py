@@ -186,15 +186,36 @@ class AlignPipeline:
         """evaluation/evalHpatch/evaluation.py:23-55 (PredFlowMask) for a batch."""
         IsSample = ops.grid_sample(IsTensor, flowCoarse)
         feats = ops.l2norm(self.feat(IsSample))
-        corr12 = ops.corr_neigh(featt, feats)
+        B = IsTensor.shape[0]
+        # both correlation directions in ONE launch, both matchability passes in one batch
+        c = ops.corr_neigh(torch.cat((featt, feats), dim=0), torch.cat((feats, featt), dim=0))
+        corr12 = c[:B]
         flowDown8 = self.flow(corr12, False)
-        match12Down8 = self.match(corr12, False)
-        corr21 = ops.corr_neigh(feats, featt)
-        match21Down8 = self.match(corr21, False)
+        md = self.match(c, False)
+        match12Down8, match21Down8 = md[:B], md[B:]
         H, W = flowCoarse.shape[1], flowCoarse.shape[2]
         match12 = ops.resize_bilinear(match12Down8, (H, W), align_corners=False)
         flow12, inb, _ = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True)
         match = match12 * inb.unsqueeze(1)
+        return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
+                    match21Down8=match21Down8)
+
+    def pred_flow_mask_kitti(self, IsSample, ItSample, flowCoarse):
+        """evaluation/evalKITTI/evaluation.py:49-81: both images go through the FeatureExtractor here, and the
+        matchability is cycle-checked: match = match12 * grid_sample(match21, flowUp) * in-bounds(flow12)."""
+        B = IsSample.shape[0]
+        f = ops.l2norm(self.feat(torch.cat((IsSample, ItSample), dim=0)))
+        feats, featt = f[:B], f[B:]
+        c = ops.corr_neigh(torch.cat((featt, feats), dim=0), torch.cat((feats, featt), dim=0))   # corr12 | corr21, one launch
+        corr12 = c[:B]
+        flowDown8 = self.flow(corr12, False)
+        md = self.match(c, False)
+        match12Down8, match21Down8 = md[:B], md[B:]
+        H, W = flowCoarse.shape[1], flowCoarse.shape[2]
+        m = ops.resize_bilinear(md, (H, W), align_corners=False)
+        match12, match21 = m[:B], m[B:]
+        flow12, inb, flowUp = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True, want_flow_up=True)
+        match = match12 * ops.grid_sample(match21, flowUp) * inb.unsqueeze(1)
         return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
                     match21Down8=match21Down8)
 

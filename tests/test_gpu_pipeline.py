@@ -89,6 +89,15 @@ def test_fine_stage_against_oracle_given_same_homography(dev):
     assert (pm["flow12"][0].cpu() - flow12[0]).abs().max() < 1e-3
     assert np.abs(pm["match"][0, 0].cpu().numpy() - match).max() < 1e-3
     assert np.abs(pm["match21Down8"][0].cpu().numpy() - md8[0, 1:2]).max() < 1e-4
+    # KITTI variant (evaluation/evalKITTI/evaluation.py:49-81): cycle-checked matchability
+    IsSample = ops.grid_sample(prep["IsTensor"], fc_d)
+    pk = pipe.pred_flow_mask_kitti(IsSample, prep["ItTensor"], fc_d)
+    with torch.no_grad():
+        f12k, mk, fdk, mdk = restate.pred_flow_mask_kitti(dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]),
+                                                          IsSample[:1].cpu(), prep["ItTensor"][:1].cpu(),
+                                                          restate.warp_grid(Hs[:1], 240, 320), restate.identity_grid(240, 320))
+    assert (pk["flow12"][0].cpu() - f12k[0]).abs().max() < 1e-3
+    assert np.abs(pk["match"][0, 0].cpu().numpy() - mk).max() < 1e-3
 
 
 def test_config2_coarse_480x640_properties(dev):
