@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--nb-iter", type=int, default=1000)
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-prep", action="store_true",
+                    help="build the LANCZOS pyramid with PIL on the host before the timed region (default: raw uint8 images "
+                         "resident in HBM, pyramid + ToTensor + Normalize on the device inside the timed step)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-file", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -182,12 +185,18 @@ def main():
     # this rank's shard of the synthetic stream: pair i -> rank i mod world
     pairs = [synth.make_pair(H, W, seed=rank + world * i) for i in range(B)]
     log("weights packed, synthetic pairs made")
-    prep = pipe.prepare(pairs)          # host PIL pyramid + upload: outside the timed region (inputs resident in HBM)
+    if args.host_prep:
+        prep = pipe.prepare(pairs)      # host PIL pyramid + upload: outside the timed region
+        raw = None
+    else:
+        raw = pipe.upload_raw(pairs)    # raw uint8 images resident in HBM; the pyramid is part of the timed step
+        prep = pipe.prepare_device(*raw)
     torch.manual_seed(123 + rank)
     log("inputs resident on %s" % dev)
 
     def step():
-        res = pipe.align_prepared(prep, fine=True)
+        p = prep if raw is None else pipe.prepare_device(*raw)
+        res = pipe.align_prepared(p, fine=True)
         rec = rdist.pack_records(res)                       # (B, 9 + 1 + 2*h8*w8) float32 on device
         return rdist.gather_records(rec, dist)              # ONE all_gather per step (no-op copy when world == 1)
 
@@ -260,7 +269,9 @@ def main():
                                    " + grid_sample (BASELINE configs 2+3 at the metric's 480x640)" % (B, H, W, args.nb_scale, args.nb_iter),
                        "pairs_per_step_per_gpu": B, "nbIter": args.nb_iter, "nbScale": args.nb_scale,
                        "parallelism": "pairs sharded over %d rank(s), one all_gather of result records per step" % world,
-                       "weights": "random-init", "aligned_ok_last_step": ok_pairs},
+                       "weights": "random-init", "aligned_ok_last_step": ok_pairs,
+                       "preprocessing": "host PIL, outside the timed region" if args.host_prep else
+                       "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step"},
             "roofline": roofline, "roofline_corr": roofline_corr,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -96,6 +96,25 @@ int rfx_resize_bilinear_f32(const float* in, float* out, int NC, int Hin, int Wi
                             int align_corners, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Image pre-processing on the device (host-side in the reference:
+ * quick_start/coarseAlignFeatMatch.py:55-57,80-110).
+ * ------------------------------------------------------------------------------------------ */
+/* One separable pass of Pillow's fixed-point LANCZOS resampler on uint8 NHWC images (C <= 4).
+ * vertical = 0: out (N, outH, outW, C) with out row y filtered from source row y + row_offset (outH + row_offset
+ * <= inH); vertical = 1: out (N, outH, inW, C) (outW must equal inW).  bounds: int32 (n_out, 2) = [first source
+ * index, tap count] per output coordinate; weights: int32 (n_out, ksize) = round(w * 2^22) (Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc; rfx/lanczos.py computes them).  Integer arithmetic: bit-identical to
+ * PIL.Image.resize(resample=LANCZOS) when the two passes are chained as Pillow does. */
+int rfx_lanczos_pass_u8(const uint8_t* in, uint8_t* out, int N, int inH, int inW, int outH, int outW, int C,
+                        const int32_t* bounds, const int32_t* weights, int ksize, int vertical, int row_offset,
+                        void* stream);
+
+/* torchvision ToTensor (+ Normalize): uint8 (N,H,W,3) -> float32 (N,3,H,W).  raw = x/255 (may be NULL),
+ * norm = (x/255 - mean[c]) / std[c] (may be NULL); mean3_host / std3_host are HOST pointers to 3 floats. */
+int rfx_u8_to_f32_chw(const uint8_t* in, float* raw, float* norm, int N, int H, int W, const float* mean3_host,
+                      const float* std3_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 7x7 local correlation volume (model/model.py:129-160, CorrNeigh.do_forward):
  *     out[n, i*K+j, r, c] = sum_ch x[n,ch,r,c] * y[n,ch,r+i-K/2,c+j-K/2]   (zero outside y)
  * K must be 7 (the only size the reference instantiates: quick_start/align2images.py:38).

@@ -22,6 +22,8 @@ SIGNATURES = {
     "rfx_l2norm_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "rfx_flow_head_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_resize_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "rfx_lanczos_pass_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "rfx_u8_to_f32_chw": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 3),
     "rfx_corr_neigh_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "rfx_grid_sample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),

@@ -158,6 +158,51 @@ def resize_bilinear(x, size, align_corners=False):
     return out
 
 
+_LANCZOS_TABLES = {}
+
+
+def lanczos_resize_u8(img, out_w, out_h):
+    """PIL.Image.resize((out_w, out_h), LANCZOS) for a uint8 (N,H,W,3) device tensor -- bit-identical to Pillow."""
+    from . import lanczos
+    img = _dev(img, "image", torch.uint8)
+    N, H, W, C = img.shape
+    p = lanczos.plan(W, H, out_w, out_h)
+    if p is None:
+        return img.clone()
+    key = (W, H, out_w, out_h, str(img.device))
+    tabs = _LANCZOS_TABLES.get(key)
+    if tabs is None:
+        tabs = {k: torch.from_numpy(p[k]).to(img.device) for k in ("bounds_h", "kk_h", "bounds_v", "kk_v")}
+        _LANCZOS_TABLES[key] = tabs
+    lib = _lib.load()
+    cur, curH = img, H
+    if p["need_h"]:
+        tmp = torch.empty((N, p["rows_h"], out_w, C), dtype=torch.uint8, device=img.device)
+        _lib.check(lib.rfx_lanczos_pass_u8(_p(cur), _p(tmp), N, H, W, p["rows_h"], out_w, C, _p(tabs["bounds_h"]),
+                                           _p(tabs["kk_h"]), p["ks_h"], 0, p["y_first"], _stream()), "rfx_lanczos_pass_u8")
+        cur, curH = tmp, p["rows_h"]
+    if p["need_v"]:
+        out = torch.empty((N, out_h, out_w, C), dtype=torch.uint8, device=img.device)
+        _lib.check(lib.rfx_lanczos_pass_u8(_p(cur), _p(out), N, curH, out_w, out_h, out_w, C, _p(tabs["bounds_v"]),
+                                           _p(tabs["kk_v"]), p["ks_v"], 1, 0, _stream()), "rfx_lanczos_pass_u8")
+        cur = out
+    return cur
+
+
+def u8_to_f32(img, mean=None, std=None, want_raw=True):
+    """ToTensor (/255) and, with mean/std, Normalize: uint8 (N,H,W,3) -> float32 (N,3,H,W) raw and/or normalised."""
+    img = _dev(img, "image", torch.uint8)
+    N, H, W, C = img.shape
+    if C != 3:
+        raise ValueError("u8_to_f32 expects 3 channels")
+    raw = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device) if want_raw else None
+    norm = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device) if mean is not None else None
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    s = (ctypes.c_float * 3)(*std) if std is not None else None
+    _lib.check(_lib.load().rfx_u8_to_f32_chw(_p(img), _p(raw), _p(norm), N, H, W, m, s, _stream()), "rfx_u8_to_f32_chw")
+    return raw, norm
+
+
 def corr_neigh(x, y, K=7):
     x, y = _dev(x, "corr x"), _dev(y, "corr y")
     if x.shape != y.shape:

@@ -88,6 +88,32 @@ class AlignPipeline:
         return dict(src=[norm(s) for s in src], tgt=norm(tgt), IsTensor=torch.stack(IsT).to(self.dev),
                     ItTensor=torch.stack(tgt).to(self.dev), B=len(pairs))
 
+    def upload_raw(self, pairs):
+        """Raw uint8 images of a batch -> device (N,H,W,3) tensors (what a decoder would leave in HBM)."""
+        src = torch.from_numpy(np.stack([np.asarray(p[0].convert("RGB"), dtype=np.uint8) for p in pairs])).to(self.dev)
+        tgt = torch.from_numpy(np.stack([np.asarray(p[1].convert("RGB"), dtype=np.uint8) for p in pairs])).to(self.dev)
+        return src, tgt
+
+    def prepare_device(self, src_u8, tgt_u8):
+        """Same result as ``prepare`` -- bit for bit -- with the LANCZOS pyramid, ToTensor and Normalize computed on
+        the device from raw uint8 (N,H,W,3) images: Pillow's fixed-point resampler and the float
+        conversions are reproduced exactly by rfx_lanczos_pass_u8 / rfx_u8_to_f32_chw."""
+        mode = "max" if self.variant == "A" else "min"
+        B, h, w, _ = src_u8.shape
+        srcs, IsT = [], None
+        mid = len(self.scaleList) // 2
+        for i, sc in enumerate(self.scaleList):
+            nw, nh = resize_dims(w, h, int(self.minSize * sc), mode)
+            im = ops.lanczos_resize_u8(src_u8, nw, nh)
+            raw, norm = ops.u8_to_f32(im, IMAGENET_MEAN, IMAGENET_STD, want_raw=(i == mid))
+            srcs.append(norm)
+            if i == mid:
+                IsT = raw
+        th, tw = tgt_u8.shape[1], tgt_u8.shape[2]
+        nw, nh = resize_dims(tw, th, self.minSize, mode)
+        ItT, tnorm = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, nw, nh), IMAGENET_MEAN, IMAGENET_STD)
+        return dict(src=srcs, tgt=tnorm, IsTensor=IsT, ItTensor=ItT, B=B)
+
     # ---------------------------------------------------------------- coarse stage
     def features(self, prep):
         """ResNet-50 conv4 features of every pyramid level and of the target, L2-normalised, written into

@@ -288,3 +288,32 @@ def test_networks_match_reference_golden(dev):
     assert np.abs(nf(c, False).cpu().numpy() - g["fine_flow"]).max() < 1e-5
     assert np.abs(nf(c, True).cpu().numpy() - g["fine_flow8"]).max() < 1e-5
     assert np.abs(nm(c, False).cpu().numpy() - g["fine_match"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ device pre-processing
+
+
+def test_lanczos_and_to_tensor_bit_exact_vs_pillow(dev):
+    """The device resampler reproduces PIL.Image.resize(LANCZOS) byte for byte and ToTensor/Normalize bit for bit,
+    so prepare_device() == prepare()."""
+    import PIL.Image as Image
+    from rfx import synth
+    from rfx.pipeline import AlignPipeline
+    rng = np.random.RandomState(3)
+    for (w, h, ow, oh) in [(640, 480, 768, 576), (640, 480, 528, 400), (333, 217, 640, 416), (640, 480, 320, 480),
+                           (500, 300, 500, 150), (64, 48, 64, 48)]:
+        imgs = (rng.rand(2, h, w, 3) * 255).astype(np.uint8)
+        ref = np.stack([np.asarray(Image.fromarray(im).resize((ow, oh), resample=Image.LANCZOS)) for im in imgs])
+        got = ops.lanczos_resize_u8(torch.from_numpy(imgs).to(dev), ow, oh).cpu().numpy()
+        assert np.array_equal(got, ref), (w, h, ow, oh)
+    pairs = [synth.make_pair(240, 320, seed=s) for s in (0, 1)]
+    for variant, minSize in (("A", 320), ("B", 240)):
+        pipe = AlignPipeline(dict(trunk=weights.resnet50_trunk_sd(0)), nbScale=7, nbIter=10, tolerance=0.05, minSize=minSize,
+                             scaleR=1.2, variant=variant, device=dev)
+        host = pipe.prepare(pairs)
+        devp = pipe.prepare_device(*pipe.upload_raw(pairs))
+        assert len(host["src"]) == len(devp["src"])
+        for a, b in zip(host["src"], devp["src"]):
+            assert a.shape == b.shape and torch.equal(a, b)
+        for k in ("tgt", "IsTensor", "ItTensor"):
+            assert torch.equal(host[k], devp[k]), k
