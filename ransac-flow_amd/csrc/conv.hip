@@ -21,6 +21,7 @@
 // Epilogue fused: y = fma(acc, scale[m], shift[m]) (+ residual) -> ReLU / sigmoid; stores coalesced
 // along the pixel dimension (the MFMA C/D column index is the pixel).
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const float* in;
@@ -38,8 +39,13 @@ struct ConvArgs {
 
 // ONE = 1x1 kernel with pad 0 (any stride): k IS the input channel and every tap is in bounds, so the im2col
 // gather needs no ktab decode and no bounds logic (address = pixel base + k * Hin*Win).
-template <int TM, int TN, bool ONE>
-__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
+// WS = wave-specialised form for long K loops: 512 threads = 4 MFMA wavefronts (one per SIMD, 64x64 outputs each,
+// nothing but ds_read_b128 + MFMA in their loop) + 4 loader wavefronts (one per SIMD) that run the whole im2col
+// gather / weight fetch / LDS staging.  A 32x32x2 fp32 MFMA keeps the matrix pipe busy for 64 cycles per issue,
+// so the loader wave's ~600 address/load/store instructions per K step fit in the issue slots the MFMA wave
+// leaves free -- the overlap the single-role kernel only gets statistically from a second workgroup.
+template <int TM, int TN, bool ONE, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
     constexpr int B_NI = BN / 8;                                      // gathered values per thread per step
     constexpr int A_MG = BM / 4;                                        // groups of 4 consecutive m per tile
@@ -52,7 +58,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KK];
     __shared__ float s_scale[BM], s_shift[BM];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int t = tid & 255;  // staging index (WS: the loader wavefronts are threads 256..511)
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware bijective remap: each XCD (observed: block b -> XCD b%8) walks a contiguous chunk of
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     const int m0 = tm_idx * BM;
     const long long n0 = (long long)tp_idx * BN;
 
-    if (t < BM) {  // folded BatchNorm of this block's output channels -> LDS (visible after the first barrier)
+    if (tid < BM) {  // folded BatchNorm of this block's output channels -> LDS (visible after the first barrier)
         const int m = m0 + t;
         s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
         s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
@@ -165,17 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = a.Kpad / BK;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-
     const int lrow = lane >> 5, lcol = lane & 31;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // branch-free body (the last step re-loads its own tile into the unused buffer): one basic block, so the
-        // scheduler is free to interleave the gather of step kt+1 with the MFMAs of step kt
-        load_global((kt + 1 < nk ? kt + 1 : kt) * BK);
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {  // two halves of 8 k-pairs keep the fragment registers at 32
             f32x4 af[TM][2], bf[TN][2];
@@ -203,9 +201,43 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
-        store_lds(cur ^ 1);
+    };
+
+    const int nk = a.Kpad / BK;
+    if (WS) {
+        if (__builtin_amdgcn_readfirstlane(tid >> 8) != 0) {
+            // ---- loader wavefronts: tile kt+1 is written to LDS during step kt, tile kt+2 is in flight ----
+            load_global(0);
+            store_lds(0);
+            if (nk > 1) load_global(BK);
+            __syncthreads();
+            for (int kt = 0; kt < nk; ++kt) {
+                if (kt + 1 < nk) store_lds((kt + 1) & 1);
+                if (kt + 2 < nk) load_global((kt + 2) * BK);
+                __syncthreads();
+            }
+            return;
+        }
+        // ---- MFMA wavefronts ----
         __syncthreads();
-        cur ^= 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            compute(kt & 1);
+            __syncthreads();
+        }
+    } else {
+        load_global(0);
+        store_lds(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // branch-free body (the last step re-loads its own tile into the unused buffer): one basic block, so the
+            // scheduler is free to interleave the gather of step kt+1 with the MFMAs of step kt
+            load_global((kt + 1 < nk ? kt + 1 : kt) * BK);
+            compute(cur);
+            store_lds(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -246,14 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     }
 }
 
-template <int TM, int TN, bool ONE>
+template <int TM, int TN, bool ONE, bool WS>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     a.tilesM = (a.Cout + BM - 1) / BM;
     a.tilesP = (int)((a.P + BN - 1) / BN);
     const long long nwg = (long long)a.tilesM * a.tilesP;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE, WS>), dim3((unsigned)nwg), dim3(WS ? 512 : 256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -289,9 +321,19 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     a.P = (long long)N * a.Hout * a.Wout;
     hipStream_t st = rfx_stream(stream);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
-    switch (rfx_conv2d_tile_variant(N, Cout, a.Hout, a.Wout)) {
-        case 0: return one ? launch_conv<2, 2, true>(a, st) : launch_conv<2, 2, false>(a, st);
-        case 1: return one ? launch_conv<1, 2, true>(a, st) : launch_conv<1, 2, false>(a, st);
-        default: return one ? launch_conv<1, 1, true>(a, st) : launch_conv<1, 1, false>(a, st);
+    // The wave-specialised form pays off where the gather is the heavy part and the K loop is long: KxK (K > 1)
+    // convolutions on the 128x128 tile (measured +5 % there, -5...-15 % on 1x1 and 64-wide tiles, which keep the
+    // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
+    static const int ws_env = getenv("RFX_CONV_WS") ? atoi(getenv("RFX_CONV_WS")) : -1;
+    const int variant = rfx_conv2d_tile_variant(N, Cout, a.Hout, a.Wout);
+    const bool ws = ws_env < 0 ? (variant == 0 && !one && a.Kpad >= 256) : (ws_env != 0);
+    switch (variant) {
+        case 0:
+            if (ws) return one ? launch_conv<2, 2, true, true>(a, st) : launch_conv<2, 2, false, true>(a, st);
+            return one ? launch_conv<2, 2, true, false>(a, st) : launch_conv<2, 2, false, false>(a, st);
+        case 1:
+            if (ws) return one ? launch_conv<1, 2, true, true>(a, st) : launch_conv<1, 2, false, true>(a, st);
+            return one ? launch_conv<1, 2, true, false>(a, st) : launch_conv<1, 2, false, false>(a, st);
+        default: return one ? launch_conv<1, 1, true, false>(a, st) : launch_conv<1, 1, false, false>(a, st);
     }
 }
