@@ -227,8 +227,15 @@ def main():
     ok_pairs = int((out[:, 9] == 0).sum().item())
 
     # ---- roofline of the dominant kernel (events were recorded on the launch stream inside the timed region)
-    dom = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _) in conv_t if v == 0]
     allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _) in conv_t]
+    by_kernel = {}
+    for (v, f, e0, e1, _) in conv_t:
+        g = by_kernel.setdefault(v, [0, 0.0, 0.0])
+        g[0] += 1; g[1] += f; g[2] += e0.elapsed_time(e1) * 1e-3
+    dom_id = max(by_kernel, key=lambda k: by_kernel[k][2])          # the kernel instance with the most GPU time
+    dom_n, dom_f, dom_t = by_kernel[dom_id]
+    tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
+    dom_name = "conv2d_mfma_kernel<%s, %s, %s>" % (tmn, "true" if dom_id & 4 else "false", "true" if dom_id & 8 else "false")
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
         agg = {}
         for (v, f, e0, e1, shp) in conv_t:
@@ -240,22 +247,39 @@ def main():
             tot = sum(r[3] for r in rows)
             for k, c, f, t in rows:
                 fh.write(",".join(str(x) for x in k) + ",%d,%.3f,%.1f,%.3f\n" % (c, t * 1e3, f / t / 1e12, t / tot))
-    if not dom:
-        dom = allc
-    flops_per_launch = sum(f for f, _ in dom) / len(dom)
-    avg_dur = sum(d for _, d in dom) / len(dom)
+    flops_per_launch = dom_f / dom_n
+    avg_dur = dom_t / dom_n
     ach = flops_per_launch / avg_dur / 1e12
-    roofline = {"kernel": "conv2d_mfma_kernel<2,2>", "bound": "mfma", "achieved": round(ach, 2),
+    roofline = {"kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches": len(dom), "avg_launch_us": round(avg_dur * 1e6, 2),
-                "flop_per_launch": flops_per_launch,
+                "traffic": None, "launches": dom_n, "avg_launch_us": round(avg_dur * 1e6, 2),
+                "flop_per_launch": flops_per_launch, "time_share": round(dom_t / elapsed, 3),
                 "all_conv_tflops": round(sum(f for f, _ in allc) / sum(d for _, d in allc) / 1e12, 2),
-                "conv_time_share": round(sum(d for _, d in allc) / elapsed, 3)}
+                "conv_time_share": round(sum(d for _, d in allc) / elapsed, 3),
+                "conv_kernels": {("%d" % k): {"launches": n, "tflops": round(f / t / 1e12, 1), "time_share": round(t / elapsed, 3)}
+                                 for k, (n, f, t) in sorted(by_kernel.items())}}
+    # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench)
+    roofline["algorithmic_bytes_per_launch"] = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_b64.json")))["kernels"]
+        for name, e in pmc.items():
+            if dom_name in name and B == 64:
+                roofline["traffic"] = round(e["FETCH_SIZE_bytes_per_launch_raw"] + e["WRITE_SIZE_bytes_per_launch_raw"])
+                roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE (x1024 B) per launch from profiles/r01_pmc_summary_b64.json, raw: "
+                                            "4-byte/lane reads are uncalibrated on gfx950 (16-byte/lane reads under-count 2x)")
+                roofline["mfma_busy_frac_pmc"] = round(e.get("mfma_busy_frac_at_2.4GHz", 0.0), 3)
+            if "corr7_dma_kernel" in name and B == 64:
+                corr_pmc = e
+    except Exception:
+        corr_pmc = None
     cb = sum(b for b, _, _ in corr_t) / len(corr_t)
     cd = sum(e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in corr_t) / len(corr_t)
     roofline_corr = {"kernel": "corr7_dma_kernel", "bound": "hbm", "achieved": round(cb / cd / 1e9, 1),
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(cb / cd / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                      "bytes_per_launch": cb, "avg_launch_us": round(cd * 1e6, 2)}
+    if locals().get("corr_pmc"):
+        # 16-byte/lane LDS-DMA reads: FETCH_SIZE counts exactly half the bytes on gfx950 (MI355X_MICROARCH.md) -> x2
+        roofline_corr["traffic"] = round(2 * corr_pmc["FETCH_SIZE_bytes_per_launch_raw"] + corr_pmc["WRITE_SIZE_bytes_per_launch_raw"])
 
     if rank == 0:
         total_pairs = B * args.steps * world

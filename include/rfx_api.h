@@ -63,6 +63,10 @@ int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const 
  * caller attribute algorithmic FLOPs to the kernel instance rocprofv3 reports. */
 int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 
+/* Full kernel-instance id of the launch: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
+ * wave-specialised form (4 MFMA + 4 loader wavefronts): the template arguments <TM,TN,ONE,WS> rocprofv3 prints. */
+int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int pad, int Hout, int Wout);
+
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;
  * model/model.py:71: k=2,s=1,p=0).  Hout = (Hin+2p-k)/s+1. */
 int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int k, int stride,

@@ -301,6 +301,23 @@ extern "C" int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout) {
     return 2;
 }
 
+static int conv_ws_env() {
+    static const int v = getenv("RFX_CONV_WS") ? atoi(getenv("RFX_CONV_WS")) : -1;
+    return v;
+}
+
+// Kernel instance rfx_conv2d_f32 launches for this geometry: bits 0-1 tile variant (0: <2,2>, 1: <1,2>, 2: <1,1>),
+// bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), i.e. the template arguments of
+// conv2d_mfma_kernel<TM,TN,ONE,WS> that rocprofv3 prints.
+extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int pad, int Hout, int Wout) {
+    const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
+    const bool one = (KH == 1 && KW == 1 && pad == 0);
+    const int Kpad = (Cin * KH * KW + 31) / 32 * 32;
+    const int env = conv_ws_env();
+    const bool ws = variant == 2 ? false : (env < 0 ? (variant == 0 && !one && Kpad >= 256) : (env != 0));
+    return variant | (one ? 4 : 0) | (ws ? 8 : 0);
+}
+
 extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
                               const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
                               int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
@@ -324,9 +341,9 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     // The wave-specialised form pays off where the gather is the heavy part and the K loop is long: KxK (K > 1)
     // convolutions on the 128x128 tile (measured +5 % there, -5...-15 % on 1x1 and 64-wide tiles, which keep the
     // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
-    static const int ws_env = getenv("RFX_CONV_WS") ? atoi(getenv("RFX_CONV_WS")) : -1;
-    const int variant = rfx_conv2d_tile_variant(N, Cout, a.Hout, a.Wout);
-    const bool ws = ws_env < 0 ? (variant == 0 && !one && a.Kpad >= 256) : (ws_env != 0);
+    const int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, pad, a.Hout, a.Wout);
+    const int variant = kid & 3;
+    const bool ws = (kid & 8) != 0;
     switch (variant) {
         case 0:
             if (ws) return one ? launch_conv<2, 2, true, true>(a, st) : launch_conv<2, 2, false, true>(a, st);

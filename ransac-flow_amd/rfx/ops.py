@@ -88,7 +88,7 @@ class ConvPlan:
         if tm is not None:
             e1.record()
             flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
-            tm.append((lib.rfx_conv2d_tile_variant(N, self.Cout, Ho, Wo), flops, e0, e1,
+            tm.append((lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.pad, Ho, Wo), flops, e0, e1,
                        (N, self.Cin, H, W, self.Cout, self.KH, self.stride)))
         return out
 
