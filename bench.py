@@ -227,18 +227,18 @@ def main():
     ok_pairs = int((out[:, 9] == 0).sum().item())
 
     # ---- roofline of the dominant kernel (events were recorded on the launch stream inside the timed region)
-    allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _) in conv_t]
+    allc = [(f, e0.elapsed_time(e1) * 1e-3) for (v, f, e0, e1, _, _) in conv_t]
     by_kernel = {}
-    for (v, f, e0, e1, _) in conv_t:
-        g = by_kernel.setdefault(v, [0, 0.0, 0.0])
-        g[0] += 1; g[1] += f; g[2] += e0.elapsed_time(e1) * 1e-3
+    for (v, f, e0, e1, _, nb) in conv_t:
+        g = by_kernel.setdefault(v, [0, 0.0, 0.0, 0.0])
+        g[0] += 1; g[1] += f; g[2] += e0.elapsed_time(e1) * 1e-3; g[3] += nb
     dom_id = max(by_kernel, key=lambda k: by_kernel[k][2])          # the kernel instance with the most GPU time
-    dom_n, dom_f, dom_t = by_kernel[dom_id]
+    dom_n, dom_f, dom_t, dom_b = by_kernel[dom_id]
     tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
     dom_name = "conv2d_mfma_kernel<%s, %s, %s>" % (tmn, "true" if dom_id & 4 else "false", "true" if dom_id & 8 else "false")
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
         agg = {}
-        for (v, f, e0, e1, shp) in conv_t:
+        for (v, f, e0, e1, shp, _) in conv_t:
             a = agg.setdefault((v,) + shp, [0, 0.0, 0.0])
             a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1) * 1e-3
         rows = sorted(((k, c, f, t) for k, (c, f, t) in agg.items()), key=lambda r: -r[3])
@@ -257,9 +257,9 @@ def main():
                 "all_conv_tflops": round(sum(f for f, _ in allc) / sum(d for _, d in allc) / 1e12, 2),
                 "conv_time_share": round(sum(d for _, d in allc) / elapsed, 3),
                 "conv_kernels": {("%d" % k): {"launches": n, "tflops": round(f / t / 1e12, 1), "time_share": round(t / elapsed, 3)}
-                                 for k, (n, f, t) in sorted(by_kernel.items())}}
+                                 for k, (n, f, t, _) in sorted(by_kernel.items())}}
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench)
-    roofline["algorithmic_bytes_per_launch"] = None
+    roofline["algorithmic_bytes_per_launch"] = round(dom_b / dom_n)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_b64.json")))["kernels"]
         for name, e in pmc.items():
