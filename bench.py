@@ -235,7 +235,8 @@ def main():
     dom_id = max(by_kernel, key=lambda k: by_kernel[k][2])          # the kernel instance with the most GPU time
     dom_n, dom_f, dom_t, dom_b = by_kernel[dom_id]
     tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
-    dom_name = "conv2d_mfma_kernel<%s, %s, %s>" % (tmn, "true" if dom_id & 4 else "false", "true" if dom_id & 8 else "false")
+    tf = lambda b: "true" if b else "false"
+    dom_name = "conv2d_mfma_kernel<%s, %s, %s, %s>" % (tmn, tf(dom_id & 4), tf(dom_id & 8), tf(dom_id & 16))
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
         agg = {}
         for (v, f, e0, e1, shp, _) in conv_t:

@@ -44,13 +44,17 @@ struct ConvArgs {
 // gather / weight fetch / LDS staging.  A 32x32x2 fp32 MFMA keeps the matrix pipe busy for 64 cycles per issue,
 // so the loader wave's ~600 address/load/store instructions per K step fit in the issue slots the MFMA wave
 // leaves free -- the overlap the single-role kernel only gets statistically from a second workgroup.
-template <int TM, int TN, bool ONE, bool WS>
+// VECB (only with ONE, stride 1, Hout*Wout % 4 == 0): a thread fetches 4 consecutive pixels of one input channel
+// with one 16-byte load (the im2col row of a 1x1 convolution is the NCHW plane itself), mirroring the weight side:
+// 4x fewer gather instructions.
+template <int TM, int TN, bool ONE, bool WS, bool VECB>
 __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
     constexpr int B_NI = BN / 8;                                      // gathered values per thread per step
     constexpr int A_MG = BM / 4;                                        // groups of 4 consecutive m per tile
     constexpr int A_KQ = 256 / A_MG;                                    // k-roles per m-group (8 or 16)
     constexpr int A_NJ = 32 / A_KQ;                                     // k rows (float4 loads) per thread: 4 or 2
+    constexpr int B_PG = BN / 4, B_KQ = 256 / B_PG, B_NJ = 32 / B_KQ;   // the same decomposition for the pixel side (VECB)
     // LDS image per operand: [h = k&1][row (m or pixel)][kk = k>>1], 16 consecutive k-pairs per row, so that a
     // lane fetches its operands for a whole K step with four ds_read_b128.  16-byte chunk q of row r is stored
     // at chunk q ^ ((r>>2)&3): the 16-lane ds_read_b128 service groups then touch 16 distinct bank quads.
@@ -105,6 +109,20 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
     }
     const size_t HWin = (size_t)a.Hin * a.Win;
     const float* wcol = a.wT + m0 + mg * 4;
+    // VECB staging role: pixels pg*4 .. pg*4+3 of the tile (same image: HWo % 4 == 0), B_NJ k rows of parity hV
+    const int pg = t % B_PG, kqB = t / B_PG;
+    const int hV = kqB & 1, iV0 = (kqB >> 1) * B_NJ;
+    const float* inv = a.in;
+    bool vvalid = false;
+    if (VECB) {
+        const long long pv4 = n0 + pg * 4;
+        vvalid = pv4 < a.P;
+        if (vvalid) {
+            const int n = (int)(pv4 / HWo);
+            inv = a.in + (size_t)n * a.Cin * HWin + (size_t)(pv4 - (long long)n * HWo);  // stride 1, pad 0: same plane offset
+        }
+    }
+    f32x4 rv[B_NJ];
 
     f32x4 ra[A_NJ];
     float rb[B_NI];
@@ -113,6 +131,17 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
 #pragma unroll
         for (int j = 0; j < A_NJ; ++j)
             ra[j] = *reinterpret_cast<const f32x4*>(wcol + (size_t)(k0 + hA + 2 * (iA0 + j)) * a.Mpad);
+        if (VECB) {
+#pragma unroll
+            for (int j = 0; j < B_NJ; ++j) {
+                const int k = k0 + hV + 2 * (iV0 + j);
+                const bool ok = vvalid & (k < a.Cin);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(inv + (size_t)(ok ? k : 0) * HWin);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rv[j] = ok ? v : z;
+            }
+            return;
+        }
         if (ONE) {
 #pragma unroll
             for (int i = 0; i < B_NI; ++i) {
@@ -156,6 +185,21 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
                 v.x = ra[0][e]; v.y = ra[1][e];
                 *reinterpret_cast<float2*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2) + (iA0 & 3)) = v;
             }
+        }
+        if (VECB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = &Bs[buf][hV][pg * 4 + e][0];
+                if (B_NJ == 4) {
+                    f32x4 v = {rv[0][e], rv[1][e], rv[2][e], rv[3][e]};
+                    *reinterpret_cast<f32x4*>(dst + (((iV0 >> 2) ^ (pg & 3)) << 2)) = v;
+                } else {
+                    float2 v;
+                    v.x = rv[0][e]; v.y = rv[1][e];
+                    *reinterpret_cast<float2*>(dst + (((iV0 >> 2) ^ (pg & 3)) << 2) + (iV0 & 3)) = v;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int q = 0; q < B_NI / 4; ++q) {
@@ -278,14 +322,14 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
     }
 }
 
-template <int TM, int TN, bool ONE, bool WS>
+template <int TM, int TN, bool ONE, bool WS, bool VECB = false>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     a.tilesM = (a.Cout + BM - 1) / BM;
     a.tilesP = (int)((a.P + BN - 1) / BN);
     const long long nwg = (long long)a.tilesM * a.tilesP;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE, WS>), dim3((unsigned)nwg), dim3(WS ? 512 : 256), 0, st, a);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE, WS, VECB>), dim3((unsigned)nwg), dim3(WS ? 512 : 256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -307,15 +351,17 @@ static int conv_ws_env() {
 }
 
 // Kernel instance rfx_conv2d_f32 launches for this geometry: bits 0-1 tile variant (0: <2,2>, 1: <1,2>, 2: <1,1>),
-// bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), i.e. the template arguments of
-// conv2d_mfma_kernel<TM,TN,ONE,WS> that rocprofv3 prints.
+// bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), bit 4 = vectorised pixel-side loads
+// (VECB; assumes stride 1), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
 extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int pad, int Hout, int Wout) {
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     const int Kpad = (Cin * KH * KW + 31) / 32 * 32;
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env < 0 ? (variant == 0 && !one && Kpad >= 256) : (env != 0));
-    return variant | (one ? 4 : 0) | (ws ? 8 : 0);
+    static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
+    const bool vecb = vec_env && one && !ws && ((long long)Hout * Wout) % 4 == 0;  // stride checked by the caller
+    return variant | (one ? 4 : 0) | (ws ? 8 : 0) | (vecb ? 16 : 0);
 }
 
 extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
@@ -341,9 +387,18 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     // The wave-specialised form pays off where the gather is the heavy part and the K loop is long: KxK (K > 1)
     // convolutions on the 128x128 tile (measured +5 % there, -5...-15 % on 1x1 and 64-wide tiles, which keep the
     // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
-    const int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, pad, a.Hout, a.Wout);
+    int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, pad, a.Hout, a.Wout);
+    if (stride != 1 || (reinterpret_cast<uintptr_t>(in) & 15)) kid &= ~16;  // VECB needs the plane offsets to coincide and 16-B alignment
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;
+    const bool vecb = (kid & 16) != 0;
+    if (vecb) {  // 1x1, stride 1, Hout*Wout % 4 == 0: vectorised pixel-side loads (never wave-specialised)
+        switch (variant) {
+            case 0: return launch_conv<2, 2, true, false, true>(a, st);
+            case 1: return launch_conv<1, 2, true, false, true>(a, st);
+            default: return launch_conv<1, 1, true, false, true>(a, st);
+        }
+    }
     switch (variant) {
         case 0:
             if (ws) return one ? launch_conv<2, 2, true, true>(a, st) : launch_conv<2, 2, false, true>(a, st);
