@@ -236,7 +236,10 @@ def main():
     dom_n, dom_f, dom_t, dom_b = by_kernel[dom_id]
     tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
     tf = lambda b: "true" if b else "false"
-    dom_name = "conv2d_mfma_kernel<%s, %s, %s, %s>" % (tmn, tf(dom_id & 4), tf(dom_id & 8), tf(dom_id & 16))
+    if dom_id & 32:
+        dom_name = "conv3x3_direct_kernel<%d>" % (1 if dom_id & 3 else 2)
+    else:
+        dom_name = "conv2d_mfma_kernel<%s, %s, %s, %s>" % (tmn, tf(dom_id & 4), tf(dom_id & 8), tf(dom_id & 16))
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
         agg = {}
         for (v, f, e0, e1, shp, _) in conv_t:

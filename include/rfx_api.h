@@ -64,9 +64,10 @@ int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const 
 int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 
 /* Full kernel-instance id of the launch: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
- * wave-specialised form (4 MFMA + 4 loader wavefronts), bit 4 = 16-byte pixel-side loads (1x1, assumes stride 1):
- * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints. */
-int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int pad, int Hout, int Wout);
+ * wave-specialised form (4 MFMA + 4 loader wavefronts), bit 4 = 16-byte pixel-side loads (1x1, stride 1):
+ * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints.  Bit 5 = the direct 3x3 / stride 1 / pad 1 kernel
+ * conv3x3_direct_kernel<TM> (Cin % 8 == 0), TM = 2 if bits 0-1 are 0 else 1. */
+int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
 
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;
  * model/model.py:71: k=2,s=1,p=0).  Hout = (Hin+2p-k)/s+1. */

@@ -334,6 +334,10 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return RFX_OK;
 }
 
+int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
+                              const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
+                              int act, int tm, hipStream_t st);  // conv3x3.hip
+
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
 extern "C" int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout) {
@@ -352,15 +356,23 @@ static int conv_ws_env() {
 
 // Kernel instance rfx_conv2d_f32 launches for this geometry: bits 0-1 tile variant (0: <2,2>, 1: <1,2>, 2: <1,1>),
 // bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), bit 4 = vectorised pixel-side loads
-// (VECB; assumes stride 1), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
-extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int pad, int Hout, int Wout) {
+// (VECB), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
+// bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM>, TM = 2 - (bits 0-1 != 0)).
+extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout,
+                                    int Wout) {
+    static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
+    if (direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
+        const long long tiles = (long long)N * ((Hout + 7) / 8) * ((Wout + 15) / 16);
+        const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
+        return 32 | (big ? 0 : 1);
+    }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     const int Kpad = (Cin * KH * KW + 31) / 32 * 32;
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env < 0 ? (variant == 0 && !one && Kpad >= 256) : (env != 0));
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
-    const bool vecb = vec_env && one && !ws && ((long long)Hout * Wout) % 4 == 0;  // stride checked by the caller
+    const bool vecb = vec_env && one && !ws && stride == 1 && ((long long)Hout * Wout) % 4 == 0;
     return variant | (one ? 4 : 0) | (ws ? 8 : 0) | (vecb ? 16 : 0);
 }
 
@@ -387,8 +399,11 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     // The wave-specialised form pays off where the gather is the heavy part and the K loop is long: KxK (K > 1)
     // convolutions on the 128x128 tile (measured +5 % there, -5...-15 % on 1x1 and 64-wide tiles, which keep the
     // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
-    int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, pad, a.Hout, a.Wout);
-    if (stride != 1 || (reinterpret_cast<uintptr_t>(in) & 15)) kid &= ~16;  // VECB needs the plane offsets to coincide and 16-B alignment
+    int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout);
+    if (kid & 32)
+        return rfx_conv3x3_direct_launch(in, wT, scale, shift, residual, out, N, Cin, Hin, Win, Cout, a.Mpad, act,
+                                         (kid & 3) ? 1 : 2, st);
+    if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;
     const bool vecb = (kid & 16) != 0;

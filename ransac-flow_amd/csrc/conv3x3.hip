@@ -1,0 +1,220 @@
+// conv3x3.hip -- direct 3x3 / stride 1 / pad 1 convolution on the fp32 MFMA (the heaviest layer class of the path:
+// ResNet-50 Bottleneck conv2 at stride 1, model/resnet50.py:75; every BasicBlock conv of the FeatureExtractor,
+// model/model.py:32-35; the NetFlowCoarse / NetMatchability stacks, model/model.py:170-181).
+//
+// The implicit-GEMM kernel of conv.hip gathers its im2col operand element by element: ~10 address / bounds
+// instructions per gathered float, which is what holds it at ~60 % of the matrix peak.  Here a workgroup owns an
+// 8 x 16 patch of output pixels of ONE image and stages the RAW input patch (10 x 18 per channel, zero filled at the
+// image border) in LDS once per 8 input channels; the MFMA B operand for tap (c, kh, kw) of pixel (r, x) is then the
+// LDS word [c][r+kh][x+kw] -- fetched with one ds_read_b32 at a per-lane address that is precomputed ONCE (the 36
+// k-pair offsets of a K step repeat every step).  No per-element index arithmetic is left in the loop:
+//     per K step (72 = 8 channels x 9 taps): 12 float4 weight loads + 6 input loads per thread,
+//     then per wavefront 18 ds_read_b128 (A) + 72 ds_read_b32 (B) + 144 MFMAs.
+// A operand (weights) as in conv.hip: LDS image [k&1][m][k>>1] with 36 k-pairs per row (row stride 144 B: the
+// 16-lane ds_read_b128 groups hit 16 distinct bank quads without a swizzle because 9 is odd).
+// B patch rows are 48 floats apart so that the two 16-pixel rows a 32-lane half reads fall on disjoint banks.
+// Numerics: k runs channel-major, taps row-major -- the same order as conv.hip / the packed weight matrix, so the
+// result is bit-identical to the implicit-GEMM kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int PT_R = 8, PT_C = 16;          // output patch
+constexpr int PR = PT_R + 2, PC = PT_C + 2;  // input patch incl. halo
+constexpr int BS = 48;                       // LDS row stride of the patch (floats)
+constexpr int CH = 8;                        // input channels per K step
+constexpr int KS = CH * 9;                   // 72 k per step
+constexpr int KK = KS / 2;                   // 36 k-pairs
+
+struct C3Args {
+    const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
+    int N, Cin, H, W, Cout, act, Mpad;
+    int tilesM, tilesH, tilesW;
+};
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
+    constexpr int BM = 64 * TM;
+    constexpr int A_MG = BM / 4;          // groups of 4 consecutive output channels
+    constexpr int A_THREADS = 6 * A_MG;   // 2 parities x 3 chunk-triples
+    __shared__ __attribute__((aligned(16))) float As[2][BM][KK];
+    __shared__ __attribute__((aligned(16))) float Bs[CH][PR][BS];
+    __shared__ float s_scale[BM], s_shift[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    const int tilesP = a.N * a.tilesH * a.tilesW;
+    const int nwg = a.tilesM * tilesP;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap, m-tile fastest: the workgroups sharing one input patch sit on one L2
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int m0 = (bid % a.tilesM) * BM;
+    int pt = bid / a.tilesM;
+    const int n = pt / (a.tilesH * a.tilesW);
+    pt -= n * a.tilesH * a.tilesW;
+    const int oh0 = (pt / a.tilesW) * PT_R, ow0 = (pt % a.tilesW) * PT_C;
+    const size_t HW = (size_t)a.H * a.W;
+    const float* inn = a.in + (size_t)n * a.Cin * HW;
+
+    if (t < BM) {
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
+
+    // ---- staging roles ----
+    // weights: thread owns 4 consecutive m (one float4 per k row), parity hA, k-pairs [12*cq, 12*cq+12)
+    const int mg = t % A_MG, roleA = t / A_MG;
+    const bool a_on = t < A_THREADS;
+    const int hA = roleA & 1, cq = roleA >> 1;
+    const float* wcol = a.wT + m0 + mg * 4;
+    // input patch: up to 6 of the CH*PR*PC = 1440 patch elements; per-thread constant offsets / validity
+    int boff[6];      // offset inside one channel group: cl*HW + gy*W + gx, or -1 (zero)
+    int blds[6];      // LDS float index
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int idx = t + 256 * u;
+        const int cl = idx / (PR * PC), rem = idx - cl * (PR * PC);
+        const int pr = rem / PC, px = rem - pr * PC;
+        const int gy = oh0 - 1 + pr, gx = ow0 - 1 + px;
+        const bool ok = idx < CH * PR * PC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        boff[u] = ok ? (int)(cl * HW) + gy * a.W + gx : -1;
+        blds[u] = idx < CH * PR * PC ? (cl * PR + pr) * BS + px : -1;
+    }
+
+    f32x4 ra[12];
+    float rb[6];
+    auto load_global = [&](int s) {
+        if (a_on) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                ra[j] = *reinterpret_cast<const f32x4*>(wcol + (size_t)(s * KS + hA + 2 * (12 * cq + j)) * a.Mpad);
+        }
+        const float* base = inn + (size_t)s * CH * HW;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const float v = base[boff[u] >= 0 ? boff[u] : 0];
+            rb[u] = boff[u] >= 0 ? v : 0.0f;
+        }
+    };
+    auto store_lds = [&]() {
+        if (a_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    f32x4 v = {ra[4 * c3][e], ra[4 * c3 + 1][e], ra[4 * c3 + 2][e], ra[4 * c3 + 3][e]};
+                    *reinterpret_cast<f32x4*>(&As[hA][mg * 4 + e][(3 * cq + c3) * 4]) = v;
+                }
+        }
+        float* bflat = &Bs[0][0][0];
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            if (blds[u] >= 0) bflat[blds[u]] = rb[u];
+    };
+
+    // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
+    const int pixb = (wn * 4 + (lcol >> 4)) * BS + (lcol & 15);   // sub-tile tn adds 2 rows = 2*BS
+    int baddr[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int k = 2 * kk + lrow;
+        const int cl = k / 9, t9 = k - cl * 9;
+        const int kh = t9 / 3, kw = t9 - kh * 3;
+        baddr[kk] = pixb + cl * (PR * BS) + kh * BS + kw;
+    }
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nsteps = a.Cin / CH;
+    load_global(0);
+    store_lds();
+    __syncthreads();
+    const float* bflat = &Bs[0][0][0];
+    for (int s = 0; s < nsteps; ++s) {
+        load_global(s + 1 < nsteps ? s + 1 : s);   // in flight during the 144 MFMAs below
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            f32x4 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&As[lrow][(wm * TM + i) * 32 + lcol][q * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float b0 = bflat[baddr[q * 4 + e]];
+                const float b1 = bflat[baddr[q * 4 + e] + 2 * BS];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], b1, acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // everyone is done reading the tile
+        store_lds();       // tile s+1 (the last step rewrites its own tile: harmless)
+        __syncthreads();
+    }
+
+    // ---- epilogue (same arithmetic as conv.hip): y = fma(acc, scale, shift) (+ residual) -> activation ----
+    const bool has_res = a.res != nullptr;
+    const float* __restrict__ resp = a.res;
+    float* __restrict__ outp = a.out;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int oh = oh0 + wn * 4 + j * 2 + (lcol >> 4), ow = ow0 + (lcol & 15);
+        const bool pv = oh < a.H && ow < a.W;
+        const size_t obase = (size_t)n * a.Cout * HW + (size_t)(pv ? oh : 0) * a.W + (pv ? ow : 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const int mc = (m0 + ml < a.Cout) ? (m0 + ml) : (a.Cout - 1);
+                rv[r] = has_res ? resp[obase + (size_t)mc * HW] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const int m = m0 + ml;
+                float v = fmaf(acc[i][j][r], s_scale[ml], s_shift[ml]);
+                if (has_res) v += rv[r];
+                if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
+                else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                if (pv && m < a.Cout) outp[obase + (size_t)m * HW] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 3x3, stride 1, pad 1,
+// Cin % 8 == 0.  tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64.
+int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
+                              const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
+                              int act, int tm, hipStream_t st) {
+    C3Args a;
+    a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
+    const int BM = 64 * tm;
+    a.tilesM = (Cout + BM - 1) / BM;
+    a.tilesH = (H + PT_R - 1) / PT_R;
+    a.tilesW = (W + PT_C - 1) / PT_C;
+    const long long nwg = (long long)a.tilesM * N * a.tilesH * a.tilesW;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    if (tm == 2) hipLaunchKernelGGL((conv3x3_direct_kernel<2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_direct_kernel<1>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

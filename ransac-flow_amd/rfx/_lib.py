@@ -16,7 +16,7 @@ SIGNATURES = {
     "rfx_version": (c_char_p, []),
     "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
     "rfx_conv2d_tile_variant": (c_int, [c_int] * 4),
-    "rfx_conv2d_kernel_id": (c_int, [c_int] * 8),
+    "rfx_conv2d_kernel_id": (c_int, [c_int] * 9),
     "rfx_maxpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rfx_blurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_maxblurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),

@@ -90,7 +90,7 @@ class ConvPlan:
             flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
             nbytes = 4.0 * (N * C * H * W + N * self.Cout * Ho * Wo * (2 if res is not None else 1)
                             + self.Cout * self.Cin * self.KH * self.KW)
-            tm.append((lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.pad, Ho, Wo), flops, e0, e1,
+            tm.append((lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo), flops, e0, e1,
                        (N, self.Cin, H, W, self.Cout, self.KH, self.stride), nbytes))
         return out
 
