@@ -42,6 +42,9 @@ CONV_CASES = [
     (1, 3, 40, 56, 64, 3, 1, 1, True, False, 1),      # FeatureExtractor conv1 (K=27)
     (4, 256, 30, 40, 256, 3, 1, 1, True, True, 1),    # layer3-like 3x3 (<2,2> / <1,2> tiles)
     (16, 256, 30, 40, 1024, 1, 1, 0, True, True, 1),  # big enough for the 128x128 tile
+    (2, 64, 19, 21, 64, 3, 1, 1, True, True, 1),      # direct 3x3 kernel <1>, ragged 8x16 patches + residual
+    (8, 128, 60, 80, 256, 3, 1, 1, True, False, 1),   # direct 3x3 kernel <2>
+    (1, 8, 5, 3, 130, 3, 1, 1, False, False, 0),      # direct 3x3: one K step, image smaller than a patch
 ]
 
 
