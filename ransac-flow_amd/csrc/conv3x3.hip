@@ -71,35 +71,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     const int mg = t % A_MG, roleA = t / A_MG;
     const bool a_on = t < A_THREADS;
     const int hA = roleA & 1, cq = roleA >> 1;
-    const float* wcol = a.wT + m0 + mg * 4;
-    // input patch: up to 6 of the CH*PR*PC = 1440 patch elements; per-thread constant offsets / validity
-    int boff[6];      // offset inside one channel group: cl*HW + gy*W + gx, or -1 (zero)
-    int blds[6];      // LDS float index
+    // byte offset of this thread's first weight float4 inside a K step (uniform step base + 32-bit lane offset)
+    const unsigned woff0 = (unsigned)(((a_on ? hA + 24 * cq : 0) * a.Mpad + m0 + mg * 4) * 4);
+    const unsigned wrow2 = (unsigned)(2 * a.Mpad * 4);
+    // input patch: 6 of the CH*PR*PC = 1440 patch elements per thread (the 96 surplus slots land in the unused
+    // columns of the last patch row, so that every load is consumed unconditionally: no divergent store).
+    unsigned boffB[6];   // byte offset inside one channel group (cl*HW + gy*W + gx)*4; 0 with bok=false -> zero
+    bool bok[6];
+    int blds[6];         // LDS float index
 #pragma unroll
     for (int u = 0; u < 6; ++u) {
         const int idx = t + 256 * u;
+        const bool real = idx < CH * PR * PC;
         const int cl = idx / (PR * PC), rem = idx - cl * (PR * PC);
         const int pr = rem / PC, px = rem - pr * PC;
         const int gy = oh0 - 1 + pr, gx = ow0 - 1 + px;
-        const bool ok = idx < CH * PR * PC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        boff[u] = ok ? (int)(cl * HW) + gy * a.W + gx : -1;
-        blds[u] = idx < CH * PR * PC ? (cl * PR + pr) * BS + px : -1;
+        bok[u] = real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        boffB[u] = bok[u] ? (unsigned)(((int)(cl * HW) + gy * a.W + gx) * 4) : 0u;
+        blds[u] = real ? (cl * PR + pr) * BS + px : ((CH - 1) * PR + PR - 1) * BS + PC + (idx - CH * PR * PC) % (BS - PC);
     }
 
     f32x4 ra[12];
     float rb[6];
     auto load_global = [&](int s) {
+        const char* wstep = reinterpret_cast<const char*>(a.wT + (size_t)s * KS * a.Mpad);
         if (a_on) {
 #pragma unroll
-            for (int j = 0; j < 12; ++j)
-                ra[j] = *reinterpret_cast<const f32x4*>(wcol + (size_t)(s * KS + hA + 2 * (12 * cq + j)) * a.Mpad);
+            for (int j = 0; j < 12; ++j) ra[j] = *reinterpret_cast<const f32x4*>(wstep + (woff0 + j * wrow2));
         }
-        const float* base = inn + (size_t)s * CH * HW;
+        const char* base = reinterpret_cast<const char*>(inn + (size_t)s * CH * HW);
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const float v = base[boff[u] >= 0 ? boff[u] : 0];
-            rb[u] = boff[u] >= 0 ? v : 0.0f;
-        }
+        for (int u = 0; u < 6; ++u) rb[u] = *reinterpret_cast<const float*>(base + boffB[u]);   // masked at store time
     };
     auto store_lds = [&]() {
         if (a_on) {
@@ -113,8 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         }
         float* bflat = &Bs[0][0][0];
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            if (blds[u] >= 0) bflat[blds[u]] = rb[u];
+        for (int u = 0; u < 6; ++u) bflat[blds[u]] = bok[u] ? rb[u] : 0.0f;
     };
 
     // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
@@ -143,22 +144,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     const float* bflat = &Bs[0][0][0];
     for (int s = 0; s < nsteps; ++s) {
         load_global(s + 1 < nsteps ? s + 1 : s);   // in flight during the 144 MFMAs below
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            f32x4 af[TM];
+        // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
+        f32x4 af[2][TM];
+        float bv[2][8];
+        auto read_chunk = [&](int q, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&As[lrow][(wm * TM + i) * 32 + lcol][q * 4]);
+                af[slot][i] = *reinterpret_cast<const f32x4*>(&As[lrow][(wm * TM + i) * 32 + lcol][q * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float b0 = bflat[baddr[q * 4 + e]];
-                const float b1 = bflat[baddr[q * 4 + e] + 2 * BS];
+                bv[slot][2 * e] = bflat[baddr[q * 4 + e]];
+                bv[slot][2 * e + 1] = bflat[baddr[q * 4 + e] + 2 * BS];
+            }
+        };
+        read_chunk(0, 0);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < 9) read_chunk(q + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], b1, acc[i][1], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][2 * e], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][2 * e + 1], acc[i][1], 0, 0, 0);
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // everyone is done reading the tile
         store_lds();       // tile s+1 (the last step rewrites its own tile: harmless)
