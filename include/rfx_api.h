@@ -149,6 +149,24 @@ int rfx_grid_sample_f32(const float* in, const float* grid, float* out, int N, i
 int rfx_compose_flow_f32(const float* flowDown, const float* coarseGrid, float* flow12, float* inb,
                          float* flowUp, int N, int hd, int wd, int H, int W, int clamp, void* stream);
 
+/* Multi-homography merge of the offline flow assembly (evaluation/evalHpatch/getResults.py:48-61,
+ * evaluation/evalCorr/getResults.py:121-134, evaluation/evalKITTI/getResults.py:126-138).
+ * flow (n,HW,2) composed flows; match12 = up-sampled matchability of homography i at match12 + i*match12_stride;
+ * cyc (n,HW) = grid_sample(up(match21), flowUp) or NULL; inb (n,HW) in-bounds mask or NULL.
+ * score_i = match12_i * cyc_i * inb_i (left to right).  Pixel owner: homography 0 if score_0 >= th, otherwise the
+ * first i >= 1 with score_i >= th (only when multiH != 0), otherwise 0.  Outputs: flowGlobal (HW,2) = owner's flow
+ * clamped to [-1,1]; matchGlobal (HW) = owner's score (may be NULL); binary (HW) u8 = "some score reached th"
+ * (may be NULL). */
+int rfx_merge_multi_h_f32(const float* flow, const float* match12, long long match12_stride, const float* cyc,
+                          const float* inb, int n, long long HW, float th, int multiH, float* flowGlobal,
+                          float* matchGlobal, uint8_t* binary, void* stream);
+
+/* score (n,HW) = match12_i * cyc_i * inb_i (same operands and order as above; cyc / inb may be NULL): the "match"
+ * tensor of evaluation/evalKITTI/getResults.py:120, materialised when a host-side filter (remove_small_cc, :122)
+ * runs before the merge -- rfx_merge_multi_h_f32 is then called with cyc = inb = NULL on the filtered scores. */
+int rfx_match_score_f32(const float* match12, long long match12_stride, const float* cyc, const float* inb, int n,
+                        long long HW, float* score, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * All-pairs correlation + mutual nearest neighbours (utils/outil.py:32-45, mutualMatching).
  * featA: (C, nA) and featB: (C, nB), column = one cell ("K-major": element (k,i) at k*ld+i).

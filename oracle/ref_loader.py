@@ -165,6 +165,29 @@ def load():
     return _loaded
 
 
+def script_functions(rel_path, names):
+    """Compile ONLY the named top-level functions of a reference *script* (e.g. evaluation/evalHpatch/getResults.py,
+    whose module level parses argv and walks a dataset directory) and return them, bound to a namespace holding the
+    modules those functions use (np, torch, F, os, and the kornia stub as ``tgm``).  The reference source is read
+    and executed from where it lies; nothing is copied."""
+    import ast
+    _install_stubs()
+    path = os.path.join(REF_ROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in keep}
+    if missing:
+        raise KeyError("not in %s: %s" % (rel_path, sorted(missing)))
+    from scipy import ndimage
+    # skimage is not installed: measure.label(mask, background=0) (8-connectivity in 2-D) -> scipy's labelling
+    measure = types.SimpleNamespace(
+        label=lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0])
+    ns = {"np": np, "torch": torch, "F": torch.nn.functional, "os": os, "tgm": sys.modules["kornia.geometry"],
+          "nd": ndimage, "measure": measure}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return {n: ns[n] for n in names}
+
+
 def quiet(fn, *a, **k):
     """Run fn with stdout silenced (the reference prints scaleList / 'Not initializing')."""
     with contextlib.redirect_stdout(io.StringIO()):

@@ -150,6 +150,56 @@ __global__ __launch_bounds__(256) void compose_flow_kernel(const float* __restri
     }
 }
 
+// Multi-homography merge of the offline flow assembly (evaluation/evalHpatch/getResults.py:48-61,
+// evaluation/evalCorr/getResults.py:121-134, evaluation/evalKITTI/getResults.py:126-138): one thread per pixel walks the
+// n homographies in order.  score_i = m12_i (* cyc_i) (* inb_i), multiplied left to right like the reference's
+// tensor expression; pixel owner = 0 if score_0 >= th, else the first i >= 1 with score_i >= th (only if multiH), else 0.
+__global__ __launch_bounds__(256) void merge_multi_h_kernel(const float* __restrict__ flow, const float* __restrict__ m12,
+                                                           long long m12_stride, const float* __restrict__ cyc,
+                                                           const float* __restrict__ inb, int n, long long HW, float th,
+                                                           int multiH, float* __restrict__ flowG,
+                                                           float* __restrict__ matchG, uint8_t* __restrict__ binary) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    int best = 0;
+    float mbest = 0.0f;
+    bool found = false;
+    const int last = multiH ? n : 1;
+    for (int i = 0; i < last; ++i) {
+        float v = m12[(long long)i * m12_stride + p];
+        if (cyc) v = v * cyc[(long long)i * HW + p];
+        if (inb) v = v * inb[(long long)i * HW + p];
+        if (i == 0) mbest = v;
+        if (v >= th) {
+            best = i;
+            mbest = v;
+            found = true;
+            break;
+        }
+    }
+    const float2 f = reinterpret_cast<const float2*>(flow)[(long long)best * HW + p];
+    float2 o;
+    o.x = fminf(fmaxf(f.x, -1.0f), 1.0f);
+    o.y = fminf(fmaxf(f.y, -1.0f), 1.0f);
+    reinterpret_cast<float2*>(flowG)[p] = o;
+    if (matchG) matchG[p] = mbest;
+    if (binary) binary[p] = found ? 1 : 0;
+}
+
+// score = match12 (* cyc) (* inb), left to right: the "match" tensor of evaluation/evalKITTI/getResults.py:120, needed
+// materialised only when the host-side small-component filter (:122) sits between it and the merge.
+__global__ __launch_bounds__(256) void match_score_kernel(const float* __restrict__ m12, long long m12_stride,
+                                                         const float* __restrict__ cyc, const float* __restrict__ inb,
+                                                         long long HW, long long total, float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const long long i = q / HW, p = q - i * HW;
+    float v = m12[i * m12_stride + p];
+    if (cyc) v = v * cyc[q];
+    if (inb) v = v * inb[q];
+    out[q] = v;
+}
+
 }  // namespace
 
 extern "C" int rfx_warp_grid_f32(const float* Hm, float* grid, int B, int h, int w, void* stream) {
@@ -177,6 +227,26 @@ extern "C" int rfx_compose_flow_f32(const float* flowDown, const float* coarseGr
     const float sh = (float)hd / (float)H, sw = (float)wd / (float)W;
     hipLaunchKernelGGL(compose_flow_kernel, dim3(grid_for(NP, 256)), dim3(256), 0, rfx_stream(stream), flowDown,
                        coarseGrid, flow12, inb, flowUp, NP, hd, wd, H, W, sh, sw, clamp);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_merge_multi_h_f32(const float* flow, const float* match12, long long match12_stride,
+                                     const float* cyc, const float* inb, int n, long long HW, float th, int multiH,
+                                     float* flowGlobal, float* matchGlobal, uint8_t* binary, void* stream) {
+    if (!flow || !match12 || !flowGlobal || n <= 0 || HW <= 0 || match12_stride < HW) return RFX_E_ARG;
+    hipLaunchKernelGGL(merge_multi_h_kernel, dim3(grid_for(HW, 256)), dim3(256), 0, rfx_stream(stream), flow, match12,
+                       match12_stride, cyc, inb, n, HW, th, multiH, flowGlobal, matchGlobal, binary);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_match_score_f32(const float* match12, long long match12_stride, const float* cyc, const float* inb,
+                                   int n, long long HW, float* score, void* stream) {
+    if (!match12 || !score || n <= 0 || HW <= 0 || match12_stride < HW) return RFX_E_ARG;
+    const long long total = (long long)n * HW;
+    hipLaunchKernelGGL(match_score_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), match12,
+                       match12_stride, cyc, inb, HW, total, score);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

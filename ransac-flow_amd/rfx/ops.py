@@ -257,6 +257,44 @@ def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up
     return flow12, inb, fup
 
 
+def _match_plane(match12, n, H, W):
+    if not isinstance(match12, torch.Tensor) or not match12.is_cuda or match12.dtype != torch.float32:
+        raise RuntimeError("match12 must be a float32 tensor on a HIP device (no CPU fallback)")
+    if tuple(match12.shape) != (n, H, W) or match12.stride(2) != 1 or match12.stride(1) != W:
+        raise ValueError("match12 must be (n,H,W) with contiguous planes")
+    return match12.stride(0) if n > 1 else H * W
+
+
+def match_score(match12, cyc=None, inb=None):
+    """match12 (n,H,W) (channel slice allowed) * cyc * inb -> (n,H,W)."""
+    n, H, W = match12.shape
+    stride = _match_plane(match12, n, H, W)
+    c = _dev(cyc, "cyc") if cyc is not None else None
+    b = _dev(inb, "inb") if inb is not None else None
+    out = torch.empty((n, H, W), dtype=torch.float32, device=match12.device)
+    _lib.check(_lib.load().rfx_match_score_f32(match12.data_ptr(), stride, _p(c), _p(b), n, H * W, _p(out), _stream()),
+               "rfx_match_score_f32")
+    return out
+
+
+def merge_multi_h(flow, match12, th, multiH, cyc=None, inb=None):
+    """flow (n,H,W,2); match12 (n,H,W) -- may be a channel slice of an (n,C,H,W) tensor (batch stride honoured);
+    cyc / inb (n,H,W) contiguous or None  ->  flowGlobal (1,H,W,2), matchGlobal (1,H,W), binary (1,H,W) bool."""
+    flow = _dev(flow, "flow")
+    n, H, W, _ = flow.shape
+    HW = H * W
+    stride = _match_plane(match12, n, H, W)
+    c = _dev(cyc, "cyc") if cyc is not None else None
+    b = _dev(inb, "inb") if inb is not None else None
+    fg = torch.empty((1, H, W, 2), dtype=torch.float32, device=flow.device)
+    mg = torch.empty((1, H, W), dtype=torch.float32, device=flow.device)
+    binary = torch.empty((1, H, W), dtype=torch.uint8, device=flow.device)
+    _lib.check(_lib.load().rfx_merge_multi_h_f32(_p(flow), match12.data_ptr(), stride, _p(c),
+                                                _p(b), n, HW, float(th), 1 if multiH else 0, _p(fg), _p(mg),
+                                                _p(binary), _stream()), "rfx_merge_multi_h_f32")
+    return fg, mg, binary.bool()
+
+
 def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
     """featA (C,nA), featB (C,nB) -> (index1, index2) int64 device tensors (ascending index1).
     Synchronises once to read the match count (the reference's nonzero() does the same)."""

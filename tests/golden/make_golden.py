@@ -189,9 +189,63 @@ def gen_config1():
     print("config1.npz: matches", len(i1), "inliers", int(inlierMask.sum()), "H", bestPrm.ravel()[:3])
 
 
+def gen_assemble():
+    """Offline flow assembly: the reference's own getFlow* functions, compiled out of the three
+    getResults.py scripts, run on seeded .npy files written in the on-disk format they expect."""
+    import tempfile
+    kg = ref_loader.load()["kornia_geometry"]
+    fh = ref_loader.script_functions("evaluation/evalHpatch/getResults.py", ["getFlow_all", "getFlow_onlyCoarse"])
+    fc = ref_loader.script_functions("evaluation/evalCorr/getResults.py", ["getFlow", "getFlow_Coarse"])
+    fk = ref_loader.script_functions("evaluation/evalKITTI/getResults.py",
+                                     ["getFlow_all", "remove_small_cc", "interpolate_flow_match"])
+    n, hd, wd = 3, 10, 14
+    flowDown, flowd2, param, md = synth.assembly_arrays(11, n, hd, wd)
+    d = tempfile.mkdtemp()
+    fine, coarse, maskp, kit = [os.path.join(d, x) for x in ("fine", "coarse", "mask", "kitti")]
+    for x in (fine, coarse, maskp, kit):
+        os.makedirs(x)
+    H8, W8 = hd * 8, wd * 8
+    np.save(os.path.join(fine, "flow_7_3H.npy"), flowDown)
+    np.save(os.path.join(coarse, "flow_7_3H.npy"), param)
+    np.save(os.path.join(fine, "mask_7_3H.npy"), md)
+    np.save(os.path.join(maskp, "maskBG_7_3H.npy"), np.ones((H8, W8), bool))
+    np.save(os.path.join(kit, "Homograpy_7_3.npy"), param)
+    np.save(os.path.join(kit, "Finetune_D2_7_3.npy"), flowd2)
+    np.save(os.path.join(kit, "Finetune_7_3.npy"), flowDown)
+    np.save(os.path.join(kit, "Finetune_Mask_7_3.npy"), md)
+    np.save(os.path.join(kit, "BG_7_3H.npy"), np.ones((H8, W8), bool))
+    out = dict(seed=11, n=n, hd=hd, wd=wd)
+    # Hpatch: arbitrary output size (the script uses minSize x minSize), no cycle check
+    oh, ow = 72, 100
+    grid = torch.cat((torch.linspace(-1, 1, ow).view(1, 1, -1, 1).expand(1, oh, ow, 1),
+                      torch.linspace(-1, 1, oh).view(1, -1, 1, 1).expand(1, oh, ow, 1)), dim=3)
+    for tag, th, multiH in (("a", 0.45, True), ("b", 0.45, False), ("c", 0.7, True)):
+        r = fh["getFlow_all"](7, fine, coarse, os.listdir(fine), multiH, kg.HomographyWarper(oh, ow), grid, th, ow, oh)
+        out["hpatch_%s" % tag] = r.numpy()
+        out["hpatch_%s_cfg" % tag] = np.asarray([th, float(multiH), oh, ow])
+    out["hpatch_missing"] = np.asarray(len(fh["getFlow_all"](8, fine, coarse, os.listdir(fine), True, None, grid, 0.5, ow, oh)))
+    out["hpatch_coarse"] = fh["getFlow_onlyCoarse"](7, fine, coarse, os.listdir(fine), True,
+                                                   kg.HomographyWarper(oh, ow), grid, 0.5, ow, oh).numpy()
+    for tag, th, multiH in (("a", 0.2, True), ("b", 0.2, False), ("c", 0.35, True)):
+        rf, rm = fc["getFlow"](7, fine, os.listdir(fine), coarse, maskp, multiH, th)
+        out["corr_%s_flow" % tag] = rf.numpy()
+        out["corr_%s_match" % tag] = rm.numpy()
+        out["corr_%s_cfg" % tag] = np.asarray([th, float(multiH)])
+    grid8 = torch.cat((torch.linspace(-1, 1, W8).view(1, 1, -1, 1).expand(1, H8, W8, 1),
+                       torch.linspace(-1, 1, H8).view(1, -1, 1, 1).expand(1, H8, W8, 1)), dim=3)
+    for tag, th, cc, interp, multiH in (("a", 0.2, 0.0, False, True), ("b", 0.25, 0.01, False, True),
+                                        ("c", 0.25, 0.02, True, True), ("d", 0.2, 0.01, True, False)):
+        r = fk["getFlow_all"](7, kit, 3, "Finetune", kg.HomographyWarper(H8, W8), multiH, grid8, th, cc, interp)
+        out["kitti_%s" % tag] = r.numpy()
+        out["kitti_%s_cfg" % tag] = np.asarray([th, cc, float(interp), float(multiH)])
+    np.savez_compressed(os.path.join(HERE, "assemble.npz"), **out)
+    print("assemble.npz:", sorted(k for k in out if not k.endswith("_cfg"))[:6], "...")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_ransac()
     gen_mutual()
     gen_nets()
     gen_config1()
+    gen_assemble()

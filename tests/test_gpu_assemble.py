@@ -1,0 +1,136 @@
+"""Offline flow assembly on the GPU: rfx.assemble / the getResults drop-in against the CPU oracle,
+against the reference's own outputs (tests/golden/assemble.npz) and, at full evaluation sizes, through
+size-independent properties.  The device composes flows to ~1e-6 of the CPU result, so a pixel whose score lies
+within float rounding of the threshold may change owner: comparisons allow a vanishing fraction of such pixels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import restate
+from rfx import assemble, ops, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-4
+
+
+def _close(dev_t, ref, what, max_bad=0.002):
+    d = (dev_t.cpu().float() - torch.as_tensor(ref).float()).abs()
+    bad = float((d > TOL).float().mean())
+    assert bad <= max_bad, "%s: %.4f%% of the values differ by more than %g (max %g)" % (what, 100 * bad, TOL, float(d.max()))
+
+
+def test_assemble_matches_reference_golden(dev):
+    g = np.load(os.path.join(GOLD, "assemble.npz"))
+    n, hd, wd = int(g["n"]), int(g["hd"]), int(g["wd"])
+    fd, fd2, pm, md = synth.assembly_arrays(int(g["seed"]), n, hd, wd)
+    for tag in "abc":
+        th, multiH, oh, ow = g["hpatch_%s_cfg" % tag]
+        fg, _, _ = assemble.assemble(fd, pm, md, (int(oh), int(ow)), float(th), bool(multiH), False, dev)
+        _close(fg, g["hpatch_%s" % tag], "hpatch " + tag)
+        th, multiH = g["corr_%s_cfg" % tag]
+        fg, mg, _ = assemble.assemble(fd, pm, md, (hd * 8, wd * 8), float(th), bool(multiH), True, dev)
+        _close(fg, g["corr_%s_flow" % tag], "corr flow " + tag)
+        _close(mg.unsqueeze(3), g["corr_%s_match" % tag], "corr match " + tag)
+    for tag in "abcd":
+        th, cc, interp, multiH = g["kitti_%s_cfg" % tag]
+        fg, _, _ = assemble.assemble_kitti(fd2, fd, pm, md, (hd * 8, wd * 8), float(th), bool(multiH), float(cc),
+                                           bool(interp), dev)
+        _close(fg, g["kitti_%s" % tag], "kitti " + tag, max_bad=0.01)
+
+
+@pytest.mark.parametrize("seed,n,cycle", [(21, 1, False), (22, 5, True), (23, 11, False)])
+def test_assemble_matches_oracle(dev, seed, n, cycle):
+    hd, wd = 9, 13
+    fd, _, pm, md = synth.assembly_arrays(seed, n, hd, wd)
+    t = torch.from_numpy
+    out_hw = (hd * 8, wd * 8) if cycle else (61, 83)
+    th = 0.2 if cycle else 0.45
+    fg, mg, b = assemble.assemble(fd, pm, md, out_hw, th, True, cycle, dev)
+    rf, rm, rb = restate.assemble_flow(t(fd), t(pm), t(md), out_hw, th, True, cycle)
+    _close(fg, rf, "flow")
+    _close(mg, rm, "match")
+    assert float((b.cpu() != rb).float().mean()) <= 0.002
+
+
+def test_merge_kernel_is_exact_on_given_scores(dev):
+    """With the scores handed over (no device-side composition in front) the ownership rule is integer work."""
+    g = torch.Generator().manual_seed(5)
+    n, H, W = 7, 37, 53
+    flow = (torch.rand(n, H, W, 2, generator=g) * 2.4 - 1.2)
+    m = torch.rand(n, 2, H, W, generator=g)
+    cyc = torch.rand(n, H, W, generator=g)
+    inb = (torch.rand(n, H, W, generator=g) > 0.2).float()
+    for multiH in (True, False):
+        fg, mg, b = ops.merge_multi_h(flow.to(dev), m.to(dev)[:, 0], 0.3, multiH, cyc=cyc.to(dev), inb=inb.to(dev))
+        rf, rm, rb = restate.merge_multi_h(flow.clamp(-1, 1), m[:, 0] * cyc * inb, 0.3, multiH)
+        assert torch.equal(fg.cpu(), rf) and torch.equal(mg.cpu(), rm) and torch.equal(b.cpu(), rb)
+    sc = ops.match_score(m.to(dev)[:, 0], cyc=cyc.to(dev), inb=inb.to(dev))
+    assert torch.equal(sc.cpu(), m[:, 0] * cyc * inb)
+
+
+def test_assemble_full_size_properties(dev):
+    """480x640 output, 11 homographies (the padded maximum of the result record): properties that need no oracle."""
+    n, hd, wd = 11, 60, 80
+    fd, fd2, pm, md = synth.assembly_arrays(31, n, hd, wd)
+    H, W = 480, 640
+    single, _, _ = assemble.assemble(fd, pm, md, (H, W), 0.5, False, True, dev)
+    allpass, mg, b = assemble.assemble(fd, pm, md, (H, W), -1.0, True, True, dev)     # every score >= th: owner 0
+    assert torch.equal(single, allpass) and bool(b.all())
+    nopass, _, b2 = assemble.assemble(fd, pm, md, (H, W), 2.0, True, True, dev)       # nothing reaches th: owner 0
+    assert torch.equal(single, nopass) and not bool(b2.any())
+    multi, mg, b3 = assemble.assemble(fd, pm, md, (H, W), 0.5, True, True, dev)
+    assert float(multi.abs().max()) <= 1.0
+    # wherever homography 0 already reaches th the merged flow is homography 0's
+    _, m0, b0 = assemble.assemble(fd[:1], pm[:1], md[:1], (H, W), 0.5, True, True, dev)
+    assert torch.equal(multi[b0], single[b0]) and bool((b3 | ~b0).all())
+    assert torch.equal(mg[b0], m0[b0]) and float(mg[b3].min()) >= 0.5
+    # reversing the order of homographies 1..n-1 changes owners only where two of them qualify
+    perm = [0] + list(range(n - 1, 0, -1))
+    rev, _, b4 = assemble.assemble(fd[perm], pm[perm], md[perm], (H, W), 0.5, True, True, dev)
+    assert torch.equal(b4, b3)
+    # KITTI two-level composition with a zero half-resolution flow equals the one-level composition
+    k, _, _ = assemble.assemble_kitti(np.zeros_like(fd2), fd, pm, md, (H, W), 0.5, True, 0.0, False, dev)
+    d = (k - multi).abs()
+    assert float((d > 1e-4).float().mean()) < 0.002
+
+
+def test_getresults_dropin_reads_the_on_disk_format(dev, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd", "dropin"))
+    import getResults
+    n, hd, wd = 3, 8, 10
+    fd, fd2, pm, md = synth.assembly_arrays(41, n, hd, wd)
+    fine, coarse, maskp, kit = [tmp_path / x for x in ("fine", "coarse", "mask", "kitti")]
+    for x in (fine, coarse, maskp, kit):
+        x.mkdir()
+    np.save(fine / "flow_3_3H.npy", fd.astype(np.float64))          # the scripts save whatever dtype they had
+    np.save(fine / "mask_3_3H.npy", md)
+    np.save(coarse / "flow_3_3H.npy", pm)
+    np.save(maskp / "maskBG_3_3H.npy", np.ones((hd * 8, wd * 8), bool))
+    np.save(kit / "Homograpy_3_3.npy", pm)
+    np.save(kit / "Finetune_D2_3_3.npy", fd2)
+    np.save(kit / "Finetune_3_3.npy", fd)
+    np.save(kit / "Finetune_Mask_3_3.npy", md)
+    t = torch.from_numpy
+    names = os.listdir(fine)
+    f = getResults.hpatch.getFlow_all(3, str(fine), str(coarse), names, True, None, None, 0.45, 72, 48)
+    assert f.device.type == "cpu" and tuple(f.shape) == (1, 48, 72, 2)
+    _close(f, restate.assemble_flow(t(fd), t(pm), t(md), (48, 72), 0.45, True, False)[0], "hpatch drop-in")
+    assert getResults.hpatch.getFlow_all(4, str(fine), str(coarse), names, True, None, None, 0.45, 72, 48) == []
+    c = getResults.hpatch.getFlow_onlyCoarse(3, str(fine), str(coarse), names, True, None, None, 0.45, 72, 48)
+    _close(c, restate.warp_grid(t(pm[:1]), 48, 72), "coarse only")
+    f, m = getResults.corr.getFlow(3, str(fine), names, str(coarse), str(maskp), True, 0.2)
+    rf, rm, _ = restate.assemble_flow(t(fd), t(pm), t(md), (hd * 8, wd * 8), 0.2, True, True)
+    assert tuple(m.shape) == (1, hd * 8, wd * 8, 1)
+    _close(f, rf, "corr drop-in flow")
+    _close(m[..., 0], rm, "corr drop-in match")
+    c, ones = getResults.corr.getFlow_Coarse(3, names, str(fine), str(coarse))
+    assert tuple(c.shape) == (1, hd * 8, wd * 8, 2) and float(ones.min()) == 1.0
+    grid_org = restate.identity_grid(hd * 8, wd * 8)
+    f = getResults.kitti.getFlow_all(3, str(kit), 3, "Finetune", None, True, grid_org, 0.25, 0.01, True)
+    rf, _, _ = restate.assemble_flow_kitti(t(fd2), t(fd), t(pm), t(md), (hd * 8, wd * 8), 0.25, True, 0.01, True)
+    _close(f, rf, "kitti drop-in", max_bad=0.01)

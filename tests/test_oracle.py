@@ -231,3 +231,85 @@ def test_ops_refuse_cpu_tensors():
         ops.corr_neigh(torch.zeros(1, 8, 4, 4), torch.zeros(1, 8, 4, 4))
     with pytest.raises(RuntimeError):
         ops.ransac_h4(torch.zeros(8, 3), torch.zeros(8, 3), torch.zeros(4, 4, dtype=torch.int64), 0.05)
+
+
+# ---------------------------------------------------------------- offline flow assembly
+
+def _assembly_case():
+    g = gold("assemble.npz")
+    n, hd, wd = int(g["n"]), int(g["hd"]), int(g["wd"])
+    flowDown, flowd2, param, md = synth.assembly_arrays(int(g["seed"]), n, hd, wd)
+    t = torch.from_numpy
+    return g, (t(flowDown), t(flowd2), t(param), t(md)), (hd, wd)
+
+
+def test_assemble_restatement_matches_reference_golden():
+    """The goldens are outputs of the reference's own getFlow_all / getFlow functions (make_golden.gen_assemble)."""
+    g, (fd, fd2, pm, md), (hd, wd) = _assembly_case()
+    for tag in "abc":
+        th, multiH, oh, ow = g["hpatch_%s_cfg" % tag]
+        fg, _, _ = restate.assemble_flow(fd, pm, md, (int(oh), int(ow)), float(th), bool(multiH), False)
+        assert np.array_equal(fg.numpy(), g["hpatch_%s" % tag]), tag
+        th, multiH = g["corr_%s_cfg" % tag]
+        fg, mg, _ = restate.assemble_flow(fd, pm, md, (hd * 8, wd * 8), float(th), bool(multiH), True)
+        assert np.array_equal(fg.numpy(), g["corr_%s_flow" % tag]), tag
+        assert np.array_equal(mg.numpy()[..., None], g["corr_%s_match" % tag]), tag
+    for tag in "abcd":
+        th, cc, interp, multiH = g["kitti_%s_cfg" % tag]
+        fg, _, _ = restate.assemble_flow_kitti(fd2, fd, pm, md, (hd * 8, wd * 8), float(th), bool(multiH), float(cc),
+                                               bool(interp))
+        assert np.array_equal(fg.numpy(), g["kitti_%s" % tag]), tag
+    assert np.array_equal(restate.warp_grid(pm[:1], 72, 100).numpy(), g["hpatch_coarse"])
+    # the multi-H settings really differ from the single-H ones (the merge is exercised)
+    assert not np.array_equal(g["hpatch_a"], g["hpatch_b"]) and not np.array_equal(g["corr_a_flow"], g["corr_b_flow"])
+
+
+def test_merge_multi_h_ownership_rule():
+    flow = torch.stack([torch.full((2, 3, 2), float(i)) * 0.1 for i in range(3)])
+    match = torch.tensor([[[0.9, 0.1, 0.1], [0.1, 0.1, 0.5]],
+                          [[0.9, 0.9, 0.1], [0.1, 0.6, 0.5]],
+                          [[0.9, 0.9, 0.9], [0.1, 0.9, 0.5]]])
+    fg, mg, b = restate.merge_multi_h(flow, match, 0.5, True)
+    assert torch.equal((fg[0, ..., 0] * 10).round().long(), torch.tensor([[0, 1, 2], [0, 1, 0]]))
+    assert torch.equal(b[0], torch.tensor([[True, True, True], [False, True, True]]))
+    assert torch.equal(mg[0], torch.tensor([[0.9, 0.9, 0.9], [0.1, 0.6, 0.5]]))
+    fg1, _, b1 = restate.merge_multi_h(flow, match, 0.5, False)
+    assert float(fg1.abs().max()) == 0.0 and torch.equal(b1[0], match[0] >= 0.5)
+
+
+def test_assembly_file_lookup_follows_reference():
+    from rfx import assemble
+    names = ["mask_12_3H.npy", "flow_1_2H.npy", "flow_12_3H.npy", "junk"]
+    assert assemble.find_nbH(12, names) == "3" and assemble.find_nbH(1, names) == "2"
+    assert assemble.find_nbH(2, names) is None
+    # a pair without saved arrays gives the reference's [] sentinels before any device work
+    assert assemble.hpatch_getFlow_all(99, "/nonexistent", "/nonexistent", names, True, None, None, 0.5, 8, 8) == []
+    assert assemble.corr_getFlow(99, "/nonexistent", names, "/nonexistent", "/nonexistent", True, 0.5) == ([], [])
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("seed", [3, 4])
+def test_assemble_restatement_matches_live_reference(seed, tmp_path):
+    """Fresh seeds against the reference's getFlow functions executed from /root/reference (authoring container)."""
+    import ref_loader
+    kg = ref_loader.load()["kornia_geometry"]
+    fh = ref_loader.script_functions("evaluation/evalHpatch/getResults.py", ["getFlow_all"])["getFlow_all"]
+    fc = ref_loader.script_functions("evaluation/evalCorr/getResults.py", ["getFlow"])["getFlow"]
+    n, hd, wd = 4, 6, 9
+    flowDown, _, param, md = synth.assembly_arrays(seed, n, hd, wd)
+    fine, coarse, maskp = [tmp_path / x for x in ("fine", "coarse", "mask")]
+    for x in (fine, coarse, maskp):
+        x.mkdir()
+    np.save(fine / "flow_5_4H.npy", flowDown)
+    np.save(fine / "mask_5_4H.npy", md)
+    np.save(coarse / "flow_5_4H.npy", param)
+    np.save(maskp / "maskBG_5_4H.npy", np.ones((hd * 8, wd * 8), bool))
+    t = torch.from_numpy
+    oh, ow = 40, 56
+    ref = fh(5, str(fine), str(coarse), os.listdir(fine), True, kg.HomographyWarper(oh, ow), restate.identity_grid(oh, ow),
+             0.4, ow, oh)
+    fg, _, _ = restate.assemble_flow(t(flowDown), t(param), t(md), (oh, ow), 0.4, True, False)
+    assert torch.equal(ref, fg)
+    rf, rm = fc(5, str(fine), os.listdir(fine), str(coarse), str(maskp), True, 0.15)
+    fg, mg, _ = restate.assemble_flow(t(flowDown), t(param), t(md), (hd * 8, wd * 8), 0.15, True, True)
+    assert torch.equal(rf, fg) and torch.equal(rm[..., 0], mg)
