@@ -240,7 +240,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
         const float hy = 1.f - ly, hx = 1.f - lx;
         const float v00 = src[(size_t)y0 * Win + x0], v01 = src[(size_t)y0 * Win + x1];
         const float v10 = src[(size_t)y1 * Win + x0], v11 = src[(size_t)y1 * Win + x1];
-        out[idx] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        // pinned operation order (ATen's Interpolate<>::eval compiled with FMA contraction: t0*w0, then += t1*w1 as an
+        // fma) so that every compiled copy of this loop body rounds identically
+        const float r0 = fmaf(v01, lx, __fmul_rn(v00, hx));
+        const float r1 = fmaf(v11, lx, __fmul_rn(v10, hx));
+        out[idx] = fmaf(r1, ly, __fmul_rn(r0, hy));
     }
 }
 
