@@ -93,10 +93,15 @@ def test_assemble_full_size_properties(dev):
     perm = [0] + list(range(n - 1, 0, -1))
     rev, _, b4 = assemble.assemble(fd[perm], pm[perm], md[perm], (H, W), 0.5, True, True, dev)
     assert torch.equal(b4, b3)
-    # KITTI two-level composition with a zero half-resolution flow equals the one-level composition
-    k, _, _ = assemble.assemble_kitti(np.zeros_like(fd2), fd, pm, md, (H, W), 0.5, True, 0.0, False, dev)
-    d = (k - multi).abs()
-    assert float((d > 1e-4).float().mean()) < 0.002
+    # KITTI variant: the nearest-neighbour fill only touches unexplained pixels, and every filled pixel carries the
+    # flow of some explained pixel
+    k0, _, kb = assemble.assemble_kitti(fd2, fd, pm, md, (H, W), 0.5, True, 0.0, False, dev)
+    k1, _, kb1 = assemble.assemble_kitti(fd2, fd, pm, md, (H, W), 0.5, True, 0.0, True, dev)
+    assert torch.equal(kb, kb1) and torch.equal(k0[kb], k1[kb]) and float(k1.abs().max()) <= 1.0
+    if bool(kb.any()) and not bool(kb.all()):
+        explained = set(map(tuple, k0[kb].cpu().numpy().round(6).tolist()))
+        filled = k1[~kb].cpu().numpy().round(6).tolist()[:2000]
+        assert all(tuple(v) in explained for v in filled)
 
 
 def test_getresults_dropin_reads_the_on_disk_format(dev, tmp_path):
