@@ -21,6 +21,7 @@
 // Epilogue fused: y = fma(acc, scale[m], shift[m]) (+ residual) -> ReLU / sigmoid; stores coalesced
 // along the pixel dimension (the MFMA C/D column index is the pixel).
 #include "common.h"
+#include "conv_epilogue.h"
 #include <stdlib.h>
 
 struct ConvArgs {
@@ -35,7 +36,18 @@ struct ConvArgs {
     int Kpad, Mpad;
     long long P;  // N*Hout*Wout
     int tilesM, tilesP;
+#ifdef RFX_TRACE
+    long long* trace;  // experiments only (make TRACE=1): 4 wall-clock stamps per workgroup
+#endif
 };
+#ifdef RFX_TRACE
+#define RFX_STAMP(i) do { if (tid == 0 && a.trace) a.trace[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+static long long* g_trace = nullptr;
+extern "C" void rfx_debug_trace(long long* p) { g_trace = p; }
+extern "C" long long* rfx_debug_trace_ptr() { return g_trace; }
+#else
+#define RFX_STAMP(i)
+#endif
 
 // ONE = 1x1 kernel with pad 0 (any stride): k IS the input channel and every tap is in bounds, so the im2col
 // gather needs no ktab decode and no bounds logic (address = pixel base + k * Hin*Win).
@@ -48,7 +60,7 @@ struct ConvArgs {
 // with one 16-byte load (the im2col row of a 1x1 convolution is the NCHW plane itself), mirroring the weight side:
 // 4x fewer gather instructions.
 template <int TM, int TN, bool ONE, bool WS, bool VECB>
-__global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel(ConvArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
     constexpr int B_NI = BN / 8;                                      // gathered values per thread per step
     constexpr int A_MG = BM / 4;                                        // groups of 4 consecutive m per tile
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
     // the tile space, m-tile fastest, so the blocks that share one im2col pixel tile run on one L2.
     const int nwg = a.tilesM * a.tilesP;
     int bid = blockIdx.x;
+    RFX_STAMP(0);
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -272,6 +285,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
         load_global(0);
         store_lds(0);
         __syncthreads();
+        RFX_STAMP(1);
         int cur = 0;
         for (int kt = 0; kt < nk; ++kt) {
             // branch-free body (the last step re-loads its own tile into the unused buffer): one basic block, so the
@@ -284,42 +298,26 @@ __global__ __launch_bounds__(WS ? 512 : 256, 2) void conv2d_mfma_kernel(ConvArgs
         }
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // scale/shift come from LDS and the residual values of one 32x32 sub-tile are fetched as a batch of 16
-    // independent loads BEFORE its stores: out/res/scale may alias as far as the compiler knows, so a
-    // load placed after a store would otherwise serialise the whole epilogue on memory latency.
-    const bool has_res = a.res != nullptr;
-    const float* __restrict__ resp = a.res;
-    float* __restrict__ outp = a.out;
+    RFX_STAMP(2);
+    // epilogue (conv_epilogue.h): this lane's pixel of each 32-pixel sub-tile -> plane offset
+    size_t pix_off[TN];
+    bool pix_ok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         long long pp = n0 + (wn * TN + j) * 32 + lcol;
-        const bool pv = pp < a.P;
-        if (!pv) pp = a.P - 1;
+        pix_ok[j] = pp < a.P;
+        if (!pix_ok[j]) pp = a.P - 1;
         const int n = (int)(pp / HWo);
         const int rem = (int)(pp - (long long)n * HWo);
-        const size_t obase = (size_t)n * a.Cout * HWo + rem;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const int mc = (m0 + ml < a.Cout) ? (m0 + ml) : (a.Cout - 1);
-                rv[r] = has_res ? resp[obase + (size_t)mc * HWo] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const int m = m0 + ml;
-                float v = fmaf(acc[i][j][r], s_scale[ml], s_shift[ml]);
-                if (has_res) v += rv[r];
-                if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
-                else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                if (pv && m < a.Cout) outp[obase + (size_t)m * HWo] = v;
-            }
-        }
+        pix_off[j] = (size_t)n * a.Cout * HWo + rem;
     }
+    const bool full = m0 + BM <= a.Cout;
+    conv_epilogue<TM, TN, WS>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, (size_t)HWo, m0, wm, lrow, pix_off, pix_ok,
+                          full);
+#ifdef RFX_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RFX_STAMP(3);
+#endif
 }
 
 template <int TM, int TN, bool ONE, bool WS, bool VECB = false>
@@ -329,6 +327,9 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     a.tilesP = (int)((a.P + BN - 1) / BN);
     const long long nwg = (long long)a.tilesM * a.tilesP;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+#ifdef RFX_TRACE
+    a.trace = g_trace;
+#endif
     hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE, WS, VECB>), dim3((unsigned)nwg), dim3(WS ? 512 : 256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

@@ -16,6 +16,7 @@
 // Numerics: k runs channel-major, taps row-major -- the same order as conv.hip / the packed weight matrix, so the
 // result is bit-identical to the implicit-GEMM kernel.
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -30,7 +31,16 @@ struct C3Args {
     const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
     int N, Cin, H, W, Cout, act, Mpad;
     int tilesM, tilesH, tilesW;
+#ifdef RFX_TRACE
+    long long* trace;
+#endif
 };
+#ifdef RFX_TRACE
+#define RFX_STAMP(i) do { if (threadIdx.x == 0 && a.trace) a.trace[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+extern "C" long long* rfx_debug_trace_ptr();
+#else
+#define RFX_STAMP(i)
+#endif
 
 template <int TM>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
@@ -48,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     const int tilesP = a.N * a.tilesH * a.tilesW;
     const int nwg = a.tilesM * tilesP;
     int bid = blockIdx.x;
+    RFX_STAMP(0);
     {   // XCD-aware bijective remap, m-tile fastest: the workgroups sharing one input patch sit on one L2
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     load_global(0);
     store_lds();
     __syncthreads();
+    RFX_STAMP(1);
     const float* bflat = &Bs[0][0][0];
     for (int s = 0; s < nsteps; ++s) {
         load_global(s + 1 < nsteps ? s + 1 : s);   // in flight during the 144 MFMAs below
@@ -177,36 +189,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         __syncthreads();
     }
 
-    // ---- epilogue (same arithmetic as conv.hip): y = fma(acc, scale, shift) (+ residual) -> activation ----
-    const bool has_res = a.res != nullptr;
-    const float* __restrict__ resp = a.res;
-    float* __restrict__ outp = a.out;
+    RFX_STAMP(2);
+    // ---- epilogue (conv_epilogue.h) ----
+    size_t pix_off[2];
+    bool pix_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int oh = oh0 + wn * 4 + j * 2 + (lcol >> 4), ow = ow0 + (lcol & 15);
-        const bool pv = oh < a.H && ow < a.W;
-        const size_t obase = (size_t)n * a.Cout * HW + (size_t)(pv ? oh : 0) * a.W + (pv ? ow : 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const int mc = (m0 + ml < a.Cout) ? (m0 + ml) : (a.Cout - 1);
-                rv[r] = has_res ? resp[obase + (size_t)mc * HW] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const int m = m0 + ml;
-                float v = fmaf(acc[i][j][r], s_scale[ml], s_shift[ml]);
-                if (has_res) v += rv[r];
-                if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
-                else if (a.act == RFX_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                if (pv && m < a.Cout) outp[obase + (size_t)m * HW] = v;
-            }
-        }
+        pix_ok[j] = oh < a.H && ow < a.W;
+        pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pix_ok[j] ? oh : 0) * a.W + (pix_ok[j] ? ow : 0);
     }
+    const bool full = m0 + BM <= a.Cout;
+    conv_epilogue<TM, 2, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+#ifdef RFX_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RFX_STAMP(3);
+#endif
 }
 
 }  // namespace
@@ -219,6 +217,9 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
     C3Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
+#ifdef RFX_TRACE
+    a.trace = rfx_debug_trace_ptr();
+#endif
     const int BM = 64 * tm;
     a.tilesM = (Cout + BM - 1) / BM;
     a.tilesH = (H + PT_R - 1) / PT_R;

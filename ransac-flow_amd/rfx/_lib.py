@@ -9,7 +9,7 @@ import os
 from ctypes import c_int, c_int32, c_int64, c_float, c_void_p, c_size_t, c_longlong, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "librfx.so"))
+LIB_PATH = os.environ.get("RFX_LIB") or os.path.normpath(os.path.join(_HERE, "..", "librfx.so"))  # RFX_LIB: experiments
 
 # name -> (restype, argtypes); mirrors include/rfx_api.h one to one
 SIGNATURES = {
