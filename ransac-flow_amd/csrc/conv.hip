@@ -369,9 +369,8 @@ extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, in
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
-    const int Kpad = (Cin * KH * KW + 31) / 32 * 32;
     const int env = conv_ws_env();
-    const bool ws = variant == 2 ? false : (env < 0 ? (variant == 0 && !one && Kpad >= 256) : (env != 0));
+    const bool ws = variant == 2 ? false : (env > 0);  // off by default: since the branch-free epilogue the single-role kernel is as fast
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
     const bool vecb = vec_env && one && !ws && stride == 1 && ((long long)Hout * Wout) % 4 == 0;
     return variant | (one ? 4 : 0) | (ws ? 8 : 0) | (vecb ? 16 : 0);
