@@ -130,11 +130,112 @@ __global__ __launch_bounds__(256) void maxblurpool2d_kernel(const float* __restr
     }
 }
 
+// Register-blocked form for stride 2 and Win % 4 == 0 (the FeatureExtractor stem: 64 x 480 x 640 planes, the largest
+// tensor of the pipeline): one thread produces a 2x2 block of outputs.  Its 25 max-pooled values come from a 6x6
+// input window that is fetched as 6 rows x 3 aligned float4 loads (18 loads instead of the 144 scalar ones the
+// per-output kernel issues for the same four outputs).  Blocks that touch the reflected border take the per-output
+// code.  Same operations in the same order as maxblurpool2d_kernel -> bit-identical.
+__device__ __forceinline__ float maxblur_one(const float* __restrict__ src, int oh, int ow, int Win, int Hm, int Wm) {
+    const float w[3] = {0.25f, 0.5f, 0.25f};
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int my = reflect1(oh * 2 - 1 + i, Hm);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int mx = reflect1(ow * 2 - 1 + j, Wm);
+            const float* q = src + (size_t)my * Win + mx;
+            const float a = q[0], b = q[1], c = q[Win], d = q[Win + 1];
+            float m = a;
+            m = (b > m || b != b) ? b : m;
+            m = (c > m || c != c) ? c : m;
+            m = (d > m || d != d) ? d : m;
+            acc = fmaf(m, w[i] * w[j], acc);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void maxblurpool2d_s2_block_kernel(const float* __restrict__ in,
+                                                                     float* __restrict__ out, long long nblocks,
+                                                                     int Hin, int Win, int Hout, int Wout) {
+    const float w[3] = {0.25f, 0.5f, 0.25f};
+    const int Hm = Hin - 1, Wm = Win - 1;
+    const int BH = (Hout + 1) / 2, BW = (Wout + 1) / 2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < nblocks;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int bx = (int)(idx % BW);
+        const long long r = idx / BW;
+        const int by = (int)(r % BH);
+        const long long nc = r / BH;
+        const float* src = in + nc * Hin * Win;
+        float* dst = out + nc * Hout * Wout;
+        const bool interior = by >= 1 && 4 * by + 4 <= Hin - 1 && bx >= 1 && 4 * bx + 8 <= Win && 2 * by + 1 < Hout &&
+                              2 * bx + 1 < Wout;
+        if (!interior) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oh = 2 * by + dy, ow = 2 * bx + dx;
+                    if (oh < Hout && ow < Wout) dst[(size_t)oh * Wout + ow] = maxblur_one(src, oh, ow, Win, Hm, Wm);
+                }
+            continue;
+        }
+        // input rows 4by-1 .. 4by+4, columns 4bx-4 .. 4bx+7 (window columns 4bx-1 .. 4bx+4 = v[3..8])
+        float v[6][12];
+        const float* p0 = src + (size_t)(4 * by - 1) * Win + (4 * bx - 4);
+#pragma unroll
+        for (int y = 0; y < 6; ++y)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(p0 + (size_t)y * Win + 4 * q);
+                v[y][4 * q] = t4[0]; v[y][4 * q + 1] = t4[1]; v[y][4 * q + 2] = t4[2]; v[y][4 * q + 3] = t4[3];
+            }
+        // max-pooled 5x5: M[y][x] over input (y..y+1, x..x+1), window column x -> v[.][3 + x]
+        float M[5][5];
+#pragma unroll
+        for (int y = 0; y < 5; ++y)
+#pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                const float a = v[y][3 + x], b = v[y][4 + x], c = v[y + 1][3 + x], d = v[y + 1][4 + x];
+                float m = a;
+                m = (b > m || b != b) ? b : m;
+                m = (c > m || c != c) ? c : m;
+                m = (d > m || d != d) ? d : m;
+                M[y][x] = m;
+            }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            float o[2];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc = fmaf(M[2 * dy + i][2 * dx + j], w[i] * w[j], acc);
+                o[dx] = acc;
+            }
+            float* d2 = dst + (size_t)(2 * by + dy) * Wout + 2 * bx;
+            d2[0] = o[0];
+            d2[1] = o[1];
+        }
+    }
+}
+
 extern "C" int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream) {
     if (!in || !out || NC <= 0 || Hin < 3 || Win < 3 || stride <= 0) return RFX_E_ARG;
     const int Hm = Hin - 1, Wm = Win - 1;
     const int Hout = (Hm - 1) / stride + 1, Wout = (Wm - 1) / stride + 1;
     const long long total = (long long)NC * Hout * Wout;
+    if (stride == 2 && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const long long nblocks = (long long)NC * ((Hout + 1) / 2) * ((Wout + 1) / 2);
+        hipLaunchKernelGGL(maxblurpool2d_s2_block_kernel, dim3(grid_for(nblocks, 256)), dim3(256), 0, rfx_stream(stream),
+                           in, out, nblocks, Hin, Win, Hout, Wout);
+        RFX_LAUNCH_CHECK();
+        return RFX_OK;
+    }
     hipLaunchKernelGGL(maxblurpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), in, out,
                        total, Hin, Win, Hout, Wout, stride);
     RFX_LAUNCH_CHECK();

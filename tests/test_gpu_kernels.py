@@ -86,6 +86,12 @@ def test_pools_norm_head_resize(dev):
     for s in (1, 2):   # fused stem == the two separate kernels, bit for bit
         assert torch.equal(ops.maxblurpool2d(xd, s), ops.blurpool2d(ops.maxpool2d(xd, 2, 1, 0), s))
     assert (ops.maxblurpool2d(xd, 2).cpu() - restate.blur_pool(F.max_pool2d(x, 2, 1), 2)).abs().max() < 1e-6
+    for shp in ((2, 3, 22, 28), (1, 2, 37, 40), (1, 2, 8, 8), (1, 1, 5, 4), (1, 1, 64, 96)):   # W % 4 == 0: 2x2-block kernel
+        y = torch.randn(*shp, generator=g)
+        y[0, 0, 3, 1] = float("nan")
+        yd = y.to(dev)
+        a, b = ops.maxblurpool2d(yd, 2), ops.blurpool2d(ops.maxpool2d(yd, 2, 1, 0), 2)
+        assert a.shape == b.shape and torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0)), shp
     f = torch.randn(2, 1024, 3, 5, generator=g)
     assert (ops.l2norm(f.to(dev)).cpu() - F.normalize(f)).abs().max() < 1e-6
     z = torch.zeros(1, 8, 2, 2)
