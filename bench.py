@@ -165,13 +165,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RFX_BENCH_DEVICE / RFX_BENCH_BACKEND exist only to rehearse the N>1 control flow on a 1-GPU box (all ranks on
+    # one device, gloo instead of RCCL); the driver's multi-GPU runs use the defaults: one GPU per rank, RCCL.
+    dev_index = int(os.environ.get("RFX_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("RFX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from rfx import weights, synth, ops
     from rfx.pipeline import AlignPipeline
