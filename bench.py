@@ -244,7 +244,7 @@ def main():
     tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
     tf = lambda b: "true" if b else "false"
     if dom_id & 32:
-        dom_name = "conv3x3_direct_kernel<%d>" % (1 if dom_id & 3 else 2)
+        dom_name = "conv3x3_direct_kernel<%d, %d>" % (1 if dom_id & 3 else 2, 4 if dom_id & 128 else (8 if dom_id & 64 else 16))
     else:
         dom_name = "conv2d_mfma_kernel<%s, %s, %s, %s>" % (tmn, tf(dom_id & 4), tf(dom_id & 8), tf(dom_id & 16))
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:

@@ -66,7 +66,8 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 /* Full kernel-instance id of the launch: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
  * wave-specialised form (4 MFMA + 4 loader wavefronts), bit 4 = 16-byte pixel-side loads (1x1, stride 1):
  * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints.  Bit 5 = the direct 3x3 / stride 1 / pad 1 kernel
- * conv3x3_direct_kernel<TM> (Cin % 8 == 0), TM = 2 if bits 0-1 are 0 else 1. */
+ * conv3x3_direct_kernel<TM, PT_C> (Cin % 8 == 0), TM = 2 if bits 0-1 are 0 else 1; bits 6-7 = output patch shape
+ * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least). */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
 
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;

@@ -337,7 +337,8 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 
 int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
-                              int act, int tm, hipStream_t st);  // conv3x3.hip
+                              int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
+int rfx_conv3x3_patch_cols(int H, int W);                                              // conv3x3.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -358,14 +359,16 @@ static int conv_ws_env() {
 // Kernel instance rfx_conv2d_f32 launches for this geometry: bits 0-1 tile variant (0: <2,2>, 1: <1,2>, 2: <1,1>),
 // bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), bit 4 = vectorised pixel-side loads
 // (VECB), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
-// bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM>, TM = 2 - (bits 0-1 != 0)).
+// bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM, PT_C>, TM = 2 - (bits 0-1 != 0),
+// output patch 128/PT_C x PT_C with PT_C = 16 / 8 / 4 for bits 6-7 = 0 / 1 / 2).
 extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout,
                                     int Wout) {
     static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
     if (direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
-        const long long tiles = (long long)N * ((Hout + 7) / 8) * ((Wout + 15) / 16);
+        const int pc = rfx_conv3x3_patch_cols(Hout, Wout), pr = 128 / pc;
+        const long long tiles = (long long)N * ((Hout + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
-        return 32 | (big ? 0 : 1);
+        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128));
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
@@ -402,7 +405,7 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout);
     if (kid & 32)
         return rfx_conv3x3_direct_launch(in, wT, scale, shift, residual, out, N, Cin, Hin, Win, Cout, a.Mpad, act,
-                                         (kid & 3) ? 1 : 2, st);
+                                         (kid & 3) ? 1 : 2, (kid & 128) ? 4 : ((kid & 64) ? 8 : 16), st);
     if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;

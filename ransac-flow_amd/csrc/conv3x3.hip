@@ -20,9 +20,16 @@
 
 namespace {
 
-constexpr int PT_R = 8, PT_C = 16;          // output patch
-constexpr int PR = PT_R + 2, PC = PT_C + 2;  // input patch incl. halo
-constexpr int BS = 48;                       // LDS row stride of the patch (floats)
+// Output patch of a workgroup: 128 pixels as PT_R x PT_C = 8x16, 16x8 or 32x4 (the host picks the shape that wastes
+// the fewest pixels on the image at hand: the trunk runs on 25x33 ... 36x48 maps at its small scales).  A 32-lane half
+// of a B read covers 32/PT_C patch rows; the LDS row stride BS puts those rows on disjoint banks:
+//   PT_C 16 -> 2 rows,  BS 48 (row offsets 0,16);  PT_C 8 -> 4 rows, BS 24 (0,24,16,8);  PT_C 4 -> 8 rows, BS 12 (0,12,24,4,16,28,8,20).
+template <int PT_C_> struct Patch {
+    static constexpr int PT_C = PT_C_, PT_R = 128 / PT_C_;
+    static constexpr int PR = PT_R + 2, PC = PT_C + 2;        // input patch incl. halo
+    static constexpr int BS = PT_C_ == 16 ? 48 : (PT_C_ == 8 ? 24 : 12);
+    static constexpr int RH = 32 / PT_C_;                     // patch rows per 32-pixel MFMA sub-tile
+};
 constexpr int CH = 8;                        // input channels per K step
 constexpr int KS = CH * 9;                   // 72 k per step
 constexpr int KK = KS / 2;                   // 36 k-pairs
@@ -42,8 +49,12 @@ extern "C" long long* rfx_debug_trace_ptr();
 #define RFX_STAMP(i)
 #endif
 
-template <int TM>
+template <int TM, int PTC>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
+    using G = Patch<PTC>;
+    constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
+    constexpr int NB = (CH * PR * PC + 255) / 256;   // patch elements per thread (6; 7 for the 32x4 patch)
+    static_assert(PC < BS, "the surplus staging slots live in the never-read padding columns");
     constexpr int BM = 64 * TM;
     constexpr int A_MG = BM / 4;          // groups of 4 consecutive output channels
     constexpr int A_THREADS = 6 * A_MG;   // 2 parities x 3 chunk-triples
@@ -85,13 +96,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     // byte offset of this thread's first weight float4 inside a K step (uniform step base + 32-bit lane offset)
     const unsigned woff0 = (unsigned)(((a_on ? hA + 24 * cq : 0) * a.Mpad + m0 + mg * 4) * 4);
     const unsigned wrow2 = (unsigned)(2 * a.Mpad * 4);
-    // input patch: 6 of the CH*PR*PC = 1440 patch elements per thread (the 96 surplus slots land in the unused
+    // input patch: NB of the CH*PR*PC (1440 or 1632) patch elements per thread (the surplus slots land in the unused
     // columns of the last patch row, so that every load is consumed unconditionally: no divergent store).
-    unsigned boffB[6];   // byte offset inside one channel group (cl*HW + gy*W + gx)*4; 0 with bok=false -> zero
-    bool bok[6];
-    int blds[6];         // LDS float index
+    unsigned boffB[NB];   // byte offset inside one channel group (cl*HW + gy*W + gx)*4; 0 with bok=false -> zero
+    bool bok[NB];
+    int blds[NB];        // LDS float index
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
+    for (int u = 0; u < NB; ++u) {
         const int idx = t + 256 * u;
         const bool real = idx < CH * PR * PC;
         const int cl = idx / (PR * PC), rem = idx - cl * (PR * PC);
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     }
 
     f32x4 ra[12];
-    float rb[6];
+    float rb[NB];
     auto load_global = [&](int s) {
         const char* wstep = reinterpret_cast<const char*>(a.wT + (size_t)s * KS * a.Mpad);
         if (a_on) {
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         }
         const char* base = reinterpret_cast<const char*>(inn + (size_t)s * CH * HW);
 #pragma unroll
-        for (int u = 0; u < 6; ++u) rb[u] = *reinterpret_cast<const float*>(base + boffB[u]);   // masked at store time
+        for (int u = 0; u < NB; ++u) rb[u] = *reinterpret_cast<const float*>(base + boffB[u]);   // masked at store time
     };
     auto store_lds = [&]() {
         if (a_on) {
@@ -126,11 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         }
         float* bflat = &Bs[0][0][0];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) bflat[blds[u]] = bok[u] ? rb[u] : 0.0f;
+        for (int u = 0; u < NB; ++u) bflat[blds[u]] = bok[u] ? rb[u] : 0.0f;
     };
 
     // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
-    const int pixb = (wn * 4 + (lcol >> 4)) * BS + (lcol & 15);   // sub-tile tn adds 2 rows = 2*BS
+    const int pixb = (wn * 2 * RH + lcol / PT_C) * BS + lcol % PT_C;   // sub-tile tn adds RH rows = RH*BS
     int baddr[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 bv[slot][2 * e] = bflat[baddr[q * 4 + e]];
-                bv[slot][2 * e + 1] = bflat[baddr[q * 4 + e] + 2 * BS];
+                bv[slot][2 * e + 1] = bflat[baddr[q * 4 + e] + RH * BS];
             }
         };
         read_chunk(0, 0);
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     bool pix_ok[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int oh = oh0 + wn * 4 + j * 2 + (lcol >> 4), ow = ow0 + (lcol & 15);
+        const int oh = oh0 + wn * 2 * RH + j * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
         pix_ok[j] = oh < a.H && ow < a.W;
         pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pix_ok[j] ? oh : 0) * a.W + (pix_ok[j] ? ow : 0);
     }
@@ -209,11 +220,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 
 }  // namespace
 
+// Patch shape with the fewest padded pixels for an H x W map (ties: the widest, whose stores coalesce best).
+int rfx_conv3x3_patch_cols(int H, int W) {
+    int best = 16;
+    long long best_area = -1;
+    for (int pc = 16; pc >= 4; pc >>= 1) {
+        const int pr = 128 / pc;
+        const long long area = (long long)((H + pr - 1) / pr) * ((W + pc - 1) / pc);
+        if (best_area < 0 || area < best_area) { best_area = area; best = pc; }
+    }
+    return best;
+}
+
+template <int TM, int PTC>
+static int launch_direct(C3Args& a, hipStream_t st) {
+    using G = Patch<PTC>;
+    a.tilesH = (a.H + G::PT_R - 1) / G::PT_R;
+    a.tilesW = (a.W + G::PT_C - 1) / G::PT_C;
+    const long long nwg = (long long)a.tilesM * a.N * a.tilesH * a.tilesW;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
 // Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 3x3, stride 1, pad 1,
-// Cin % 8 == 0.  tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64.
+// Cin % 8 == 0.  tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; patch_cols in {16, 8, 4}.
 int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
-                              int act, int tm, hipStream_t st) {
+                              int act, int tm, int patch_cols, hipStream_t st) {
     C3Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
@@ -222,12 +257,12 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
 #endif
     const int BM = 64 * tm;
     a.tilesM = (Cout + BM - 1) / BM;
-    a.tilesH = (H + PT_R - 1) / PT_R;
-    a.tilesW = (W + PT_C - 1) / PT_C;
-    const long long nwg = (long long)a.tilesM * N * a.tilesH * a.tilesW;
-    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    if (tm == 2) hipLaunchKernelGGL((conv3x3_direct_kernel<2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_direct_kernel<1>), dim3((unsigned)nwg), dim3(256), 0, st, a);
-    RFX_LAUNCH_CHECK();
-    return RFX_OK;
+    if (tm == 2) {
+        if (patch_cols == 16) return launch_direct<2, 16>(a, st);
+        if (patch_cols == 8) return launch_direct<2, 8>(a, st);
+        return launch_direct<2, 4>(a, st);
+    }
+    if (patch_cols == 16) return launch_direct<1, 16>(a, st);
+    if (patch_cols == 8) return launch_direct<1, 8>(a, st);
+    return launch_direct<1, 4>(a, st);
 }

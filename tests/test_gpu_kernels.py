@@ -45,6 +45,10 @@ CONV_CASES = [
     (2, 64, 19, 21, 64, 3, 1, 1, True, True, 1),      # direct 3x3 kernel <1>, ragged 8x16 patches + residual
     (8, 128, 60, 80, 256, 3, 1, 1, True, False, 1),   # direct 3x3 kernel <2>
     (1, 8, 5, 3, 130, 3, 1, 1, False, False, 0),      # direct 3x3: one K step, image smaller than a patch
+    (2, 64, 25, 33, 64, 3, 1, 1, True, True, 1),      # direct 3x3 <1, 4>: 32x4 patch
+    (64, 16, 25, 33, 128, 3, 1, 1, True, False, 1),   # direct 3x3 <2, 4>
+    (48, 16, 30, 40, 256, 3, 1, 1, True, True, 1),    # direct 3x3 <2, 8>: 16x8 patch
+    (3, 24, 28, 37, 40, 3, 1, 1, False, False, 0),    # direct 3x3 <1, 8>, Cout not a multiple of the tile
 ]
 
 
