@@ -71,20 +71,27 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
     const float* Bp = Bb + (bval ? j0 + col : 0);
     const float mk = (bval && a.maskB) ? a.maskB[(size_t)pair * a.strideMask + j0 + col] : 1.0f;
 
+    // The loads carry no select: a value that depends on a just-issued load makes the compiler wait for it on the
+    // spot (the whole gather would serialise on memory latency).  Out-of-range rows / cells read a valid dummy
+    // address and are zeroed when the registers are written to LDS, one K step later.
     float ra[KK], rb[KK];
     auto load_global = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < KK; ++i) {
             const int k = k0 + h + 2 * i;
-            const bool kin = k < a.C;
-            const float va = Ap[(size_t)(kin ? k : 0) * a.ldA];
-            const float vb = Bp[(size_t)(kin ? k : 0) * a.ldB];
-            ra[i] = (kin & aval) ? va : 0.0f;
-            rb[i] = (kin & bval) ? vb * mk : 0.0f;
+            const int kc = k < a.C ? k : 0;
+            ra[i] = Ap[(size_t)kc * a.ldA];
+            rb[i] = Bp[(size_t)kc * a.ldB];
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, int k0) {
         const int sw = (col >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < KK; ++i) {
+            const bool kin = (k0 + h + 2 * i) < a.C;
+            ra[i] = (kin & aval) ? ra[i] : 0.0f;
+            rb[i] = (kin & bval) ? rb[i] * mk : 0.0f;
+        }
 #pragma unroll
         for (int q = 0; q < KK / 4; ++q) {
             f32x4 va = {ra[4 * q], ra[4 * q + 1], ra[4 * q + 2], ra[4 * q + 3]};
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
 
     const int nk = (a.C + BK - 1) / BK;
     load_global(0);
-    store_lds(0);
+    store_lds(0, 0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_lds(cur ^ 1);
+        if (kt + 1 < nk) store_lds(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
         cur ^= 1;
     }
