@@ -311,9 +311,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
         const int rem = (int)(pp - (long long)n * HWo);
         pix_off[j] = (size_t)n * a.Cout * HWo + rem;
     }
-    const bool full = m0 + BM <= a.Cout;
     conv_epilogue<TM, TN, WS>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, (size_t)HWo, m0, wm, lrow, pix_off, pix_ok,
-                          full);
+                              m0 + BM <= a.Cout);
 #ifdef RFX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RFX_STAMP(3);
@@ -343,6 +342,8 @@ int rfx_conv3x3_patch_cols(int H, int W);                                       
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
 extern "C" int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout) {
+    static const int forced = getenv("RFX_CONV_FORCE_VARIANT") ? atoi(getenv("RFX_CONV_FORCE_VARIANT")) : -1;  // experiments
+    if (forced >= 0) return forced;
     const long long P = (long long)N * Hout * Wout;
     const long long b22 = (long long)((Cout + 127) / 128) * ((P + 127) / 128);
     const long long b12 = (long long)((Cout + 63) / 64) * ((P + 127) / 128);
