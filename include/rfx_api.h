@@ -218,6 +218,26 @@ size_t rfx_ransac_ws_bytes(int n, int N);
 int rfx_ransac_h4(const float* match1, const float* match2, int n, const int64_t* samples, int N,
                   float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, void* stream);
 
+/* The same for a whole batch of pairs in ONE launch chain (pack, DLT, count, select with blockIdx.y = pair): what the
+ * per-pair host loop around outil.RANSAC (quick_start/coarseAlignFeatMatch.py:157-170, once per pair) costs in launches
+ * and host round trips.  match1/match2 (batch,cap,3); n (batch) int32 ON THE DEVICE = matches of each pair (<= cap);
+ * samples (batch,N,4) int64; bestH (batch,9); inlier (batch,cap) uint8; result (batch,4) as above with the extra
+ * status 3 = fewer than nbPoint (4) matches (the reference returns its None sentinel before calling RANSAC,
+ * quick_start/coarseAlignFeatMatch.py:157-158).  Per pair bit-identical to rfx_ransac_h4.  batch <= 65535.
+ * ws: rfx_ransac_batched_ws_bytes(cap, N, batch). */
+size_t rfx_ransac_batched_ws_bytes(int cap, int N, int batch);
+int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_t* n, int cap, const int64_t* samples,
+                          int N, float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, int batch,
+                          void* stream);
+
+/* Match lists of a batch (quick_start/coarseAlignFeatMatch.py:150-155): match1[b,i] = (xa[idx1[b,i]], ya[idx1[b,i]], 1),
+ * match2[b,i] = (xb[idx2[b,i]], yb[idx2[b,i]], 1) for i < n[b], zeros after.  idx1/idx2 (batch,cap) int64 as written by
+ * rfx_mutual_nn_batched_f32; xa/ya = source cell coordinates (getWHTensor "H"/"W" of all scales, utils/outil.py:21-24),
+ * xb/yb = target cell coordinates; match1/match2 (batch,cap,3). */
+int rfx_gather_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32_t* n, int cap, const float* xa,
+                           const float* ya, const float* xb, const float* yb, float* match1, float* match2, int batch,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,8 +21,18 @@ namespace {
 constexpr int CHUNK = 100;         // nbMaxIter, utils/outil.py:136
 constexpr int MAX_CHUNKS = 8192;   // LDS table in select kernel -> N <= 819200 hypotheses
 
+// Batched forms (rfx_ransac_h4_batched): blockIdx.y = pair b; every per-pair array is `cap` matches / N hypotheses
+// apart and the match count comes from the device array narr (nullptr = the single-pair entry points).
 __global__ __launch_bounds__(256) void ransac_pack_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
-                                                          int n, float4* __restrict__ P, float* __restrict__ Z) {
+                                                          int n, float4* __restrict__ P, float* __restrict__ Z,
+                                                          const int32_t* __restrict__ narr, int cap, size_t wsStride) {
+    if (narr) {
+        const int b = blockIdx.y;
+        n = narr[b];
+        m1 += (size_t)b * cap * 3; m2 += (size_t)b * cap * 3;
+        P = reinterpret_cast<float4*>(reinterpret_cast<char*>(P) + b * wsStride);
+        Z = reinterpret_cast<float*>(reinterpret_cast<char*>(Z) + b * wsStride);
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         float4 p;
@@ -44,11 +54,20 @@ __device__ __forceinline__ float det3_f32(const float* h) {
 // X,Y given either as gathered samples (N,4,3) [direct != 0] or through indices into the match arrays.
 __global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict__ m1, const float* __restrict__ m2, int n,
                                                         const int64_t* __restrict__ samples, int N, int filter_dup,
-                                                        float* __restrict__ Hout, uint8_t* __restrict__ flags) {
+                                                        float* __restrict__ Hout, uint8_t* __restrict__ flags,
+                                                        const int32_t* __restrict__ narr, int cap, size_t wsStride) {
+    if (narr) {
+        const int b = blockIdx.y;
+        n = narr[b];
+        m1 += (size_t)b * cap * 3; m2 += (size_t)b * cap * 3;
+        samples += (size_t)b * N * 4;
+        Hout = reinterpret_cast<float*>(reinterpret_cast<char*>(Hout) + b * wsStride);
+        flags += b * wsStride;
+    }
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= N) return;
     float src[4][2], tgt[4][2];
-    bool dup = false, bad = false;
+    bool dup = false, bad = narr && n < 4;   // batched: a pair with fewer than nbPoint matches evaluates nothing
     if (samples) {
         int64_t s[4];
 #pragma unroll
@@ -117,7 +136,17 @@ __global__ __launch_bounds__(256) void prediction_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ransac_count_kernel(const float4* __restrict__ P, const float* __restrict__ Z, int n,
                                                            const float* __restrict__ Hs, const uint8_t* __restrict__ flags,
                                                            int N, float tol, int* __restrict__ counts32,
-                                                           int64_t* __restrict__ counts64) {
+                                                           int64_t* __restrict__ counts64,
+                                                           const int32_t* __restrict__ narr, size_t wsStride) {
+    if (narr) {
+        const int b = blockIdx.y;
+        n = narr[b];
+        P = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + b * wsStride);
+        Z = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Z) + b * wsStride);
+        Hs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Hs) + b * wsStride);
+        flags += b * wsStride;
+        counts32 = reinterpret_cast<int*>(reinterpret_cast<char*>(counts32) + b * wsStride);
+    }
     const int lane = threadIdx.x & 63;
     const int h = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (h >= N) return;
@@ -145,7 +174,20 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
                                                              const float* __restrict__ Hs, const uint8_t* __restrict__ flags,
                                                              const int* __restrict__ counts, int N, float tol,
                                                              float* __restrict__ bestH, uint8_t* __restrict__ inlier,
-                                                             int32_t* __restrict__ result) {
+                                                             int32_t* __restrict__ result,
+                                                             const int32_t* __restrict__ narr, int cap, size_t wsStride) {
+    bool too_few = false;
+    if (narr) {
+        const int b = blockIdx.x;
+        n = narr[b];
+        too_few = n < 4;
+        P = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P) + b * wsStride);
+        Z = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Z) + b * wsStride);
+        Hs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Hs) + b * wsStride);
+        flags += b * wsStride;
+        counts = reinterpret_cast<const int*>(reinterpret_cast<const char*>(counts) + b * wsStride);
+        bestH += b * 9; inlier += (size_t)b * cap; result += b * 4;
+    }
     __shared__ int chunkmax[MAX_CHUNKS];
     __shared__ int wsum[16];
     __shared__ int base;
@@ -189,6 +231,7 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
     const int bestIdx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
     int status = s_status;
     if (status == 0 && (nUnique == 0 || bestCnt == 0)) status = 2;
+    if (too_few) status = 3;
     if (t == 0) {
         result[0] = status;
         result[1] = status == 0 ? bestCnt : 0;
@@ -228,7 +271,7 @@ inline RansacWs ws_layout(int N, int n_cap) {
 extern "C" int rfx_dlt4_homography(const float* X, const float* Y, int N, float* Hout, void* stream) {
     if (!X || !Y || !Hout || N <= 0) return RFX_E_ARG;
     hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
-                       (const int64_t*)nullptr, N, 0, Hout, (uint8_t*)nullptr);
+                       (const int64_t*)nullptr, N, 0, Hout, (uint8_t*)nullptr, (const int32_t*)nullptr, 0, (size_t)0);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -248,18 +291,21 @@ extern "C" size_t rfx_ransac_ws_bytes(int n, int N) {
 }
 
 static int ransac_common(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
-                         int filter_dup, const RansacWs& L, char* w, float* Hs, int64_t* counts64, hipStream_t st) {
+                         int filter_dup, const RansacWs& L, char* w, float* Hs, int64_t* counts64, hipStream_t st,
+                         const int32_t* narr = nullptr, int cap = 0, int batch = 1) {
     float4* P = reinterpret_cast<float4*>(w + L.P);
     float* Z = reinterpret_cast<float*>(w + L.Z);
     uint8_t* flags = reinterpret_cast<uint8_t*>(w + L.flags);
     int* counts = reinterpret_cast<int*>(w + L.counts);
-    hipLaunchKernelGGL(ransac_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, match1, match2, n, P, Z);
+    const int nmax = narr ? cap : n;
+    hipLaunchKernelGGL(ransac_pack_kernel, dim3((nmax + 255) / 256, batch), dim3(256), 0, st, match1, match2, n, P, Z, narr,
+                       cap, L.total);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, st, match1, match2, n, samples, N,
-                       filter_dup, Hs, flags);
+    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
+                       filter_dup, Hs, flags, narr, cap, L.total);
     RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((N + 3) / 4), dim3(256), 0, st, P, Z, n, Hs, flags, N, tol, counts,
-                       counts64);
+    hipLaunchKernelGGL(ransac_count_kernel, dim3((N + 3) / 4, batch), dim3(256), 0, st, P, Z, n, Hs, flags, N, tol, counts,
+                       counts64, narr, L.total);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -284,7 +330,67 @@ extern "C" int rfx_ransac_h4(const float* match1, const float* match2, int n, co
     if (rc != RFX_OK) return rc;
     hipLaunchKernelGGL(ransac_select_kernel, dim3(1), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
                        reinterpret_cast<const float*>(w + L.Z), n, Hs, reinterpret_cast<const uint8_t*>(w + L.flags),
-                       reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result);
+                       reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result,
+                       (const int32_t*)nullptr, 0, (size_t)0);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// ---- batched RANSAC: every pair of a batch in ONE launch chain (pack, DLT, count, select), match counts read from a
+// device array.  Same kernels, same arithmetic per pair as rfx_ransac_h4.
+extern "C" size_t rfx_ransac_batched_ws_bytes(int cap, int N, int batch) {
+    if (N <= 0 || cap <= 0 || batch <= 0) return 0;
+    return ws_layout(N, cap).total * (size_t)batch;
+}
+
+extern "C" int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_t* n, int cap,
+                                     const int64_t* samples, int N, float tol, float* bestH, uint8_t* inlier,
+                                     int32_t* result, void* ws, int batch, void* stream) {
+    if (!match1 || !match2 || !n || !samples || !bestH || !inlier || !result || !ws || cap <= 0 || N <= 0 || batch <= 0)
+        return RFX_E_ARG;
+    if ((N + CHUNK - 1) / CHUNK > MAX_CHUNKS || batch > 65535) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, cap);
+    char* w = static_cast<char*>(ws);
+    float* Hs = reinterpret_cast<float*>(w + L.H);
+    hipStream_t st = rfx_stream(stream);
+    int rc = ransac_common(match1, match2, 0, samples, N, tol, 1, L, w, Hs, nullptr, st, n, cap, batch);
+    if (rc != RFX_OK) return rc;
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
+                       reinterpret_cast<const float*>(w + L.Z), 0, Hs, reinterpret_cast<const uint8_t*>(w + L.flags),
+                       reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result, n, cap, L.total);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// match1[b,i] = (xa[idx1[b,i]], ya[idx1[b,i]], 1), match2[b,i] = (xb[idx2[b,i]], yb[idx2[b,i]], 1) for i < n[b], zeros after:
+// the match lists of quick_start/coarseAlignFeatMatch.py:150-155 for a whole batch in one launch.
+namespace {
+__global__ __launch_bounds__(256) void gather_matches_kernel(const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2,
+                                                             const int32_t* __restrict__ narr, int cap,
+                                                             const float* __restrict__ xa, const float* __restrict__ ya,
+                                                             const float* __restrict__ xb, const float* __restrict__ yb,
+                                                             float* __restrict__ m1, float* __restrict__ m2) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const size_t o = ((size_t)b * cap + i) * 3;
+    if (i < narr[b]) {
+        const int64_t a = idx1[(size_t)b * cap + i], t = idx2[(size_t)b * cap + i];
+        m1[o] = xa[a]; m1[o + 1] = ya[a]; m1[o + 2] = 1.0f;
+        m2[o] = xb[t]; m2[o + 1] = yb[t]; m2[o + 2] = 1.0f;
+    } else {
+        m1[o] = m1[o + 1] = m1[o + 2] = 0.0f;
+        m2[o] = m2[o + 1] = m2[o + 2] = 0.0f;
+    }
+}
+}  // namespace
+
+extern "C" int rfx_gather_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32_t* n, int cap, const float* xa,
+                                      const float* ya, const float* xb, const float* yb, float* match1, float* match2,
+                                      int batch, void* stream) {
+    if (!idx1 || !idx2 || !n || !xa || !ya || !xb || !yb || !match1 || !match2 || cap <= 0 || batch <= 0) return RFX_E_ARG;
+    if (batch > 65535) return RFX_E_LIMIT;
+    hipLaunchKernelGGL(gather_matches_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, rfx_stream(stream), idx1, idx2, n,
+                       cap, xa, ya, xb, yb, match1, match2);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -363,3 +363,37 @@ def ransac_h4(match1, match2, samples, tol):
     _lib.check(lib.rfx_ransac_h4(_p(match1), _p(match2), n, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res),
                                  _p(ws), _stream()), "rfx_ransac_h4")
     return bestH, inl.bool(), res
+
+
+def gather_matches(idx1, idx2, n, xa, ya, xb, yb):
+    """idx1/idx2 (B,cap) int64, n (B,) int32 (device) -> match1, match2 (B,cap,3) float32 (rows >= n[b] are zero)."""
+    idx1, idx2 = _dev(idx1, "idx1", torch.int64), _dev(idx2, "idx2", torch.int64)
+    n = _dev(n, "n", torch.int32)
+    B, cap = idx1.shape
+    m1 = torch.empty((B, cap, 3), dtype=torch.float32, device=idx1.device)
+    m2 = torch.empty((B, cap, 3), dtype=torch.float32, device=idx1.device)
+    _lib.check(_lib.load().rfx_gather_matches_f32(_p(idx1), _p(idx2), _p(n), cap, _p(_dev(xa, "xa")), _p(_dev(ya, "ya")),
+                                                 _p(_dev(xb, "xb")), _p(_dev(yb, "yb")), _p(m1), _p(m2), B, _stream()),
+               "rfx_gather_matches_f32")
+    return m1, m2
+
+
+def ransac_h4_batched(match1, match2, n, samples, tol):
+    """match1/match2 (B,cap,3), n (B,) int32 device, samples (B,N,4) int64 -> bestH (B,3,3), inlier (B,cap) bool,
+    result (B,4) int32 [status (3 = fewer than 4 matches), count, winner, nUnique] -- all device tensors."""
+    match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
+    n = _dev(n, "n", torch.int32)
+    samples = _dev(samples, "samples", torch.int64)
+    B, cap, _ = match1.shape
+    N = samples.shape[1]
+    if samples.shape[0] != B or n.shape[0] != B:
+        raise ValueError("batch sizes differ")
+    lib = _lib.load()
+    dev = match1.device
+    bestH = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+    inl = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+    res = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.rfx_ransac_batched_ws_bytes(cap, N, B), dtype=torch.uint8, device=dev)
+    _lib.check(lib.rfx_ransac_h4_batched(_p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
+                                         _p(res), _p(ws), B, _stream()), "rfx_ransac_h4_batched")
+    return bestH, inl.bool(), res

@@ -144,36 +144,53 @@ class AlignPipeline:
         feats = feats or self.features(prep)
         B = prep["B"]
         lib_out = []
-        # phase 1: ONE batched mutual-NN launch chain for all pairs, one sync for the counts
+        # phase 1: ONE batched mutual-NN launch chain for all pairs, one sync for the counts (the index draw of
+        # utils/outil.py:120 needs nbMatch on the host)
         idx1, idx2, cnt = self._mutual_batched(feats, B, maskB)
         counts = cnt.cpu().tolist()  # <- sync #1
-        pend = [(idx1[b], idx2[b]) for b in range(B)]
-        # phase 2: index draw on the host, RANSAC launches
+        # phase 2: index draw on the host (per pair, in pair order), then ONE batched launch chain for the match
+        # lists and RANSAC of every pair
+        draws = []
         for b in range(B):
             n = counts[b]
-            i1, i2 = pend[b][0][:n], pend[b][1][:n]
+            if n >= 4:
+                draws.append(samples[b] if samples is not None else torch.randint(n, (self.nbIter, 4)))
+            else:
+                draws.append(torch.zeros((self.nbIter, 4), dtype=torch.int64))
+        if len({tuple(d.shape) for d in draws}) != 1:       # explicit draws of different lengths: one launch chain per pair
+            return self._coarse_per_pair(feats, idx1, idx2, counts, draws)
+        smp = torch.stack(draws).to(self.dev, non_blocking=True)
+        M1, M2 = ops.gather_matches(idx1, idx2, cnt, feats["HA"], feats["WA"], feats["Ht"], feats["Wt"])
+        bestH, inl, resd = ops.ransac_h4_batched(M1, M2, cnt, smp, self.tol)
+        st = resd.cpu().tolist()  # <- sync #2
+        for b in range(B):
+            n = counts[b]
+            res = dict(index1=idx1[b, :n], index2=idx2[b, :n], H=None, inlier=None, samples=None, n=n)
+            if n >= 4:
+                status, c, widx, nuniq = st[b]
+                res.update(match1=M1[b, :n], match2=M2[b, :n], samples=draws[b], status=status, count=c, winner=widx,
+                           nUnique=nuniq)
+                if status == 0:
+                    res["H"], res["inlier"] = bestH[b], inl[b, :n]
+            lib_out.append(res)
+        return lib_out
+
+    def _coarse_per_pair(self, feats, idx1, idx2, counts, draws):
+        out = []
+        for b, n in enumerate(counts):
+            i1, i2 = idx1[b, :n], idx2[b, :n]
             res = dict(index1=i1, index2=i2, H=None, inlier=None, samples=None, n=n)
             if n >= 4:
                 ones = torch.ones(n, dtype=torch.float32, device=self.dev)
                 m1 = torch.stack((feats["HA"][i1], feats["WA"][i1], ones), dim=1)
                 m2 = torch.stack((feats["Ht"][i2], feats["Wt"][i2], ones), dim=1)
-                s = samples[b] if samples is not None else torch.randint(n, (self.nbIter, 4))
-                sd = s.to(self.dev)
-                bestH, inl, r = ops.ransac_h4(m1, m2, sd, self.tol)
-                res.update(match1=m1, match2=m2, samples=s, _H=bestH, _inl=inl, _res=r)
-            lib_out.append(res)
-        stat = [r["_res"] for r in lib_out if "_res" in r]
-        if stat:
-            st = torch.stack(stat).cpu().tolist()  # <- sync #2
-            k = 0
-            for r in lib_out:
-                if "_res" in r:
-                    status, cnt, widx, nuniq = st[k]
-                    k += 1
-                    r["status"], r["count"], r["winner"], r["nUnique"] = status, cnt, widx, nuniq
-                    if status == 0:
-                        r["H"], r["inlier"] = r["_H"], r["_inl"]
-        return lib_out
+                bestH, inl, r = ops.ransac_h4(m1, m2, draws[b].to(self.dev), self.tol)
+                status, c, widx, nuniq = r.cpu().tolist()
+                res.update(match1=m1, match2=m2, samples=draws[b], status=status, count=c, winner=widx, nUnique=nuniq)
+                if status == 0:
+                    res["H"], res["inlier"] = bestH, inl
+            out.append(res)
+        return out
 
     def _mutual_batched(self, feats, B, maskB=None):
         from . import _lib

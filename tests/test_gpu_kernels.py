@@ -330,3 +330,44 @@ def test_lanczos_and_to_tensor_bit_exact_vs_pillow(dev):
             assert a.shape == b.shape and torch.equal(a, b)
         for k in ("tgt", "IsTensor", "ItTensor"):
             assert torch.equal(host[k], devp[k]), k
+
+
+def test_batched_ransac_equals_per_pair(dev):
+    """rfx_gather_matches_f32 + rfx_ransac_h4_batched against the single-pair entry point, pair by pair: identical H bits,
+    inlier masks and result records; a pair with < 4 matches reports status 3, a hopeless pair the abort status."""
+    g = torch.Generator().manual_seed(9)
+    B, cap, N = 6, 300, 700
+    rows, cols = 15, 20
+    xs = ((torch.arange(cols) + 0.5) / cols - 0.5) * 2
+    ys = ((torch.arange(rows) + 0.5) / rows - 0.5) * 2
+    xb = xs.repeat(rows); yb = ys.repeat_interleave(cols)                    # target lattice (x, y)
+    Hm = torch.tensor([[1.05, .02, .03], [-.01, .97, -.02], [.01, .02, 1.]])
+    pts = torch.stack((xb, yb, torch.ones_like(xb)), 1) @ Hm.T
+    xa, ya = pts[:, 0] / pts[:, 2], pts[:, 1] / pts[:, 2]                    # source coordinates of the same cells
+    nb = [300, 257, 3, 120, 4, 64]
+    idx1 = torch.zeros(B, cap, dtype=torch.int64); idx2 = torch.zeros(B, cap, dtype=torch.int64)
+    for b, n in enumerate(nb):
+        i2 = torch.randperm(rows * cols, generator=g)[:n]
+        i1 = i2.clone()
+        bad = torch.rand(n, generator=g) < (1.0 if b == 3 else 0.5)          # pair 3: every match wrong
+        i1[bad] = torch.randint(rows * cols, (int(bad.sum()),), generator=g)
+        idx1[b, :n], idx2[b, :n] = i1, i2
+    smp = torch.stack([torch.randint(max(n, 1), (N, 4), generator=g) for n in nb])
+    tol = 0.02
+    n_dev = torch.tensor(nb, dtype=torch.int32, device=dev)
+    M1, M2 = ops.gather_matches(idx1.to(dev), idx2.to(dev), n_dev, xa.to(dev), ya.to(dev), xb.to(dev), yb.to(dev))
+    Hb, Ib, Rb = ops.ransac_h4_batched(M1, M2, n_dev, smp.to(dev), tol)
+    Rb = Rb.cpu()
+    for b, n in enumerate(nb):
+        m1 = torch.stack((xa[idx1[b, :n]], ya[idx1[b, :n]], torch.ones(n)), 1)
+        m2 = torch.stack((xb[idx2[b, :n]], yb[idx2[b, :n]], torch.ones(n)), 1)
+        assert torch.equal(M1[b, :n].cpu(), m1) and torch.equal(M2[b, :n].cpu(), m2)
+        assert float(M1[b, n:].abs().max() if n < cap else 0) == 0.0
+        if n < 4:
+            assert Rb[b, 0].item() == 3 and not bool(Ib[b].any())
+            continue
+        h, inl, r = ops.ransac_h4(m1.to(dev), m2.to(dev), smp[b].to(dev), tol)
+        assert torch.equal(Rb[b], r.cpu()), (b, Rb[b], r)
+        assert torch.equal(Hb[b].cpu().view(torch.int32), h.cpu().view(torch.int32))
+        assert torch.equal(Ib[b, :n].cpu(), inl.cpu()) and not bool(Ib[b, n:].any())
+    assert Rb[0, 0].item() == 0 and Rb[0, 1].item() > 50
