@@ -238,8 +238,9 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
         result[2] = status == 0 ? bestIdx : -1;
         result[3] = nUnique;
     }
+    const int nout = narr ? cap : n;   // batched: the padding rows of the mask are defined (0) too
     if (status != 0) {
-        for (int m = t; m < n; m += 1024) inlier[m] = 0;
+        for (int m = t; m < nout; m += 1024) inlier[m] = 0;
         if (t < 9) bestH[t] = 0.0f;
         return;
     }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
 #pragma unroll
     for (int j = 0; j < 9; ++j) H[j] = Hs[(size_t)bestIdx * 9 + j];
     if (t < 9) bestH[t] = H[t];
-    for (int m = t; m < n; m += 1024) inlier[m] = is_inlier(P[m], Z[m], H, tol) ? 1 : 0;
+    for (int m = t; m < nout; m += 1024) inlier[m] = (m < n && is_inlier(P[m], Z[m], H, tol)) ? 1 : 0;
 }
 
 struct RansacWs {
