@@ -139,29 +139,35 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
 
     f32x4 ra[A_NJ];
     float rb[B_NI];
+    // Validity of the B-side values of the step in flight, one bit per load.  It is applied when the registers are
+    // written to LDS, NOT at the load: a select on a just-loaded value makes the compiler wait for that load on the
+    // spot, which serialises the gather on memory latency (and, with the loads pinned ahead of the MFMAs, would stall
+    // the whole step).  Invalid elements read a valid dummy address.
+    unsigned okmask = 0;
 
     auto load_global = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < A_NJ; ++j)
             ra[j] = *reinterpret_cast<const f32x4*>(wcol + (size_t)(k0 + hA + 2 * (iA0 + j)) * a.Mpad);
         if (VECB) {
+            okmask = 0;
 #pragma unroll
             for (int j = 0; j < B_NJ; ++j) {
                 const int k = k0 + hV + 2 * (iV0 + j);
                 const bool ok = vvalid & (k < a.Cin);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(inv + (size_t)(ok ? k : 0) * HWin);
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                rv[j] = ok ? v : z;
+                okmask |= ok ? (1u << j) : 0u;
+                rv[j] = *reinterpret_cast<const f32x4*>(inv + (size_t)(ok ? k : 0) * HWin);
             }
             return;
         }
         if (ONE) {
+            okmask = 0;
 #pragma unroll
             for (int i = 0; i < B_NI; ++i) {
                 const int k = k0 + hB + 2 * (iB0 + i);
                 const bool ok = pvalid & (k < a.Cin);
-                const float v = inb[(size_t)(ok ? k : 0) * HWin];
-                rb[i] = ok ? v : 0.0f;
+                okmask |= ok ? (1u << i) : 0u;
+                rb[i] = inb[(size_t)(ok ? k : 0) * HWin];
             }
             return;
         }
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
         int ev[B_NI];
 #pragma unroll
         for (int i = 0; i < B_NI; ++i) ev[i] = kt[i];
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < B_NI; ++i) {
             const int e = ev[i];
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
             // bitwise & (no short-circuit): keeps the gather branch-free (v_cndmask, not exec-mask branches)
             const bool ok = pvalid & (e >= 0) & ((unsigned)ih < (unsigned)a.Hin) & ((unsigned)iw < (unsigned)a.Win);
             const int off = (cin * a.Hin + ih) * a.Win + iw;
-            const float v = inb[ok ? off : 0];  // always a valid address; selected below
-            rb[i] = ok ? v : 0.0f;
+            okmask |= ok ? (1u << i) : 0u;
+            rb[i] = inb[ok ? off : 0];  // always a valid address; masked in store_lds
         }
     };
     auto store_lds = [&](int buf) {
@@ -201,6 +208,11 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
         }
         if (VECB) {
 #pragma unroll
+            for (int j = 0; j < B_NJ; ++j) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rv[j] = ((okmask >> j) & 1u) ? rv[j] : z;
+            }
+#pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float* dst = &Bs[buf][hV][pg * 4 + e][0];
                 if (B_NJ == 4) {
@@ -214,6 +226,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
             }
             return;
         }
+#pragma unroll
+        for (int i = 0; i < B_NI; ++i) rb[i] = ((okmask >> i) & 1u) ? rb[i] : 0.0f;
 #pragma unroll
         for (int q = 0; q < B_NI / 4; ++q) {
             f32x4 v = {rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]};
@@ -291,7 +305,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
             // branch-free body (the last step re-loads its own tile into the unused buffer): one basic block, so the
             // scheduler is free to interleave the gather of step kt+1 with the MFMAs of step kt
             load_global((kt + 1 < nk ? kt + 1 : kt) * BK);
-            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);   // the loads stay AHEAD of the MFMAs: left to itself the scheduler sinks them
+            compute(cur);                        // to the end of the step and their latency is exposed at every barrier
+            __builtin_amdgcn_sched_barrier(0);   // ... and nothing that consumes them is hoisted into the MFMA stream
             store_lds(cur ^ 1);
             __syncthreads();
             cur ^= 1;

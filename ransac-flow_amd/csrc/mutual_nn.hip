@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_global((kt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (the scheduler would sink them)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 af[2][2], bf[2][2];
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
                         for (int j = 0; j < 2; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);   // ... and their consumers behind them
         if (kt + 1 < nk) store_lds(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
         cur ^= 1;
