@@ -83,6 +83,14 @@ int rfx_blurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, in
  * (model/model.py:71-72).  Hout = (Hin-2)/stride+1.  Bit-identical to the two separate calls. */
 int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int stride, void* stream);
 
+/* The whole FeatureExtractor stem in one kernel (model/model.py:68-72, forward :106-110): conv3x3(3 -> Cout, stride 1,
+ * pad 1) + folded BatchNorm + ReLU + MaxPool2d(2, stride 1) + BlurPool(stride 2).  in (N,3,H,W); wT / scale / shift as
+ * for rfx_conv2d_f32 (the packed weights of that convolution: K = 27 -> Kpad = 32 rows); out (N,Cout,(H-2)/2+1,(W-2)/2+1).
+ * Bit-identical to rfx_conv2d_f32(act = ReLU) followed by rfx_maxblurpool2d_f32(stride 2); the full-resolution
+ * Cout-channel map never goes to HBM.  Cout % 32 == 0. */
+int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, const float* scale, const float* shift, float* out,
+                                 int N, int H, int W, int Cout, void* stream);
+
 /* F.normalize(x, p=2, dim=1, eps=1e-12) on NCHW (quick_start/coarseAlignFeatMatch.py:106,124;
  * quick_start/align2images.py:87-88).  `in` is dense; element (n,c,p) of the result goes to
  * out[n*out_batch_stride + c*out_chan_stride + p] (0 = dense defaults C*HW / HW), which lets the coarse

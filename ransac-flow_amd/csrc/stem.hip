@@ -1,0 +1,191 @@
+// stem.hip -- the FeatureExtractor stem as ONE kernel (model/model.py:68-72, forward :106-110):
+//     conv3x3(3 -> 64, stride 1, pad 1) -> BatchNorm (folded) -> ReLU -> MaxPool2d(2, stride 1) -> BlurPool(stride 2)
+// Un-fused, the 64-channel full-resolution map (480 x 640 x 64 floats per image: the largest tensor of the whole
+// pipeline, 10 GB for a batch of 128 images) is written by the convolution and read back by the pooling kernel; both
+// are bound by exactly that traffic.  Here a workgroup owns a 4 x 16 tile of POOLED outputs for 32 channels:
+//   1. the 3 x 12 x 36 input patch it needs goes to LDS (zero filled outside the image = the conv padding);
+//   2. the 10 x 34 conv outputs under the tile are computed on the fp32 MFMA: pixel p = row*34 + col is a column of
+//      the 32x32 tile, k = c*9 + kh*3 + kw (27, padded to 28) runs in the same order and the same (2kk, 2kk+1)
+//      pairing as conv.hip, so the accumulators are bit-identical to the stand-alone convolution; B operands are
+//      single ds_read_b32 from the patch at per-lane addresses;
+//   3. fma(acc, scale, shift) -> ReLU -> LDS tile [32 ch][10][34];
+//   4. max 2x2 / blur [1 2 1]^2/16 stride 2 with ReflectionPad2d(1) on the max-pooled map, in the operation order of
+//      maxblurpool2d_kernel (pool.hip) -> bit-identical to conv2d + maxblurpool2d; a thread produces 2x2 blocks of
+//      outputs from a 6x6 window (border blocks take the per-output path that reflects indices).
+// Only the /2 map is written: HBM traffic per image drops from (3 + 64 + 64 + 16) to (3 + 16) full-resolution planes.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 4, TW = 16;                 // pooled outputs per workgroup
+constexpr int CR = 2 * TH + 2, CC = 2 * TW + 2; // conv outputs under the tile: 10 x 34
+constexpr int PRW = CR + 2, PCL = CC + 2;       // input patch 12 x 36
+constexpr int CST = CC + 1;                     // row stride of the conv tile in LDS (35: odd -> rows on different banks)
+constexpr int NPX = CR * CC;                    // 340 conv pixels
+constexpr int NSUB = (NPX + 31) / 32;           // 11 MFMA sub-tiles of 32 pixels
+constexpr int KKS = 14;                         // 28 = 27 padded k, as k-pairs
+constexpr int MCH = 32;                         // channels per workgroup
+
+struct StemArgs {
+    const float* in; const float* wT; const float* scale; const float* shift; float* out;
+    int N, H, W, Cout, Mpad, Ho, Wo, tilesH, tilesW, chGroups;
+};
+
+__device__ __forceinline__ int reflect1i(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__device__ __forceinline__ float max4_first(float a, float b, float c, float d) {   // MaxPool2d scan order, NaN propagating
+    float m = a;
+    m = (b > m || b != b) ? b : m;
+    m = (c > m || c != c) ? c : m;
+    m = (d > m || d != d) ? d : m;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
+    __shared__ float P[3][PRW][PCL];          // input patch
+    __shared__ float C[MCH][CR][CST];         // conv + BN + ReLU outputs under the tile
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    int bid = blockIdx.x;
+    const int cg = bid % a.chGroups; bid /= a.chGroups;       // channel group fastest: the groups of a tile share the patch in L2
+    const int tw = bid % a.tilesW; bid /= a.tilesW;
+    const int th = bid % a.tilesH;
+    const int n = bid / a.tilesH;
+    const int oh0 = th * TH, ow0 = tw * TW;
+    const int cy0 = 2 * oh0 - 1, cx0 = 2 * ow0 - 1;           // first conv row / column under the tile (= first max-map row / column)
+    const int m0 = cg * MCH;
+    const size_t HW = (size_t)a.H * a.W;
+
+    // ---- 1. input patch (rows cy0-1 .. cy0+10, cols cx0-1 .. cx0+34), zero outside the image
+    const float* inn = a.in + (size_t)n * 3 * HW;
+    for (int idx = t; idx < 3 * PRW * PCL; idx += 256) {
+        const int c = idx / (PRW * PCL), rem = idx - c * (PRW * PCL);
+        const int pr = rem / PCL, pc = rem - pr * PCL;
+        const int gy = cy0 - 1 + pr, gx = cx0 - 1 + pc;
+        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const float v = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
+        (&P[0][0][0])[idx] = ok ? v : 0.0f;
+    }
+    // A operand of this lane: weights of channel m0 + lcol for k = 2kk + lrow (rows K..Kpad-1 of wT are zero)
+    float af[KKS];
+#pragma unroll
+    for (int kk = 0; kk < KKS; ++kk) af[kk] = a.wT[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
+    // per-lane patch offsets of the 14 k-pairs (tap (c, kh, kw) of k = 2kk + lrow); k = 27 is the zero pad
+    int koff[KKS];
+#pragma unroll
+    for (int kk = 0; kk < KKS; ++kk) {
+        const int k = 2 * kk + lrow;
+        const int c = k / 9, t9 = k - c * 9, kh = t9 / 3, kw = t9 - kh * 3;
+        koff[kk] = k < 27 ? c * (PRW * PCL) + kh * PCL + kw : 0;
+    }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = m0 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+        sc[r] = a.scale ? a.scale[ch] : 1.0f;
+        sh[r] = a.shift ? a.shift[ch] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- 2./3. conv on the MFMA, BN + ReLU, tile -> LDS
+    const float* pf = &P[0][0][0];
+    for (int s = wave; s < NSUB; s += 4) {
+        const int p = s * 32 + lcol;
+        const bool pv = p < NPX;
+        const int pc = pv ? p : 0;
+        const int py = pc / CC, px = pc - py * CC;
+        const int pbase = py * PCL + px;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KKS; ++kk) {
+            float b = pf[pbase + koff[kk]];
+            if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 27: padded tap
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
+        }
+        if (pv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acc[r], sc[r], sh[r]);
+                v = v > 0.0f ? v : 0.0f;
+                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][px] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. max 2x2 (stride 1) + blur/2 with reflection on the max-pooled map; 2x2 output blocks
+    const float w3[3] = {0.25f, 0.5f, 0.25f};
+    const int Hm = a.H - 1, Wm = a.W - 1;
+    for (int b = t; b < MCH * (TH / 2) * (TW / 2); b += 256) {
+        const int bx = b % (TW / 2), by = (b / (TW / 2)) % (TH / 2), ch = b / ((TW / 2) * (TH / 2));
+        const int oh = oh0 + 2 * by, ow = ow0 + 2 * bx;        // first output of the block
+        if (oh >= a.Ho || ow >= a.Wo) continue;
+        float* dst = a.out + ((size_t)n * a.Cout + m0 + ch) * a.Ho * a.Wo;
+        const float (*Cc)[CST] = C[ch];
+        // interior: the 5x5 max-map window rows 2oh-1 .. 2oh+3, cols 2ow-1 .. 2ow+3 needs no reflection
+        const bool interior = oh >= 1 && 2 * oh + 3 <= Hm - 1 && ow >= 1 && 2 * ow + 3 <= Wm - 1 && oh + 1 < a.Ho && ow + 1 < a.Wo;
+        if (interior) {
+            const int ly = 2 * oh - 1 - cy0, lx = 2 * ow - 1 - cx0;   // = 4*by, 4*bx
+            float v[6][6];
+#pragma unroll
+            for (int y = 0; y < 6; ++y)
+#pragma unroll
+                for (int x = 0; x < 6; ++x) v[y][x] = Cc[ly + y][lx + x];
+            float M[5][5];
+#pragma unroll
+            for (int y = 0; y < 5; ++y)
+#pragma unroll
+                for (int x = 0; x < 5; ++x) M[y][x] = max4_first(v[y][x], v[y][x + 1], v[y + 1][x], v[y + 1][x + 1]);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc = fmaf(M[2 * dy + i][2 * dx + j], w3[i] * w3[j], acc);
+                    dst[(size_t)(oh + dy) * a.Wo + ow + dx] = acc;
+                }
+            continue;
+        }
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const int o_h = oh + dy, o_w = ow + dx;
+                if (o_h >= a.Ho || o_w >= a.Wo) continue;
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int my = reflect1i(2 * o_h - 1 + i, Hm) - cy0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int mx = reflect1i(2 * o_w - 1 + j, Wm) - cx0;
+                        const float m = max4_first(Cc[my][mx], Cc[my][mx + 1], Cc[my + 1][mx], Cc[my + 1][mx + 1]);
+                        acc = fmaf(m, w3[i] * w3[j], acc);
+                    }
+                }
+                dst[(size_t)o_h * a.Wo + o_w] = acc;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, const float* scale, const float* shift,
+                                            float* out, int N, int H, int W, int Cout, void* stream) {
+    if (!in || !wT || !out || N <= 0 || H < 3 || W < 3 || Cout <= 0) return RFX_E_ARG;
+    if (Cout % MCH != 0) return RFX_E_ARG;
+    StemArgs a;
+    a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Mpad = (Cout + 127) / 128 * 128;
+    a.Ho = (H - 2) / 2 + 1; a.Wo = (W - 2) / 2 + 1;
+    a.tilesH = (a.Ho + TH - 1) / TH; a.tilesW = (a.Wo + TW - 1) / TW; a.chGroups = Cout / MCH;
+    const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL(stem_conv_maxblur_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

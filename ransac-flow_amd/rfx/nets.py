@@ -70,8 +70,7 @@ class FeatureExtractorNet:
                 self.blocks.append(blk)
 
     def __call__(self, x):
-        x = self.conv1(x)
-        x = ops.maxblurpool2d(x, 2)  # MaxPool2d(2, stride 1) + BlurPool/2 fused
+        x = ops.stem_conv_maxblur(x, self.conv1)  # conv1 + BN + ReLU + MaxPool2d(2, stride 1) + BlurPool/2 in one kernel
         for blk in self.blocks:
             o = blk["c1"](x)
             r = blk["ds"](ops.blurpool2d(x, blk["stride"])) if blk["ds"] is not None else x

@@ -123,6 +123,29 @@ def maxblurpool2d(x, stride=2):
     return out
 
 
+def stem_conv_maxblur(x, plan):
+    """FeatureExtractor stem: plan = ConvPlan of the 3x3 / stride 1 / pad 1 / ReLU convolution with 3 input channels;
+    returns maxblurpool2d(plan(x), 2) without materialising plan(x)."""
+    x = _dev(x, "stem input")
+    N, C, H, W = x.shape
+    if not (C == 3 and plan.Cin == 3 and plan.KH == 3 and plan.KW == 3 and plan.stride == 1 and plan.pad == 1
+            and plan.act == ACT_RELU and plan.Cout % 32 == 0):
+        raise ValueError("stem_conv_maxblur: not a 3x3/s1/p1 ReLU convolution of a 3-channel image")
+    Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    out = torch.empty((N, plan.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    timer = ConvPlan.timer
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().rfx_stem_conv3x3_maxblur_f32(_p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
+                                                       plan.Cout, _stream()), "rfx_stem_conv3x3_maxblur_f32")
+    if timer is not None:
+        e1.record()
+        timer.append((256, 2.0 * N * H * W * plan.Cout * 27, e0, e1, (N, 3, H, W, plan.Cout, 3, 1),
+                      4.0 * (N * 3 * H * W + N * plan.Cout * Ho * Wo)))
+    return out
+
+
 def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):
     """F.normalize(x, dim=1) for (N,C,H,W) or (N,C,L).  With ``out`` (a float32 device tensor/view start) the
     result is scattered with the given strides (elements)."""

@@ -371,3 +371,23 @@ def test_batched_ransac_equals_per_pair(dev):
         assert torch.equal(Hb[b].cpu().view(torch.int32), h.cpu().view(torch.int32))
         assert torch.equal(Ib[b, :n].cpu(), inl.cpu()) and not bool(Ib[b, n:].any())
     assert Rb[0, 0].item() == 0 and Rb[0, 1].item() > 50
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 56), (1, 37, 45), (3, 16, 16), (1, 7, 9), (1, 3, 3), (2, 64, 130)])
+def test_fused_stem_equals_conv_then_maxblurpool(dev, shape):
+    """rfx_stem_conv3x3_maxblur_f32 == rfx_conv2d_f32(ReLU) -> rfx_maxblurpool2d_f32, bit for bit (same MFMA k order,
+    same pooling order), including ragged tiles, reflected borders and a NaN pixel."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    if H > 5:
+        x[0, 1, 4, 2] = float("nan")
+    w = torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5
+    bn = dict(weight=1 + 0.3 * torch.randn(64, generator=g), bias=0.2 * torch.randn(64, generator=g),
+              running_mean=0.2 * torch.randn(64, generator=g), running_var=0.5 + torch.rand(64, generator=g))
+    plan = ops.ConvPlan(w, bn, 1, 1, ops.ACT_RELU, dev)
+    xd = x.to(dev)
+    ref = ops.maxblurpool2d(plan(xd), 2)
+    out = ops.stem_conv_maxblur(xd, plan)
+    assert out.shape == ref.shape
+    assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
