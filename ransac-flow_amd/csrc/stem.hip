@@ -33,12 +33,12 @@ struct StemArgs {
 
 __device__ __forceinline__ int reflect1i(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-__device__ __forceinline__ float max4_first(float a, float b, float c, float d) {   // MaxPool2d scan order, NaN propagating
-    float m = a;
-    m = (b > m || b != b) ? b : m;
-    m = (c > m || c != c) ? c : m;
-    m = (d > m || d != d) ? d : m;
-    return m;
+// The pooled values are ReLU outputs: +0, positive, +inf or NaN.  For such floats the IEEE order is the order of the bit
+// patterns as unsigned integers and every NaN pattern lies above +inf, so an unsigned integer max IS the NaN-propagating
+// float max of MaxPool2d (which NaN payload survives is the only freedom) -- 1 instruction instead of 4 per comparison.
+__device__ __forceinline__ float umaxf(float x, float y) {
+    const unsigned a = __float_as_uint(x), b = __float_as_uint(y);
+    return __uint_as_float(a > b ? a : b);
 }
 
 __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
@@ -59,13 +59,17 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 
     // ---- 1. input patch (rows cy0-1 .. cy0+10, cols cx0-1 .. cx0+34), zero outside the image
     const float* inn = a.in + (size_t)n * 3 * HW;
-    for (int idx = t; idx < 3 * PRW * PCL; idx += 256) {
+    constexpr int NP = (3 * PRW * PCL + 255) / 256;   // 6 patch elements per thread
+    float pv_[NP];
+    bool pok[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {   // all loads first, masks afterwards: a select on a load in flight would wait for it
+        const int idx = t + 256 * u;
         const int c = idx / (PRW * PCL), rem = idx - c * (PRW * PCL);
         const int pr = rem / PCL, pc = rem - pr * PCL;
         const int gy = cy0 - 1 + pr, gx = cx0 - 1 + pc;
-        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const float v = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
-        (&P[0][0][0])[idx] = ok ? v : 0.0f;
+        pok[u] = idx < 3 * PRW * PCL && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        pv_[u] = inn[pok[u] ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
     }
     // A operand of this lane: weights of channel m0 + lcol for k = 2kk + lrow (rows K..Kpad-1 of wT are zero)
     float af[KKS];
@@ -86,6 +90,9 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
         sc[r] = a.scale ? a.scale[ch] : 1.0f;
         sh[r] = a.shift ? a.shift[ch] : 0.0f;
     }
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+        if (t + 256 * u < 3 * PRW * PCL) (&P[0][0][0])[t + 256 * u] = pok[u] ? pv_[u] : 0.0f;
     __syncthreads();
 
     // ---- 2./3. conv on the MFMA, BN + ReLU, tile -> LDS
@@ -134,11 +141,15 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
             for (int y = 0; y < 6; ++y)
 #pragma unroll
                 for (int x = 0; x < 6; ++x) v[y][x] = Cc[ly + y][lx + x];
-            float M[5][5];
+            float hmx[5][6], M[5][5];   // separable: vertical pair max, then horizontal pair max
 #pragma unroll
             for (int y = 0; y < 5; ++y)
 #pragma unroll
-                for (int x = 0; x < 5; ++x) M[y][x] = max4_first(v[y][x], v[y][x + 1], v[y + 1][x], v[y + 1][x + 1]);
+                for (int x = 0; x < 6; ++x) hmx[y][x] = umaxf(v[y][x], v[y + 1][x]);
+#pragma unroll
+            for (int y = 0; y < 5; ++y)
+#pragma unroll
+                for (int x = 0; x < 5; ++x) M[y][x] = umaxf(hmx[y][x], hmx[y][x + 1]);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int mx = reflect1i(2 * o_w - 1 + j, Wm) - cx0;
-                        const float m = max4_first(Cc[my][mx], Cc[my][mx + 1], Cc[my + 1][mx], Cc[my + 1][mx + 1]);
+                        const float m = umaxf(umaxf(Cc[my][mx], Cc[my + 1][mx]), umaxf(Cc[my][mx + 1], Cc[my + 1][mx + 1]));
                         acc = fmaf(m, w3[i] * w3[j], acc);
                     }
                 }
