@@ -91,6 +91,13 @@ int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hin, int Win,
 int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, const float* scale, const float* shift, float* out,
                                  int N, int H, int W, int Cout, void* stream);
 
+/* The ResNet-50 stem in one kernel (model/resnet50.py:115-120, forward :157-160): conv7x7(3 -> Cout, stride 2, pad 3) +
+ * folded BatchNorm + ReLU + MaxPool2d(3, stride 2, pad 1).  in (N,3,H,W); wT / scale / shift = the packed weights of that
+ * convolution (K = 147 -> Kpad = 160 rows); out (N,Cout,Hp,Wp) with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
+ * Bit-identical to rfx_conv2d_f32(act = ReLU) followed by rfx_maxpool2d_f32(3, 2, 1).  Cout % 32 == 0. */
+int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, const float* scale, const float* shift, float* out,
+                                 int N, int H, int W, int Cout, void* stream);
+
 /* F.normalize(x, p=2, dim=1, eps=1e-12) on NCHW (quick_start/coarseAlignFeatMatch.py:106,124;
  * quick_start/align2images.py:87-88).  `in` is dense; element (n,c,p) of the result goes to
  * out[n*out_batch_stride + c*out_chan_stride + p] (0 = dense defaults C*HW / HW), which lets the coarse

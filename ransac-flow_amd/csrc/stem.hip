@@ -183,6 +183,142 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// ResNet-50 stem (model/resnet50.py:115-120, forward :157-160 as sliced by quick_start/coarseAlignFeatMatch.py:38-41):
+//     conv7x7(3 -> 64, stride 2, pad 3) -> BatchNorm (folded) -> ReLU -> MaxPool2d(3, stride 2, pad 1)
+// Same scheme: a workgroup owns 4 x 16 pooled outputs for 32 channels, computes the 9 x 33 conv outputs under them on
+// the MFMA from a 3 x 23 x 71 input patch in LDS (k = c*49 + kh*7 + kw, 147 padded to 148, same order and pairing as
+// the implicit-GEMM kernel -> bit-identical accumulators), keeps them in LDS after BN + ReLU and pools from there.
+// The stride-2 taps of 32 consecutive conv pixels would hit every second LDS word (2-way bank conflicts): the patch
+// rows are stored de-interleaved, [even columns | odd columns], so a lane's tap (kh, kw) sits at
+// parity(kw)*36 + px + kw/2 and consecutive pixels read consecutive words.
+namespace r50 {
+constexpr int TH = 4, TW = 16;
+constexpr int CR = 2 * TH + 1, CC = 2 * TW + 1;    // 9 x 33 conv outputs
+constexpr int PR = 2 * CR + 5, PCW = 2 * CC + 5;   // 23 x 71 input patch
+constexpr int PHALF = 36, PST = 2 * PHALF;         // de-interleaved row: 36 even + 36 odd columns
+constexpr int CST = CC + 1;                        // 34
+constexpr int NPX = CR * CC, NSUB = (NPX + 31) / 32;   // 297 -> 10 sub-tiles
+constexpr int KKS = 74;                            // 148 / 2
+constexpr int MCH = 32;
+__host__ __device__ constexpr int koff(int k) {    // patch offset of tap k = c*49 + kh*7 + kw
+    return k >= 147 ? 0 : (k / 49) * (PR * PST) + ((k % 49) / 7) * PST + (((k % 49) % 7) & 1) * PHALF + (((k % 49) % 7) >> 1);
+}
+}  // namespace r50
+
+struct Stem7Args {
+    const float* in; const float* wT; const float* scale; const float* shift; float* out;
+    int N, H, W, Cout, Mpad, Hc, Wc, Hp, Wp, tilesH, tilesW, chGroups;
+};
+
+__global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a) {
+    constexpr int TH = r50::TH, TW = r50::TW, CR = r50::CR, CC = r50::CC, PR = r50::PR, PCW = r50::PCW, PHALF = r50::PHALF,
+                  PST = r50::PST, CST = r50::CST, NPX = r50::NPX, NSUB = r50::NSUB, KKS = r50::KKS, MCH = r50::MCH;
+    using r50::koff;
+    __shared__ float P[3][PR][PST];
+    __shared__ float C[MCH][CR][CST];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    int bid = blockIdx.x;
+    const int cg = bid % a.chGroups; bid /= a.chGroups;
+    const int tw = bid % a.tilesW; bid /= a.tilesW;
+    const int th = bid % a.tilesH;
+    const int n = bid / a.tilesH;
+    const int oh0 = th * TH, ow0 = tw * TW;
+    const int cy0 = 2 * oh0 - 1, cx0 = 2 * ow0 - 1;          // first conv row / column under the tile
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
+    const int m0 = cg * MCH;
+    const size_t HW = (size_t)a.H * a.W;
+
+    // ---- input patch: all loads first (20 per thread), masks at store time
+    const float* inn = a.in + (size_t)n * 3 * HW;
+    constexpr int NE = 3 * PR * PCW, NP = (NE + 255) / 256;
+    float pv_[NP];
+    unsigned pok = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int idx = t + 256 * u;
+        const int c = idx / (PR * PCW), rem = idx - c * (PR * PCW);
+        const int pr = rem / PCW, pc = rem - pr * PCW;
+        const int gy = iy0 + pr, gx = ix0 + pc;
+        const bool ok = idx < NE && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        pok |= ok ? (1u << u) : 0u;
+        pv_[u] = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
+    }
+    float af[KKS];
+#pragma unroll
+    for (int kk = 0; kk < KKS; ++kk) af[kk] = a.wT[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = m0 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+        sc[r] = a.scale ? a.scale[ch] : 1.0f;
+        sh[r] = a.shift ? a.shift[ch] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int idx = t + 256 * u;
+        if (idx < NE) {
+            const int c = idx / (PR * PCW), rem = idx - c * (PR * PCW);
+            const int pr = rem / PCW, pc = rem - pr * PCW;
+            P[c][pr][(pc & 1) * PHALF + (pc >> 1)] = ((pok >> u) & 1u) ? pv_[u] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv on the MFMA, BN + ReLU -> LDS
+    const float* pf = &P[0][0][0];
+    for (int s = wave; s < NSUB; s += 4) {
+        const int p = s * 32 + lcol;
+        const bool pv = p < NPX;
+        const int pc = pv ? p : 0;
+        const int py = pc / CC, px = pc - py * CC;
+        const int pbase = 2 * py * PST + px;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KKS; ++kk) {
+            const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
+            float b = pf[pbase + off];
+            if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
+        }
+        if (pv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acc[r], sc[r], sh[r]);
+                v = v > 0.0f ? v : 0.0f;
+                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][px] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- MaxPool2d(3, stride 2, pad 1): -inf padding = positions outside the conv map are skipped; the values are ReLU
+    // outputs, so the unsigned-integer max is the NaN-propagating float max and 0 its identity (see umaxf above)
+    for (int o = t; o < MCH * TH * TW; o += 256) {
+        const int owl = o % TW, ohl = (o / TW) % TH, ch = o / (TW * TH);
+        const int oh = oh0 + ohl, ow = ow0 + owl;
+        if (oh >= a.Hp || ow >= a.Wp) continue;
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int gy = cy0 + 2 * ohl + i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int gx = cx0 + 2 * owl + j;
+                const bool ok = (unsigned)gy < (unsigned)a.Hc && (unsigned)gx < (unsigned)a.Wc;
+                const float v = C[ch][2 * ohl + i][2 * owl + j];
+                m = ok ? umaxf(m, v) : m;
+            }
+        }
+        a.out[(((size_t)n * a.Cout + m0 + ch) * a.Hp + oh) * a.Wp + ow] = m;
+    }
+}
+
 }  // namespace
 
 extern "C" int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, const float* scale, const float* shift,
@@ -197,6 +333,23 @@ extern "C" int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, co
     const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
     hipLaunchKernelGGL(stem_conv_maxblur_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, const float* scale, const float* shift,
+                                            float* out, int N, int H, int W, int Cout, void* stream) {
+    if (!in || !wT || !out || N <= 0 || H < 1 || W < 1 || Cout <= 0) return RFX_E_ARG;
+    if (Cout % r50::MCH != 0) return RFX_E_ARG;
+    Stem7Args a;
+    a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Mpad = (Cout + 127) / 128 * 128;
+    a.Hc = (H + 6 - 7) / 2 + 1; a.Wc = (W + 6 - 7) / 2 + 1;
+    a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
+    a.tilesH = (a.Hp + r50::TH - 1) / r50::TH; a.tilesW = (a.Wp + r50::TW - 1) / r50::TW; a.chGroups = Cout / r50::MCH;
+    const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL(stem7_conv_maxpool_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

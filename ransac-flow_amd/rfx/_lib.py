@@ -21,6 +21,7 @@ SIGNATURES = {
     "rfx_blurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_maxblurpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_stem_conv3x3_maxblur_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "rfx_stem_conv7x7_maxpool_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "rfx_l2norm_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_longlong, c_longlong, c_void_p]),
     "rfx_flow_head_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "rfx_resize_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),

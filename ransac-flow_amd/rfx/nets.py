@@ -38,8 +38,7 @@ class ResNet50Trunk:
                 self.blocks.append(blk)
 
     def __call__(self, x):
-        x = self.conv1(x)
-        x = ops.maxpool2d(x, 3, 2, 1)
+        x = ops.stem_conv7_maxpool(x, self.conv1)  # conv1 + BN + ReLU + MaxPool2d(3, 2, 1) in one kernel
         for blk in self.blocks:
             o = blk["c1"](x)
             o = blk["c2"](o)

@@ -146,6 +146,30 @@ def stem_conv_maxblur(x, plan):
     return out
 
 
+def stem_conv7_maxpool(x, plan):
+    """ResNet-50 stem: plan = ConvPlan of the 7x7 / stride 2 / pad 3 / ReLU convolution with 3 input channels; returns
+    maxpool2d(plan(x), 3, 2, 1) without materialising plan(x)."""
+    x = _dev(x, "stem input")
+    N, C, H, W = x.shape
+    if not (C == 3 and plan.Cin == 3 and plan.KH == 7 and plan.KW == 7 and plan.stride == 2 and plan.pad == 3
+            and plan.act == ACT_RELU and plan.Cout % 32 == 0):
+        raise ValueError("stem_conv7_maxpool: not a 7x7/s2/p3 ReLU convolution of a 3-channel image")
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((N, plan.Cout, Hp, Wp), dtype=torch.float32, device=x.device)
+    timer = ConvPlan.timer
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().rfx_stem_conv7x7_maxpool_f32(_p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
+                                                       plan.Cout, _stream()), "rfx_stem_conv7x7_maxpool_f32")
+    if timer is not None:
+        e1.record()
+        timer.append((257, 2.0 * N * Hc * Wc * plan.Cout * 147, e0, e1, (N, 3, H, W, plan.Cout, 7, 2),
+                      4.0 * (N * 3 * H * W + N * plan.Cout * Hp * Wp)))
+    return out
+
+
 def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):
     """F.normalize(x, dim=1) for (N,C,H,W) or (N,C,L).  With ``out`` (a float32 device tensor/view start) the
     result is scattered with the given strides (elements)."""

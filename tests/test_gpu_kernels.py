@@ -391,3 +391,22 @@ def test_fused_stem_equals_conv_then_maxblurpool(dev, shape):
     out = ops.stem_conv_maxblur(xd, plan)
     assert out.shape == ref.shape
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 37, 45), (3, 16, 16), (1, 7, 9), (1, 1, 1), (1, 130, 70)])
+def test_fused_resnet_stem_equals_conv_then_maxpool(dev, shape):
+    """rfx_stem_conv7x7_maxpool_f32 == rfx_conv2d_f32(7x7/2, ReLU) -> rfx_maxpool2d_f32(3, 2, 1), bit for bit."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + W + 1)
+    x = torch.randn(N, 3, H, W, generator=g)
+    if H > 5:
+        x[0, 2, 3, 5] = float("nan")
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    bn = dict(weight=1 + 0.3 * torch.randn(64, generator=g), bias=0.2 * torch.randn(64, generator=g),
+              running_mean=0.2 * torch.randn(64, generator=g), running_var=0.5 + torch.rand(64, generator=g))
+    plan = ops.ConvPlan(w, bn, 2, 3, ops.ACT_RELU, dev)
+    xd = x.to(dev)
+    ref = ops.maxpool2d(plan(xd), 3, 2, 1)
+    out = ops.stem_conv7_maxpool(xd, plan)
+    assert out.shape == ref.shape
+    assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
