@@ -234,18 +234,23 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
 
     // ---- input patch: all loads first (20 per thread), masks at store time
     const float* inn = a.in + (size_t)n * 3 * HW;
-    constexpr int NE = 3 * PR * PCW, NP = (NE + 255) / 256;
+    constexpr int NP = (3 * PR * PCW + 255) / 256;
     float pv_[NP];
     unsigned pok = 0;
+    // element t + 256u of the 3 x 23 x 71 patch: (c, pr, pc) advanced incrementally (256 = 3*71 + 43), no divisions
+    const int c_0 = t / (PR * PCW), rem_0 = t - c_0 * (PR * PCW), pr_0 = rem_0 / PCW, pc_0 = rem_0 - pr_0 * PCW;
+    {
+        int c = c_0, pr = pr_0, pc = pc_0;
 #pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int idx = t + 256 * u;
-        const int c = idx / (PR * PCW), rem = idx - c * (PR * PCW);
-        const int pr = rem / PCW, pc = rem - pr * PCW;
-        const int gy = iy0 + pr, gx = ix0 + pc;
-        const bool ok = idx < NE && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        pok |= ok ? (1u << u) : 0u;
-        pv_[u] = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
+        for (int u = 0; u < NP; ++u) {
+            const int gy = iy0 + pr, gx = ix0 + pc;
+            const bool ok = c < 3 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            pok |= ok ? (1u << u) : 0u;
+            pv_[u] = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
+            pc += 256 % PCW; pr += 256 / PCW;
+            if (pc >= PCW) { pc -= PCW; ++pr; }
+            if (pr >= PR) { pr -= PR; ++c; }
+        }
     }
     float af[KKS];
 #pragma unroll
@@ -257,13 +262,14 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
         sc[r] = a.scale ? a.scale[ch] : 1.0f;
         sh[r] = a.shift ? a.shift[ch] : 0.0f;
     }
+    {
+        int c = c_0, pr = pr_0, pc = pc_0;
 #pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int idx = t + 256 * u;
-        if (idx < NE) {
-            const int c = idx / (PR * PCW), rem = idx - c * (PR * PCW);
-            const int pr = rem / PCW, pc = rem - pr * PCW;
-            P[c][pr][(pc & 1) * PHALF + (pc >> 1)] = ((pok >> u) & 1u) ? pv_[u] : 0.0f;
+        for (int u = 0; u < NP; ++u) {
+            if (c < 3) P[c][pr][(pc & 1) * PHALF + (pc >> 1)] = ((pok >> u) & 1u) ? pv_[u] : 0.0f;
+            pc += 256 % PCW; pr += 256 / PCW;
+            if (pc >= PCW) { pc -= PCW; ++pr; }
+            if (pr >= PR) { pr -= PR; ++c; }
         }
     }
     __syncthreads();
