@@ -209,44 +209,38 @@ __host__ __device__ constexpr int koff(int k) {    // patch offset of tap k = c*
 
 struct Stem7Args {
     const float* in; const float* wT; const float* scale; const float* shift; float* out;
-    int N, H, W, Cout, Mpad, Hc, Wc, Hp, Wp, tilesH, tilesW, chGroups, segsW, tilesPerWg;
+    int N, H, W, Cout, Mpad, Hc, Wc, Hp, Wp, tilesH, tilesW, chGroups;
 };
 
 __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a) {
     constexpr int TH = r50::TH, TW = r50::TW, CR = r50::CR, CC = r50::CC, PR = r50::PR, PCW = r50::PCW, PHALF = r50::PHALF,
                   PST = r50::PST, CST = r50::CST, NPX = r50::NPX, NSUB = r50::NSUB, KKS = r50::KKS, MCH = r50::MCH;
     using r50::koff;
-    __shared__ float P[2][3][PR][PST];   // input patch, double buffered over the tiles of this workgroup
+    __shared__ float P[3][PR][PST];
     __shared__ float C[MCH][CR][CST];
-    __shared__ float s_sc[MCH], s_sh[MCH];   // folded BatchNorm of this channel group (registers are needed for the weights)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = lane >> 5, lcol = lane & 31;
-    // A workgroup walks `tilesPerWg` consecutive tiles of one tile row: the 74 weight registers, scale / shift and all
-    // index setup are paid once, and the input patch of tile i+1 is fetched while tile i is on the MFMA.
     int bid = blockIdx.x;
     const int cg = bid % a.chGroups; bid /= a.chGroups;
-    const int seg = bid % a.segsW; bid /= a.segsW;
+    const int tw = bid % a.tilesW; bid /= a.tilesW;
     const int th = bid % a.tilesH;
     const int n = bid / a.tilesH;
-    const int tw_begin = seg * a.tilesPerWg;
-    const int tw_end = tw_begin + a.tilesPerWg < a.tilesW ? tw_begin + a.tilesPerWg : a.tilesW;
-    const int oh0 = th * TH;
-    const int cy0 = 2 * oh0 - 1;                               // first conv row under the tile row
-    const int iy0 = 2 * cy0 - 3;                               // first input row of the patches
+    const int oh0 = th * TH, ow0 = tw * TW;
+    const int cy0 = 2 * oh0 - 1, cx0 = 2 * ow0 - 1;          // first conv row / column under the tile
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
     const int m0 = cg * MCH;
     const size_t HW = (size_t)a.H * a.W;
-    const float* inn = a.in + (size_t)n * 3 * HW;
 
-    // element t + 256u of the 3 x 23 x 71 patch: (c, pr, pc) advanced incrementally (256 = 3*71 + 43), no divisions
+    // ---- input patch: all loads first (20 per thread), masks at store time
+    const float* inn = a.in + (size_t)n * 3 * HW;
     constexpr int NP = (3 * PR * PCW + 255) / 256;
     float pv_[NP];
     unsigned pok = 0;
+    // element t + 256u of the 3 x 23 x 71 patch: (c, pr, pc) advanced incrementally (256 = 3*71 + 43), no divisions
     const int c_0 = t / (PR * PCW), rem_0 = t - c_0 * (PR * PCW), pr_0 = rem_0 / PCW, pc_0 = rem_0 - pr_0 * PCW;
-    auto load_patch = [&](int tw) {   // all loads first, masks at store time
-        const int ix0 = 2 * (2 * tw * TW - 1) - 3;
+    {
         int c = c_0, pr = pr_0, pc = pc_0;
-        pok = 0;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int gy = iy0 + pr, gx = ix0 + pc;
@@ -257,85 +251,77 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
             if (pc >= PCW) { pc -= PCW; ++pr; }
             if (pr >= PR) { pr -= PR; ++c; }
         }
-    };
-    auto store_patch = [&](int buf) {
+    }
+    float af[KKS];
+#pragma unroll
+    for (int kk = 0; kk < KKS; ++kk) af[kk] = a.wT[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = m0 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+        sc[r] = a.scale ? a.scale[ch] : 1.0f;
+        sh[r] = a.shift ? a.shift[ch] : 0.0f;
+    }
+    {
         int c = c_0, pr = pr_0, pc = pc_0;
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
-            if (c < 3) P[buf][c][pr][(pc & 1) * PHALF + (pc >> 1)] = ((pok >> u) & 1u) ? pv_[u] : 0.0f;
+            if (c < 3) P[c][pr][(pc & 1) * PHALF + (pc >> 1)] = ((pok >> u) & 1u) ? pv_[u] : 0.0f;
             pc += 256 % PCW; pr += 256 / PCW;
             if (pc >= PCW) { pc -= PCW; ++pr; }
             if (pr >= PR) { pr -= PR; ++c; }
         }
-    };
-
-    load_patch(tw_begin);
-    float af[KKS];
-#pragma unroll
-    for (int kk = 0; kk < KKS; ++kk) af[kk] = a.wT[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
-    if (t < MCH) {
-        s_sc[t] = a.scale ? a.scale[m0 + t] : 1.0f;
-        s_sh[t] = a.shift ? a.shift[m0 + t] : 0.0f;
     }
-    store_patch(0);
+    __syncthreads();
 
-    for (int tw = tw_begin, it = 0; tw < tw_end; ++tw, ++it) {
-        const int ow0 = tw * TW, cx0 = 2 * ow0 - 1;
-        __syncthreads();   // patch `it` is complete; every wavefront is done pooling the previous tile out of C
-        if (tw + 1 < tw_end) load_patch(tw + 1);   // in flight during the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- conv on the MFMA, BN + ReLU -> LDS
-        const float* pf = &P[it & 1][0][0][0];
-        for (int s = wave; s < NSUB; s += 4) {
-            const int p = s * 32 + lcol;
-            const bool pv = p < NPX;
-            const int pc = pv ? p : 0;
-            const int py = pc / CC, px = pc - py * CC;
-            const int pbase = 2 * py * PST + px;
-            f32x16 acc;
+    // ---- conv on the MFMA, BN + ReLU -> LDS
+    const float* pf = &P[0][0][0];
+    for (int s = wave; s < NSUB; s += 4) {
+        const int p = s * 32 + lcol;
+        const bool pv = p < NPX;
+        const int pc = pv ? p : 0;
+        const int py = pc / CC, px = pc - py * CC;
+        const int pbase = 2 * py * PST + px;
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < KKS; ++kk) {
-                const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
-                float b = pf[pbase + off];
-                if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
-            }
-            if (pv) {
+        for (int kk = 0; kk < KKS; ++kk) {
+            const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
+            float b = pf[pbase + off];
+            if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
+        }
+        if (pv) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = 4 * lrow + (r & 3) + 8 * (r >> 2);
-                    float v = fmaf(acc[r], s_sc[ch], s_sh[ch]);
-                    v = v > 0.0f ? v : 0.0f;
-                    C[ch][py][px] = v;
-                }
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acc[r], sc[r], sh[r]);
+                v = v > 0.0f ? v : 0.0f;
+                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][px] = v;
             }
         }
-        __syncthreads();
+    }
+    __syncthreads();
 
-        // ---- MaxPool2d(3, stride 2, pad 1): -inf padding = positions outside the conv map are skipped; the values are
-        // ReLU outputs, so the unsigned-integer max is the NaN-propagating float max and 0 its identity (see umaxf)
-        for (int o = t; o < MCH * TH * TW; o += 256) {
-            const int owl = o % TW, ohl = (o / TW) % TH, ch = o / (TW * TH);
-            const int oh = oh0 + ohl, ow = ow0 + owl;
-            if (oh >= a.Hp || ow >= a.Wp) continue;
-            float m = 0.0f;
+    // ---- MaxPool2d(3, stride 2, pad 1): -inf padding = positions outside the conv map are skipped; the values are ReLU
+    // outputs, so the unsigned-integer max is the NaN-propagating float max and 0 its identity (see umaxf above)
+    for (int o = t; o < MCH * TH * TW; o += 256) {
+        const int owl = o % TW, ohl = (o / TW) % TH, ch = o / (TW * TH);
+        const int oh = oh0 + ohl, ow = ow0 + owl;
+        if (oh >= a.Hp || ow >= a.Wp) continue;
+        float m = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int gy = cy0 + 2 * ohl + i;
+        for (int i = 0; i < 3; ++i) {
+            const int gy = cy0 + 2 * ohl + i;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int gx = cx0 + 2 * owl + j;
-                    const bool ok = (unsigned)gy < (unsigned)a.Hc && (unsigned)gx < (unsigned)a.Wc;
-                    const float v = C[ch][2 * ohl + i][2 * owl + j];
-                    m = ok ? umaxf(m, v) : m;
-                }
+            for (int j = 0; j < 3; ++j) {
+                const int gx = cx0 + 2 * owl + j;
+                const bool ok = (unsigned)gy < (unsigned)a.Hc && (unsigned)gx < (unsigned)a.Wc;
+                const float v = C[ch][2 * ohl + i][2 * owl + j];
+                m = ok ? umaxf(m, v) : m;
             }
-            a.out[(((size_t)n * a.Cout + m0 + ch) * a.Hp + oh) * a.Wp + ow] = m;
         }
-        if (tw + 1 < tw_end) store_patch((it + 1) & 1);   // that buffer was last read two barriers ago
+        a.out[(((size_t)n * a.Cout + m0 + ch) * a.Hp + oh) * a.Wp + ow] = m;
     }
 }
 
@@ -367,12 +353,7 @@ extern "C" int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, co
     a.Hc = (H + 6 - 7) / 2 + 1; a.Wc = (W + 6 - 7) / 2 + 1;
     a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
     a.tilesH = (a.Hp + r50::TH - 1) / r50::TH; a.tilesW = (a.Wp + r50::TW - 1) / r50::TW; a.chGroups = Cout / r50::MCH;
-    // tiles of a row per workgroup: as many as keeps >= ~4 workgroups per slot (512 slots) in the launch
-    a.tilesPerWg = a.tilesW;
-    while (a.tilesPerWg > 1 && (long long)N * a.tilesH * a.chGroups * ((a.tilesW + a.tilesPerWg - 1) / a.tilesPerWg) < 2048)
-        a.tilesPerWg = (a.tilesPerWg + 1) / 2;
-    a.segsW = (a.tilesW + a.tilesPerWg - 1) / a.tilesPerWg;
-    const long long nwg = (long long)N * a.tilesH * a.segsW * a.chGroups;
+    const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
     hipLaunchKernelGGL(stem7_conv_maxpool_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
     RFX_LAUNCH_CHECK();
