@@ -285,31 +285,12 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        // B operands are read one chunk of 8 k-pairs ahead of the MFMAs that consume them (register double buffer)
-        constexpr int CHK = 8, NCH = (KKS + CHK - 1) / CHK;
-        float bq[2][CHK];
-        auto read_chunk = [&](int c, int slot) {
 #pragma unroll
-            for (int e = 0; e < CHK; ++e) {
-                const int kk = c * CHK + e;
-                if (kk < KKS) {
-                    const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
-                    float b = pf[pbase + off];
-                    if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
-                    bq[slot][e] = b;
-                }
-            }
-        };
-        read_chunk(0, 0);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) read_chunk(c + 1, (c + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < CHK; ++e)
-                if (c * CHK + e < KKS)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c * CHK + e], bq[c & 1][e], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kk = 0; kk < KKS; ++kk) {
+            const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
+            float b = pf[pbase + off];
+            if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
         }
         if (pv) {
 #pragma unroll
