@@ -30,7 +30,7 @@ for k, e in out.items():
     if k in dur:
         e["pmc_run_launches"] = dur[k][0]; e["pmc_run_total_ns"] = dur[k][1]
 json.dump(out, open("gpurun_out/pmc_summary.json", "w"), indent=1)
-keep = {k: v for k, v in out.items() if any(s in k for s in ("conv2d", "conv3x3", "corr7", "mnn_tile", "l2norm", "maxpool", "maxblur", "lanczos"))}
+keep = {k: v for k, v in out.items() if any(s in k for s in ("conv2d", "conv3x3", "stem", "corr7", "mnn_tile", "l2norm", "maxpool", "maxblur", "lanczos"))}
 for k, v in keep.items():
     print(k[:80], {c: v[c] for c in v if not c.startswith("launches") and not c.startswith("pmc_run")})
 PY
