@@ -70,6 +70,16 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
  * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least). */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
 
+/* Bottleneck tail (model/resnet50.py:71-79, forward :93-103: conv2 3x3 -> bn2 -> relu -> conv3 1x1 -> bn3 -> += residual
+ * -> relu) as ONE kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual).  The workgroup that computed a
+ * 128-pixel tile of ALL Cmid channels of the 3x3 convolution keeps it in LDS and multiplies it with the expansion weights,
+ * so the Cmid-channel map never goes to HBM.  in (N,Cin,H,W); wT2/scale2/shift2 = packed weights / folded BN of the 3x3
+ * (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); wT3 ([Cmid rows][Cexp]) / scale3 / shift3 of the 1x1 (Cexp % 128 == 0);
+ * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.  Bit-identical to the two rfx_conv2d_f32 calls. */
+int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
+                            const float* wT3, const float* scale3, const float* shift3, const float* residual, int act3,
+                            float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream);
+
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;
  * model/model.py:71: k=2,s=1,p=0).  Hout = (Hin+2p-k)/s+1. */
 int rfx_maxpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int k, int stride,

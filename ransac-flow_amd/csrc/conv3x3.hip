@@ -38,6 +38,9 @@ struct C3Args {
     const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
     int N, Cin, H, W, Cout, act, Mpad;
     int tilesM, tilesH, tilesW;
+    // FUSE: the 1x1 expansion that follows (Bottleneck conv3 + bn3 + residual + ReLU, model/resnet50.py:77-79,99-103)
+    const float* wT3; const float* scale3; const float* shift3;
+    int Cexp, Mpad3, act3;
 #ifdef RFX_TRACE
     long long* trace;
 #endif
@@ -49,7 +52,13 @@ extern "C" long long* rfx_debug_trace_ptr();
 #define RFX_STAMP(i)
 #endif
 
-template <int TM, int PTC>
+// FUSE = true: the workgroup's tile holds ALL channels of the 3x3 convolution (Cout == 64*TM); instead of going to HBM
+// the tile (after bn + ReLU) becomes, in LDS, the B operand of the 1x1 expansion that follows it in a Bottleneck, and
+// the workgroup writes relu(bn3(conv3(.)) + residual) for its 128 pixels and all Cexp channels.  The 64/128-channel
+// intermediate never touches HBM, the expansion's launch, prologue and B-operand staging disappear, and its residual /
+// output traffic overlaps the MFMA-bound 3x3 main loops of the neighbouring workgroups.  k order and pairing of the
+// expansion are those of conv.hip: bit-identical to the two separate kernels.
+template <int TM, int PTC, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     using G = Patch<PTC>;
     constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
@@ -58,8 +67,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     constexpr int BM = 64 * TM;
     constexpr int A_MG = BM / 4;          // groups of 4 consecutive output channels
     constexpr int A_THREADS = 6 * A_MG;   // 2 parities x 3 chunk-triples
-    __shared__ __attribute__((aligned(16))) float As[2][BM][KK];
-    __shared__ __attribute__((aligned(16))) float Bs[CH][PR][BS];
+    constexpr int AS_F = 2 * BM * KK, BS_F = CH * PR * BS, T2_F = FUSE ? BM * 128 : 0;
+    constexpr int SMEM_F = AS_F + BS_F > T2_F ? AS_F + BS_F : T2_F;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_F];   // FUSE: the main-loop buffers are reused for the mid tile
+    float (*As)[BM][KK] = reinterpret_cast<float (*)[BM][KK]>(smem);
+    float (*Bs)[PR][BS] = reinterpret_cast<float (*)[PR][BS]>(smem + AS_F);
     __shared__ float s_scale[BM], s_shift[BM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -204,14 +216,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     // ---- epilogue (conv_epilogue.h) ----
     size_t pix_off[2];
     bool pix_ok[2];
+    const int Cfinal = FUSE ? a.Cexp : a.Cout;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int oh = oh0 + wn * 2 * RH + j * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
         pix_ok[j] = oh < a.H && ow < a.W;
-        pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pix_ok[j] ? oh : 0) * a.W + (pix_ok[j] ? ow : 0);
+        pix_off[j] = (size_t)n * Cfinal * HW + (size_t)(pix_ok[j] ? oh : 0) * a.W + (pix_ok[j] ? ow : 0);
     }
-    const bool full = m0 + BM <= a.Cout;
-    conv_epilogue<TM, 2, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+    if constexpr (!FUSE) {
+        const bool full = m0 + BM <= a.Cout;
+        conv_epilogue<TM, 2, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+    } else {
+        // ---- mid tile -> LDS: T2[channel][pixel], pixel = MFMA column numbering (wn*2 + j)*32 + lcol
+        float* T2 = smem;   // every wavefront is past the last barrier of the main loop: As / Bs are free
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                    float v = fmaf(acc[i][j][r], s_scale[ch], s_shift[ch]);
+                    if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
+                    T2[ch * 128 + (wn * 2 + j) * 32 + lcol] = v;
+                }
+        __syncthreads();
+        // ---- 1x1 expansion: out[Cexp x 128 px] = W3[Cexp x BM] * T2, 128 output channels per pass, waves 2 x 2
+        const float* t2col = T2 + lrow * 128 + wn * 64 + lcol;               // + 2kk*128 (+ 32 for the second sub-tile)
+        for (int mp = 0; mp < a.Cexp; mp += 128) {
+            const float* wrow = a.wT3 + (size_t)lrow * a.Mpad3 + mp + wm * 64 + lcol;   // + 2kk*Mpad3 (+ 32)
+            f32x16 acc2[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
+            constexpr int CK = 8, NCK = (BM / 2) / CK;   // weights are fetched one chunk of 8 k-pairs ahead (L2 -> registers)
+            float wq[2][CK][2];
+            auto load_w = [&](int c, int slot) {
+#pragma unroll
+                for (int e = 0; e < CK; ++e) {
+                    const float* w = wrow + (size_t)(2 * (c * CK + e)) * a.Mpad3;
+                    wq[slot][e][0] = w[0];
+                    wq[slot][e][1] = w[32];
+                }
+            };
+            load_w(0, 0);
+#pragma unroll
+            for (int c = 0; c < NCK; ++c) {
+                if (c + 1 < NCK) load_w(c + 1, (c + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < CK; ++e) {
+                    const int kk = c * CK + e;
+                    const float b0 = t2col[2 * kk * 128], b1 = t2col[2 * kk * 128 + 32];
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][0], b0, acc2[0][0], 0, 0, 0);
+                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][0], b1, acc2[0][1], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][1], b0, acc2[1][0], 0, 0, 0);
+                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][1], b1, acc2[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // scale3 / shift3 are read straight from global memory (L1 hits): conv_epilogue only indexes the pointers
+            conv_epilogue<2, 2, true>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
+                                      pix_ok, true);
+        }
+    }
 #ifdef RFX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RFX_STAMP(3);
@@ -232,14 +303,14 @@ int rfx_conv3x3_patch_cols(int H, int W) {
     return best;
 }
 
-template <int TM, int PTC>
+template <int TM, int PTC, bool FUSE = false>
 static int launch_direct(C3Args& a, hipStream_t st) {
     using G = Patch<PTC>;
     a.tilesH = (a.H + G::PT_R - 1) / G::PT_R;
     a.tilesW = (a.W + G::PT_C - 1) / G::PT_C;
     const long long nwg = (long long)a.tilesM * a.N * a.tilesH * a.tilesW;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -252,6 +323,7 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
     C3Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
+    a.wT3 = a.scale3 = a.shift3 = nullptr; a.Cexp = a.Mpad3 = a.act3 = 0;
 #ifdef RFX_TRACE
     a.trace = rfx_debug_trace_ptr();
 #endif
@@ -265,4 +337,33 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
     if (patch_cols == 16) return launch_direct<1, 16>(a, st);
     if (patch_cols == 8) return launch_direct<1, 8>(a, st);
     return launch_direct<1, 4>(a, st);
+}
+
+// Bottleneck tail in one kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual)  (model/resnet50.py:71-79,93-103).
+// The 3x3 convolution must be direct-eligible (stride 1, pad 1, Cin % 8 == 0) with Cmid in {64, 128} so that one workgroup
+// tile holds all of its channels; Cexp % 128 == 0.
+extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
+                                       const float* wT3, const float* scale3, const float* shift3, const float* residual,
+                                       int act3, float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream) {
+    if (!in || !wT2 || !wT3 || !scale3 || !shift3 || !out || N <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
+    if (Cin <= 0 || Cin % 8 != 0 || (Cmid != 64 && Cmid != 128) || Cexp <= 0 || Cexp % 128 != 0) return RFX_E_ARG;
+    if (act2 == RFX_ACT_SIGMOID || act3 == RFX_ACT_SIGMOID) return RFX_E_ARG;
+    C3Args a;
+    a.in = in; a.wT = wT2; a.scale = scale2; a.shift = shift2; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cmid; a.act = act2; a.Mpad = 128;
+    a.wT3 = wT3; a.scale3 = scale3; a.shift3 = shift3; a.Cexp = Cexp; a.Mpad3 = Cexp; a.act3 = act3;
+#ifdef RFX_TRACE
+    a.trace = rfx_debug_trace_ptr();
+#endif
+    a.tilesM = 1;
+    hipStream_t st = rfx_stream(stream);
+    const int pc = rfx_conv3x3_patch_cols(H, W);
+    if (Cmid == 128) {
+        if (pc == 16) return launch_direct<2, 16, true>(a, st);
+        if (pc == 8) return launch_direct<2, 8, true>(a, st);
+        return launch_direct<2, 4, true>(a, st);
+    }
+    if (pc == 16) return launch_direct<1, 16, true>(a, st);
+    if (pc == 8) return launch_direct<1, 8, true>(a, st);
+    return launch_direct<1, 4, true>(a, st);
 }

@@ -41,9 +41,12 @@ class ResNet50Trunk:
         x = ops.stem_conv7_maxpool(x, self.conv1)  # conv1 + BN + ReLU + MaxPool2d(3, 2, 1) in one kernel
         for blk in self.blocks:
             o = blk["c1"](x)
-            o = blk["c2"](o)
             r = blk["ds"](x) if blk["ds"] is not None else x
-            x = blk["c3"](o, residual=r)  # relu(bn3(conv3(o)) + r)
+            if ops.bottleneck_tail_eligible(blk["c2"], blk["c3"]):
+                x = ops.bottleneck_tail(o, blk["c2"], blk["c3"], residual=r)   # conv2 + conv3 in one kernel
+            else:
+                o = blk["c2"](o)
+                x = blk["c3"](o, residual=r)  # relu(bn3(conv3(o)) + r)
         return x
 
 

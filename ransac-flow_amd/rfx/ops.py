@@ -5,6 +5,7 @@ live on a HIP device, passes ``data_ptr()`` / sizes / ``torch.cuda.current_strea
 and returns freshly allocated output tensors.  No op has a CPU or eager-PyTorch fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -93,6 +94,41 @@ class ConvPlan:
             tm.append((lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo), flops, e0, e1,
                        (N, self.Cin, H, W, self.Cout, self.KH, self.stride), nbytes))
         return out
+
+
+def bottleneck_tail_eligible(plan2, plan3):
+    """Can conv2 (3x3) + conv3 (1x1 expansion) of a Bottleneck run as one kernel (rfx_conv3x3_conv1x1_f32)?"""
+    return (plan2.KH == 3 and plan2.KW == 3 and plan2.stride == 1 and plan2.pad == 1 and plan2.Cin % 8 == 0
+            and plan2.Cout in (64, 128) and plan2.act in (ACT_NONE, ACT_RELU) and plan3.KH == 1 and plan3.KW == 1
+            and plan3.stride == 1 and plan3.pad == 0 and plan3.Cin == plan2.Cout and plan3.Cout % 128 == 0
+            and plan3.act in (ACT_NONE, ACT_RELU) and plan3.scale is not None
+            and os.environ.get("RFX_FUSE_BOTTLENECK", "1") != "0")
+
+
+def bottleneck_tail(x, plan2, plan3, residual=None):
+    """plan3(plan2(x), residual) in one kernel: the plan2.Cout-channel intermediate stays in LDS."""
+    x = _dev(x, "bottleneck input")
+    N, C, H, W = x.shape
+    if C != plan2.Cin:
+        raise ValueError("conv expects %d input channels, got %d" % (plan2.Cin, C))
+    res = _dev(residual, "residual") if residual is not None else None
+    out = torch.empty((N, plan3.Cout, H, W), dtype=torch.float32, device=x.device)
+    if res is not None and res.shape != out.shape:
+        raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
+    tm = ConvPlan.timer
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(_lib.load().rfx_conv3x3_conv1x1_f32(_p(x), _p(plan2.wT), _p(plan2.scale), _p(plan2.shift), plan2.act,
+                                                  _p(plan3.wT), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
+                                                  _p(out), N, C, H, W, plan2.Cout, plan3.Cout, _stream()),
+               "rfx_conv3x3_conv1x1_f32")
+    if tm is not None:
+        e1.record()
+        flops = 2.0 * N * H * W * (plan2.Cout * plan2.Cin * 9 + plan3.Cout * plan3.Cin)
+        nbytes = 4.0 * N * H * W * (C + plan3.Cout * (2 if res is not None else 1))
+        tm.append((512 | (1 if plan2.Cout == 64 else 0), flops, e0, e1, (N, C, H, W, plan3.Cout, 3, 1), nbytes))
+    return out
 
 
 def maxpool2d(x, k, stride, pad=0):

@@ -410,3 +410,29 @@ def test_fused_resnet_stem_equals_conv_then_maxpool(dev, shape):
     out = ops.stem_conv7_maxpool(xd, plan)
     assert out.shape == ref.shape
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+
+
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cmid, Cexp, residual
+    (2, 64, 30, 40, 64, 256, True),       # layer1-like, 16x8 patch
+    (1, 64, 25, 33, 64, 256, True),       # 32x4 patch, ragged
+    (3, 128, 19, 21, 128, 512, True),     # layer2-like, 8x16 patch, ragged
+    (1, 64, 16, 48, 64, 128, False),      # no residual, single pass
+    (1, 8, 5, 3, 128, 384, True),         # one K step of the 3x3, three passes of the 1x1
+])
+def test_fused_bottleneck_tail_equals_two_convs(dev, case):
+    """rfx_conv3x3_conv1x1_f32 == rfx_conv2d_f32(3x3) -> rfx_conv2d_f32(1x1 + residual), bit for bit."""
+    N, Cin, H, W, Cmid, Cexp, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    def bn(c):
+        return dict(weight=1 + 0.3 * torch.randn(c, generator=g), bias=0.2 * torch.randn(c, generator=g),
+                    running_mean=0.2 * torch.randn(c, generator=g), running_var=0.5 + torch.rand(c, generator=g))
+    p2 = ops.ConvPlan(torch.randn(Cmid, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, bn(Cmid), 1, 1, ops.ACT_RELU, dev)
+    p3 = ops.ConvPlan(torch.randn(Cexp, Cmid, 1, 1, generator=g) / Cmid ** 0.5, bn(Cexp), 1, 0, ops.ACT_RELU, dev)
+    assert ops.bottleneck_tail_eligible(p2, p3)
+    xd = x.to(dev)
+    r = torch.randn(N, Cexp, H, W, generator=g).to(dev) if with_res else None
+    ref = p3(p2(xd), residual=r)
+    out = ops.bottleneck_tail(xd, p2, p3, residual=r)
+    assert out.shape == ref.shape and torch.equal(out, ref)
