@@ -252,6 +252,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
+            // the residual values of this pass are fetched now: their latency hides behind the MFMAs below and the
+            // epilogue is left with arithmetic and stores (the main-loop registers are dead here)
+            float rpre[4][16];
+            if (a.res) conv_residual_prefetch<2, 2>(rpre, a.res, HW, mp, wm, lrow, pix_off);
             constexpr int CK = 8, NCK = (BM / 2) / CK;   // weights are fetched one chunk of 8 k-pairs ahead (L2 -> registers)
             float wq[2][CK][2];
             auto load_w = [&](int c, int slot) {
@@ -279,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // scale3 / shift3 are read straight from global memory (L1 hits): conv_epilogue only indexes the pointers
-            conv_epilogue<2, 2, true>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
-                                      pix_ok, true);
+            conv_epilogue<2, 2, true, true>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow,
+                                            pix_off, pix_ok, true, rpre);
         }
     }
 #ifdef RFX_TRACE

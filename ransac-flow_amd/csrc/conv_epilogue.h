@@ -17,11 +17,25 @@
 
 // pix_off[j]: element offset of this lane's pixel of sub-tile j inside channel plane 0 of its image
 //             (n*Cout*HWo + oh*Wout + ow); pix_ok[j]: that pixel exists.
-template <int TM, int TN, bool LEAN = false>
+// Residual values of a whole wavefront tile, fetched ahead of time (PRE): issued before a K loop that is long enough to
+// hide their latency, they leave the epilogue with arithmetic and stores only.  Costs TM*TN*16 registers.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_residual_prefetch(float (&pre)[TM * TN][16], const float* __restrict__ resp, size_t HWo,
+                                                       int m0, int wm, int lrow, const size_t (&pix_off)[TN]) {
+#pragma unroll
+    for (int s = 0; s < TM * TN; ++s) {
+        const size_t base = pix_off[s % TN] + (size_t)(m0 + (wm * TM + s / TN) * 32 + 4 * lrow) * HWo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre[s][r] = resp[base + (size_t)((r & 3) + 8 * (r >> 2)) * HWo];
+    }
+}
+
+template <int TM, int TN, bool LEAN = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const float* s_scale, const float* s_shift,
                                               const float* __restrict__ resp, float* __restrict__ outp, int act,
                                               int Cout, size_t HWo, int m0, int wm, int lrow,
-                                              const size_t (&pix_off)[TN], const bool (&pix_ok)[TN], bool m_full) {
+                                              const size_t (&pix_off)[TN], const bool (&pix_ok)[TN], bool m_full,
+                                              const float (*pre)[16] = nullptr) {
     const bool has_res = resp != nullptr;
     if (m_full && act != RFX_ACT_SIGMOID) {
         const bool relu = act == RFX_ACT_RELU;
@@ -30,7 +44,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
         // residual values: sub-tile s+1 is in flight while s is finished and stored (LEAN: register-tight kernels
         // fetch them just in time instead)
         float rv[2][16];
-        if (has_res && !LEAN) {
+        if (has_res && !LEAN && !PRE) {
             const size_t b0 = sub_base(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[0][r] = resp[b0 + (size_t)((r & 3) + 8 * (r >> 2)) * HWo];
@@ -47,12 +61,12 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                     sh[r] = s_shift[ml0 + (r & 3) + 8 * (r >> 2)];
                 }
             }
-            if (has_res && LEAN) {
+            if (has_res && LEAN && !PRE) {
                 const size_t bc = sub_base(s);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[s & 1][r] = resp[bc + (size_t)((r & 3) + 8 * (r >> 2)) * HWo];
             }
-            if (has_res && !LEAN && s + 1 < NS) {
+            if (has_res && !LEAN && !PRE && s + 1 < NS) {
                 const size_t bn = sub_base(s + 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) rv[(s + 1) & 1][r] = resp[bn + (size_t)((r & 3) + 8 * (r >> 2)) * HWo];
@@ -63,7 +77,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
             for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[i][j][r], sc[r], sh[r]);
             if (has_res) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] += rv[s & 1][r];
+                for (int r = 0; r < 16; ++r) v[r] += PRE ? pre[s][r] : rv[s & 1][r];
             }
             if (relu) {
 #pragma unroll
