@@ -252,12 +252,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
-            // the residual values of this pass are fetched now: their latency hides behind the MFMAs below and the
-            // epilogue is left with arithmetic and stores (the main-loop registers are dead here)
-            float rpre[4][16];
-            if (a.res) conv_residual_prefetch<2, 2>(rpre, a.res, HW, mp, wm, lrow, pix_off);
-            constexpr int CK = 8, NCK = (BM / 2) / CK;   // weights are fetched one chunk of 8 k-pairs ahead (L2 -> registers)
-            float wq[2][CK][2];
+            // weights go L2 -> registers, two chunks of 8 k-pairs ahead of the MFMAs that use them (an L2 round trip under
+            // load is longer than the 32 MFMAs of one chunk)
+            constexpr int CK = 8, NCK = (BM / 2) / CK;
+            float wq[3][CK][2];
             auto load_w = [&](int c, int slot) {
 #pragma unroll
                 for (int e = 0; e < CK; ++e) {
@@ -267,24 +265,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 }
             };
             load_w(0, 0);
+            if (NCK > 1) load_w(1, 1);
 #pragma unroll
             for (int c = 0; c < NCK; ++c) {
-                if (c + 1 < NCK) load_w(c + 1, (c + 1) & 1);
+                if (c + 2 < NCK) load_w(c + 2, (c + 2) % 3);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < CK; ++e) {
                     const int kk = c * CK + e;
                     const float b0 = t2col[2 * kk * 128], b1 = t2col[2 * kk * 128 + 32];
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][0], b0, acc2[0][0], 0, 0, 0);
-                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][0], b1, acc2[0][1], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][1], b0, acc2[1][0], 0, 0, 0);
-                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c & 1][e][1], b1, acc2[1][1], 0, 0, 0);
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][0], b0, acc2[0][0], 0, 0, 0);
+                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][0], b1, acc2[0][1], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][1], b0, acc2[1][0], 0, 0, 0);
+                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][1], b1, acc2[1][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // scale3 / shift3 are read straight from global memory (L1 hits): conv_epilogue only indexes the pointers
-            conv_epilogue<2, 2, true, true>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow,
-                                            pix_off, pix_ok, true, rpre);
+            conv_epilogue<2, 2, false>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
+                                       pix_ok, true);
         }
     }
 #ifdef RFX_TRACE
