@@ -243,8 +243,13 @@ def main():
     dom_n, dom_f, dom_t, dom_b = by_kernel[dom_id]
     tmn = {0: "2, 2", 1: "1, 2", 2: "1, 1"}[dom_id & 3]
     tf = lambda b: "true" if b else "false"
-    if dom_id & 32:
-        dom_name = "conv3x3_direct_kernel<%d, %d>" % (1 if dom_id & 3 else 2, 4 if dom_id & 128 else (8 if dom_id & 64 else 16))
+    if dom_id & (32 | 512):   # direct 3x3 kernel; 512 = fused with the 1x1 expansion (Bottleneck tail)
+        dom_name = "conv3x3_direct_kernel<%d, %d, %s>" % (1 if dom_id & 3 else 2, 4 if dom_id & 128 else (8 if dom_id & 64 else 16),
+                                                          "true" if dom_id & 512 else "false")
+    elif dom_id == 256:
+        dom_name = "stem_conv_maxblur_kernel"
+    elif dom_id == 257:
+        dom_name = "stem7_conv_maxpool_kernel"
     else:
         dom_name = "conv2d_mfma_kernel<%s, %s, %s, %s>" % (tmn, tf(dom_id & 4), tf(dom_id & 8), tf(dom_id & 16))
     if os.environ.get("RFX_BENCH_DUMP") and rank == 0:
