@@ -34,6 +34,10 @@ __device__ __forceinline__ void take_min_idx(float& bv, int& bi, float ov, int o
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
 
+// VEC: both feature matrices have a leading dimension that is a multiple of 4 and 16-byte aligned rows -- the staging then
+// uses one float4 per 4 cells and k row (8 loads per thread and K step instead of 32) with the register transpose of
+// conv.hip's weight side; the LDS image and everything after it are the same.
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
     constexpr int KK = BK / 2;
     // LDS image per operand: [h = k&1][cell][kk = k>>1] (16 k-pairs per row, XOR-swizzled 16-byte chunks): a lane
@@ -63,19 +67,42 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
     const int tb = bid % a.tilesB, ta = bid / a.tilesB;
     const int i0 = ta * BM, j0 = tb * BN;
 
-    // staging roles: cell `col` of both tiles, parity h of k, all 16 k-pairs of the step
+    // staging roles.  scalar: cell `col` of both tiles, parity h of k, all 16 k-pairs of the step.
+    // VEC: cells 4*cg .. 4*cg+3, parity hv, k-pairs [iv0, iv0+4) of the step.
     const int col = t % 128;
     const int h = __builtin_amdgcn_readfirstlane(t / 128);
     const bool aval = (i0 + col) < a.nA, bval = (j0 + col) < a.nB;
     const float* Ap = Ab + (aval ? i0 + col : 0);
     const float* Bp = Bb + (bval ? j0 + col : 0);
-    const float mk = (bval && a.maskB) ? a.maskB[(size_t)pair * a.strideMask + j0 + col] : 1.0f;
+    const float mk = (!VEC && bval && a.maskB) ? a.maskB[(size_t)pair * a.strideMask + j0 + col] : 1.0f;
+    const int cg = t % 32, kq = t / 32;
+    const int hv = kq & 1, iv0 = (kq >> 1) * 4;
+    // a group of 4 cells lies entirely inside or outside the padded row (ld % 4 == 0): outside -> read cell 0, masked
+    const float* Av = Ab + ((i0 + 4 * cg) < a.ldA ? i0 + 4 * cg : 0);
+    const float* Bv = Bb + ((j0 + 4 * cg) < a.ldB ? j0 + 4 * cg : 0);
+    float mkv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (VEC && a.maskB) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j0 + 4 * cg + e < a.nB) mkv[e] = a.maskB[(size_t)pair * a.strideMask + j0 + 4 * cg + e];
+    }
 
     // The loads carry no select: a value that depends on a just-issued load makes the compiler wait for it on the
     // spot (the whole gather would serialise on memory latency).  Out-of-range rows / cells read a valid dummy
     // address and are zeroed when the registers are written to LDS, one K step later.
     float ra[KK], rb[KK];
+    f32x4 va4[4], vb4[4];
     auto load_global = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + hv + 2 * (iv0 + j);
+                const int kc = k < a.C ? k : 0;
+                va4[j] = *reinterpret_cast<const f32x4*>(Av + (size_t)kc * a.ldA);
+                vb4[j] = *reinterpret_cast<const f32x4*>(Bv + (size_t)kc * a.ldB);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KK; ++i) {
             const int k = k0 + h + 2 * i;
@@ -85,6 +112,25 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
         }
     };
     auto store_lds = [&](int buf, int k0) {
+        if (VEC) {
+            // 4x4 register transpose: element (j, e) of the loaded rows is k-pair iv0+j of cell 4*cg+e
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cell = 4 * cg + e;
+                const bool ain = (i0 + cell) < a.nA, bin = (j0 + cell) < a.nB;
+                f32x4 wa, wb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool kin = (k0 + hv + 2 * (iv0 + j)) < a.C;
+                    wa[j] = (kin & ain) ? va4[j][e] : 0.0f;
+                    wb[j] = (kin & bin) ? vb4[j][e] * mkv[e] : 0.0f;
+                }
+                const int chunk = ((iv0 >> 2) ^ (cg & 3)) * 4;   // (cell >> 2) & 3 == cg & 3
+                *reinterpret_cast<f32x4*>(&As[buf][hv][cell][chunk]) = wa;
+                *reinterpret_cast<f32x4*>(&Bs[buf][hv][cell][chunk]) = wb;
+            }
+            return;
+        }
         const int sw = (col >> 2) & 3;
 #pragma unroll
         for (int i = 0; i < KK; ++i) {
@@ -326,7 +372,10 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     a.oRowVal = L.rowVal; a.oRowIdx = L.rowIdx; a.oColIdx = L.colIdx;
     const long long nwg = (long long)a.tilesA * a.tilesB;
     if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
-    hipLaunchKernelGGL(mnn_tile_kernel, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    const bool vec = a.ldA % 4 == 0 && a.ldB % 4 == 0 && a.strideA % 4 == 0 && a.strideB % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(mnn_tile_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(mnn_tile_kernel<false>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(mnn_reduce_kernel, dim3((a.nA + a.nB + 255) / 256, batch), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();

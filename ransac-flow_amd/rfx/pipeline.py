@@ -121,12 +121,13 @@ class AlignPipeline:
         B = prep["B"]
         dims = [(x.shape[2] // 16, x.shape[3] // 16) for x in prep["src"]]
         nA = sum(r * c for r, c in dims)
-        featA = torch.empty((B, 1024, nA), dtype=torch.float32, device=self.dev)
+        ldA = (nA + 3) // 4 * 4      # rows padded to 16 bytes: the mutual-NN kernel then stages with float4 loads
+        featA = torch.empty((B, 1024, ldA), dtype=torch.float32, device=self.dev)
         Ws, Hs = [], []
         off = 0
         for x, (r, c) in zip(prep["src"], dims):
             f = self.trunk(x)
-            ops.l2norm(f, out=featA[:, :, off:], out_batch_stride=1024 * nA, out_chan_stride=nA)
+            ops.l2norm(f, out=featA[:, :, off:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
             W, Hh = cell_coords(r, c, self.dev)
             Ws.append(W)
             Hs.append(Hh)
@@ -134,7 +135,7 @@ class AlignPipeline:
         ft = ops.l2norm(self.trunk(prep["tgt"]))
         rt, ct = ft.shape[2], ft.shape[3]
         Wt, Ht = cell_coords(rt, ct, self.dev)
-        return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
+        return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
     def coarse(self, prep, feats=None, samples=None, maskB=None):
@@ -204,7 +205,8 @@ class AlignPipeline:
         mask = None
         if maskB is not None:
             mask = (torch.stack(list(maskB)) if not isinstance(maskB, torch.Tensor) else maskB).float().contiguous()
-        rc = lib.rfx_mutual_nn_batched_f32(ops._p(feats["featA"]), nA, nA, 1024 * nA, ops._p(feats["featB"]), nB, nB,
+        ldA = feats.get("ldA", nA)
+        rc = lib.rfx_mutual_nn_batched_f32(ops._p(feats["featA"]), ldA, nA, 1024 * ldA, ops._p(feats["featB"]), nB, nB,
                                            1024 * nB, 1024, ops._p(mask), ops._p(idx1), ops._p(idx2), ops._p(count),
                                            ops._p(ws), B, ops._stream())
         _lib.check(rc, "rfx_mutual_nn_batched_f32")
@@ -273,7 +275,7 @@ class AlignPipeline:
         dev = self.dev
         h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
         IsT, ItT = prep["IsTensor"][b:b + 1], prep["ItTensor"][b:b + 1]
-        i1, i2 = ops.mutual_nn(feats["featA"][b], feats["featB"][b])
+        i1, i2 = ops.mutual_nn(feats["featA"][b], feats["featB"][b], ldA=feats.get("ldA"), nA=feats["nA"])
         W1, H1 = feats["WA"][i1], feats["HA"][i1]
         W2, H2 = feats["Wt"][i2], feats["Ht"][i2]
         rt, ct = feats["rt"], feats["ct"]
