@@ -266,12 +266,59 @@ __global__ __launch_bounds__(256) void l2norm_nchw_kernel(const float* __restric
     }
 }
 
+// Same arithmetic, four threads per pixel: thread q of a pixel owns the channels c = q (mod 4) -- exactly the partial sum
+// s_q of the kernel above (same sequential fma chain), combined as (s0 + s1) + (s2 + s3) through LDS, so the result is
+// bit-identical.  The trunk's maps have only 1-2 k pixels per image: one thread per pixel leaves ~1 wavefront per SIMD walking
+// 1024 channels three times with four loads in flight; this form has 4x the wavefronts and 8 loads in flight per thread.
+__global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             long long NP, int C, int HW, long long obs, long long ocs) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long p = (long long)blockIdx.x * 64 + lane;
+    const bool pv = p < NP;
+    const long long pc = pv ? p : 0;
+    const long long n = pc / HW;
+    const int px = (int)(pc - n * HW);
+    const float* src = in + (size_t)n * C * HW + px;
+    float* dst = out + (size_t)n * obs + px;
+    float s = 0.f;
+    int c = q;
+    for (; c + 28 < C; c += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(v[u], v[u], s);
+    }
+    for (; c < C; c += 4) { const float v = src[(size_t)c * HW]; s = fmaf(v, v, s); }
+    part[q][lane] = s;
+    __syncthreads();
+    const float nrm = sqrtf((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+    const float d = nrm > 1e-12f ? nrm : 1e-12f;
+    if (!pv) return;
+    c = q;
+    for (; c + 28 < C; c += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[(size_t)(c + 4 * u) * ocs] = v[u] / d;
+    }
+    for (; c < C; c += 4) dst[(size_t)c * ocs] = src[(size_t)c * HW] / d;
+}
+
 extern "C" int rfx_l2norm_nchw_f32(const float* in, float* out, int N, int C, int HW, long long out_batch_stride,
                                    long long out_chan_stride, void* stream) {
     if (!in || !out || N <= 0 || C <= 0 || HW <= 0 || out_batch_stride < 0 || out_chan_stride < 0) return RFX_E_ARG;
     const long long NP = (long long)N * HW;
     const long long ocs = out_chan_stride ? out_chan_stride : HW;
     const long long obs = out_batch_stride ? out_batch_stride : (long long)C * HW;
+    if (C % 4 == 0 && C >= 32 && (NP + 63) / 64 <= 0x7fffffffLL) {
+        hipLaunchKernelGGL(l2norm_nchw_q4_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(256), 0, rfx_stream(stream), in, out,
+                           NP, C, HW, obs, ocs);
+        RFX_LAUNCH_CHECK();
+        return RFX_OK;
+    }
     hipLaunchKernelGGL(l2norm_nchw_kernel, dim3(grid_for(NP, 64)), dim3(64), 0, rfx_stream(stream), in, out, NP, C, HW,
                        obs, ocs);
     RFX_LAUNCH_CHECK();
