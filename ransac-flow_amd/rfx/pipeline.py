@@ -125,14 +125,22 @@ class AlignPipeline:
         featA = torch.empty((B, 1024, ldA), dtype=torch.float32, device=self.dev)
         Ws, Hs = [], []
         off = 0
+        tgt = prep["tgt"]
+        ft_raw = None
         for x, (r, c) in zip(prep["src"], dims):
-            f = self.trunk(x)
+            if ft_raw is None and x.shape == tgt.shape:
+                # the pyramid level of scale 1 has the target's size: one trunk pass over both (twice the batch, one
+                # launch tail less per layer); every sample is computed independently, bit-identical to two passes
+                f2 = self.trunk(torch.cat((x, tgt), dim=0))
+                f, ft_raw = f2[:B], f2[B:]
+            else:
+                f = self.trunk(x)
             ops.l2norm(f, out=featA[:, :, off:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
             W, Hh = cell_coords(r, c, self.dev)
             Ws.append(W)
             Hs.append(Hh)
             off += r * c
-        ft = ops.l2norm(self.trunk(prep["tgt"]))
+        ft = ops.l2norm(ft_raw if ft_raw is not None else self.trunk(tgt))
         rt, ct = ft.shape[2], ft.shape[3]
         Wt, Ht = cell_coords(rt, ct, self.dev)
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
