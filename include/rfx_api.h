@@ -74,10 +74,12 @@ int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, i
  * -> relu) as ONE kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual).  The workgroup that computed a
  * 128-pixel tile of ALL Cmid channels of the 3x3 convolution keeps it in LDS and multiplies it with the expansion weights,
  * so the Cmid-channel map never goes to HBM.  in (N,Cin,H,W); wT2/scale2/shift2 = packed weights / folded BN of the 3x3
- * (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); wT3 ([Cmid rows][Cexp]) / scale3 / shift3 of the 1x1 (Cexp % 128 == 0);
+ * (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); scale3 / shift3 of the 1x1 (Cexp % 128 == 0) and its weights in
+ * "quad" order wQ3[q][h][m][j] = W3[m][8q + 2j + h] (q < Cmid/8, h < 2, m < Cexp, j < 4; 16-byte aligned): the four MFMA A
+ * operands of a lane for four consecutive k-pairs are one 16-byte load, coalesced over the channels;
  * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.  Bit-identical to the two rfx_conv2d_f32 calls. */
 int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
-                            const float* wT3, const float* scale3, const float* shift3, const float* residual, int act3,
+                            const float* wQ3, const float* scale3, const float* shift3, const float* residual, int act3,
                             float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream);
 
 /* nn.MaxPool2d(k, stride, pad) with -inf padding (model/resnet50.py:120: k=3,s=2,p=1;

@@ -241,10 +241,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                     T2[ch * 128 + (wn * 2 + j) * 32 + lcol] = v;
                 }
         __syncthreads();
-        // ---- 1x1 expansion: out[Cexp x 128 px] = W3[Cexp x BM] * T2, 128 output channels per pass, waves 2 x 2
+        // ---- 1x1 expansion: out[Cexp x 128 px] = W3[Cexp x BM] * T2, 128 output channels per pass, waves 2 x 2.
+        // The weights come in "quad" order wQ[q][lrow][m][4] = W3[m][8q + 2j + lrow] (j = 0..3): the four A operands a lane
+        // needs for k-pairs 4q..4q+3 are ONE 16-byte load, and consecutive lanes (channels) read consecutive 16 bytes.
         const float* t2col = T2 + lrow * 128 + wn * 64 + lcol;               // + 2kk*128 (+ 32 for the second sub-tile)
         for (int mp = 0; mp < a.Cexp; mp += 128) {
-            const float* wrow = a.wT3 + (size_t)lrow * a.Mpad3 + mp + wm * 64 + lcol;   // + 2kk*Mpad3 (+ 32)
+            const f32x4* wq0 = reinterpret_cast<const f32x4*>(a.wT3) + (size_t)lrow * a.Cexp + mp + wm * 64 + lcol;   // + q*2*Cexp (+ 32)
             f32x16 acc2[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -252,32 +254,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
-            // weights go L2 -> registers, two chunks of 8 k-pairs ahead of the MFMAs that use them (an L2 round trip under
-            // load is longer than the 32 MFMAs of one chunk)
-            constexpr int CK = 8, NCK = (BM / 2) / CK;
-            float wq[3][CK][2];
-            auto load_w = [&](int c, int slot) {
-#pragma unroll
-                for (int e = 0; e < CK; ++e) {
-                    const float* w = wrow + (size_t)(2 * (c * CK + e)) * a.Mpad3;
-                    wq[slot][e][0] = w[0];
-                    wq[slot][e][1] = w[32];
-                }
+            // L2 -> registers, three quads (12 k-pairs = 48 MFMAs) ahead of use: an L2 round trip under load is longer
+            // than the 16 MFMAs of one quad
+            constexpr int NQ = BM / 8, AHEAD = 3;
+            f32x4 wq[AHEAD + 1][2];
+            auto load_w = [&](int q, int slot) {
+                wq[slot][0] = wq0[(size_t)q * 2 * a.Cexp];
+                wq[slot][1] = wq0[(size_t)q * 2 * a.Cexp + 32];
             };
-            load_w(0, 0);
-            if (NCK > 1) load_w(1, 1);
 #pragma unroll
-            for (int c = 0; c < NCK; ++c) {
-                if (c + 2 < NCK) load_w(c + 2, (c + 2) % 3);
+            for (int q = 0; q < AHEAD && q < NQ; ++q) load_w(q, q);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + AHEAD < NQ) load_w(q + AHEAD, (q + AHEAD) % (AHEAD + 1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < CK; ++e) {
-                    const int kk = c * CK + e;
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = q * 4 + e;
                     const float b0 = t2col[2 * kk * 128], b1 = t2col[2 * kk * 128 + 32];
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][0], b0, acc2[0][0], 0, 0, 0);
-                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][0], b1, acc2[0][1], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][1], b0, acc2[1][0], 0, 0, 0);
-                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[c % 3][e][1], b1, acc2[1][1], 0, 0, 0);
+                    const float w0 = wq[q % (AHEAD + 1)][0][e], w1 = wq[q % (AHEAD + 1)][1][e];
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b0, acc2[0][0], 0, 0, 0);
+                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b1, acc2[0][1], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, b0, acc2[1][0], 0, 0, 0);
+                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, b1, acc2[1][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -346,15 +345,16 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
 // The 3x3 convolution must be direct-eligible (stride 1, pad 1, Cin % 8 == 0) with Cmid in {64, 128} so that one workgroup
 // tile holds all of its channels; Cexp % 128 == 0.
 extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
-                                       const float* wT3, const float* scale3, const float* shift3, const float* residual,
+                                       const float* wQ3, const float* scale3, const float* shift3, const float* residual,
                                        int act3, float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream) {
-    if (!in || !wT2 || !wT3 || !scale3 || !shift3 || !out || N <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
+    if (!in || !wT2 || !wQ3 || !scale3 || !shift3 || !out || N <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
     if (Cin <= 0 || Cin % 8 != 0 || (Cmid != 64 && Cmid != 128) || Cexp <= 0 || Cexp % 128 != 0) return RFX_E_ARG;
+    if (reinterpret_cast<uintptr_t>(wQ3) & 15) return RFX_E_ARG;
     if (act2 == RFX_ACT_SIGMOID || act3 == RFX_ACT_SIGMOID) return RFX_E_ARG;
     C3Args a;
     a.in = in; a.wT = wT2; a.scale = scale2; a.shift = shift2; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cmid; a.act = act2; a.Mpad = 128;
-    a.wT3 = wT3; a.scale3 = scale3; a.shift3 = shift3; a.Cexp = Cexp; a.Mpad3 = Cexp; a.act3 = act3;
+    a.wT3 = wQ3; a.scale3 = scale3; a.shift3 = shift3; a.Cexp = Cexp; a.Mpad3 = Cexp; a.act3 = act3;
 #ifdef RFX_TRACE
     a.trace = rfx_debug_trace_ptr();
 #endif

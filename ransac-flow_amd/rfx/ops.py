@@ -47,6 +47,8 @@ class ConvPlan:
         Kpad, Mpad = (K + 31) // 32 * 32, (self.Cout + 127) // 128 * 128
         wT = torch.zeros(Kpad, Mpad, dtype=torch.float32)
         wT[:K, :self.Cout] = w.reshape(self.Cout, K).t()
+        self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
+        self._wq = None
         k = torch.arange(K)
         c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)
         ktab = torch.full((Kpad,), -1, dtype=torch.int32)
@@ -63,6 +65,15 @@ class ConvPlan:
             self.scale, self.shift = alpha.to(dev), beta.to(dev)
         else:
             self.scale = self.shift = None
+
+    def quad_weights(self):
+        """1x1 weights in the order rfx_conv3x3_conv1x1_f32 reads them: wQ[q][h][m][j] = W[m][8q + 2j + h]."""
+        if getattr(self, "_wq", None) is None:
+            w = self.w2d                                            # (Cout, Cin) on the CPU
+            Cout, Cin = w.shape
+            q = w.t().reshape(Cin // 8, 4, 2, Cout)                  # [q][j][h][m]
+            self._wq = q.permute(0, 2, 3, 1).contiguous().to(self.wT.device)   # [q][h][m][j]
+        return self._wq
 
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1
@@ -120,7 +131,7 @@ def bottleneck_tail(x, plan2, plan3, residual=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.check(_lib.load().rfx_conv3x3_conv1x1_f32(_p(x), _p(plan2.wT), _p(plan2.scale), _p(plan2.shift), plan2.act,
-                                                  _p(plan3.wT), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
+                                                  _p(plan3.quad_weights()), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
                                                   _p(out), N, C, H, W, plan2.Cout, plan3.Cout, _stream()),
                "rfx_conv3x3_conv1x1_f32")
     if tm is not None:
