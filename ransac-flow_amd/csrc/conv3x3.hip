@@ -254,24 +254,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
-            // L2 -> registers, three quads (12 k-pairs = 48 MFMAs) ahead of use: an L2 round trip under load is longer
-            // than the 16 MFMAs of one quad
-            constexpr int NQ = BM / 8, AHEAD = 3;
+            // L2 -> registers, two quads (8 k-pairs = 32 MFMAs) ahead of use
+            constexpr int NQ = BM / 8, AHEAD = 2;
             f32x4 wq[AHEAD + 1][2];
             auto load_w = [&](int q, int slot) {
                 wq[slot][0] = wq0[(size_t)q * 2 * a.Cexp];
                 wq[slot][1] = wq0[(size_t)q * 2 * a.Cexp + 32];
             };
+            // mid-tile operands from LDS run one quad ahead of the MFMAs as well (register double buffer)
+            float bq[2][4][2];
+            auto read_b = [&](int q, int slot) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bq[slot][e][0] = t2col[2 * (q * 4 + e) * 128];
+                    bq[slot][e][1] = t2col[2 * (q * 4 + e) * 128 + 32];
+                }
+            };
 #pragma unroll
             for (int q = 0; q < AHEAD && q < NQ; ++q) load_w(q, q);
+            read_b(0, 0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (q + AHEAD < NQ) load_w(q + AHEAD, (q + AHEAD) % (AHEAD + 1));
+                if (q + 1 < NQ) read_b(q + 1, (q + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kk = q * 4 + e;
-                    const float b0 = t2col[2 * kk * 128], b1 = t2col[2 * kk * 128 + 32];
+                    const float b0 = bq[q & 1][e][0], b1 = bq[q & 1][e][1];
                     const float w0 = wq[q % (AHEAD + 1)][0][e], w1 = wq[q % (AHEAD + 1)][1][e];
                     acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b0, acc2[0][0], 0, 0, 0);
                     acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, b1, acc2[0][1], 0, 0, 0);
