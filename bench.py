@@ -27,6 +27,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
 
+# the host driver supports only dmabuf IPC: without this RCCL / cross-process tensor sharing fails with
+# "hipIpcGetMemHandle: invalid argument" (already exported on the build and GPU boxes; kept for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
