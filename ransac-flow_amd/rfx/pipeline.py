@@ -322,6 +322,67 @@ class AlignPipeline:
         out["mask"] = Mask
         return out
 
+    def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None):
+        """multi_h() for every pair of the batch in lock-step: iteration k computes the k-th homography of all pairs
+        that are still active -- ONE batched launch chain for the match filtering, RANSAC (rfx_ransac_h4_batched), the
+        warp and PredFlowMask (FeatureExtractor / correlation / heads over all active pairs) and two host syncs per
+        iteration (match counts for the index draws; acceptance statistics), instead of two syncs and batch-1 kernels
+        per pair and homography.  Semantics per pair = evaluation/evalHpatch/evaluation.py:184-243.
+        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor (default: torch.randint, pairs in ascending order).
+        Returns a list of dicts like multi_h()."""
+        feats = feats or self.features(prep)
+        dev = self.dev
+        B = prep["B"]
+        h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
+        rt, ct = feats["rt"], feats["ct"]
+        idx1, idx2, cnt = self._mutual_batched(feats, B)
+        cap = idx1.shape[1]
+        slot_ok = torch.arange(cap, device=dev)[None, :] < cnt[:, None]                  # (B,cap)
+        cell2 = torch.where(slot_ok, idx2, torch.zeros_like(idx2))                      # target cell of every match slot
+        featt = ops.l2norm(self.feat(prep["ItTensor"]))
+        bg = torch.ones((B, h, w), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        Mask = torch.zeros((B, h, w), dtype=torch.float32, device=dev)
+        outs = [dict(H=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
+        nb = [0] * B
+        draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
+        eye = torch.eye(3, device=dev)
+        active = list(range(B))
+        while active:
+            A = torch.tensor(active, device=dev)
+            fg = ((Mask[A] + (1 - bg[A])) > 0.5).float()                                # (a,h,w)
+            keep = ops.resize_bilinear((1 - fg)[:, None], (rt, ct), align_corners=False)[:, 0] > 0.5
+            valid = keep.flatten(1).gather(1, cell2[A]) & slot_ok[A]                    # matches outside the explained region
+            n_dev = valid.sum(1).to(torch.int32)
+            n_host = n_dev.cpu().tolist()                                               # sync: sizes of the index draws
+            order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)         # surviving matches first, in order
+            M1, M2 = ops.gather_matches(idx1[A].gather(1, order), idx2[A].gather(1, order), n_dev, feats["HA"], feats["WA"],
+                                        feats["Ht"], feats["Wt"])
+            smp = torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
+                               for b, n in zip(active, n_host)]).to(dev, non_blocking=True)
+            bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            ok = (res[:, 0] == 0)
+            Hs = torch.where(ok[:, None, None], bestH, eye)                             # failed pairs: any finite warp
+            flowCoarse = ops.warp_grid(Hs, h, w)
+            pm = self.pred_flow_mask(prep["IsTensor"][A], featt[A], flowCoarse)
+            new = pm["match"][:, 0] * (1 - fg)
+            stat = torch.stack((new.mean(dim=(1, 2)), res[:, 0].float()), dim=1).cpu().tolist()   # sync: acceptance statistics
+            nxt = []
+            for k, b in enumerate(active):
+                gain, status = stat[k]
+                if n_host[k] < 4 or status != 0 or not (gain > maskRegionTh or nb[b] == 0):
+                    continue
+                outs[b]["H"].append(bestH[k])
+                outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
+                outs[b]["matchDown8"].append(torch.cat((pm["match12Down8"][k:k + 1], pm["match21Down8"][k:k + 1]), dim=1))
+                nb[b] += 1
+                Mask[b] = ((Mask[b] + new[k]) >= 1.0).float()
+                if nb[b] <= maxCoarse:
+                    nxt.append(b)
+            active = nxt
+        for b in range(B):
+            outs[b]["mask"] = Mask[b]
+        return outs
+
     # ---------------------------------------------------------------- whole path
     def align_prepared(self, prep, fine=True, samples=None):
         res = self.coarse(prep, samples=samples)

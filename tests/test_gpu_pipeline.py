@@ -215,3 +215,34 @@ def test_failed_and_mixed_batches_keep_the_reference_sentinels(dev):
         else:
             assert r["status"] == 0 and r["count"] >= 4 and int(r["inlier"].sum()) == r["count"]
 
+
+
+def test_batched_multi_homography_equals_per_pair_driver(dev):
+    """pipeline.multi_h_batched (all pairs in lock-step) against pipeline.multi_h (one pair at a time) with the same index
+    draws per (pair, homography): same number of homographies, same H / flows / masks."""
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=0.02)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev)
+    pairs = [synth.make_pair(240, 320, seed=s) for s in (9, 10, 11)]
+    prep = pipe.prepare(pairs)
+    feats = pipe.features(prep)
+
+    def draws(b):
+        state = {"k": 0}
+        def fn(n, it):
+            g = torch.Generator().manual_seed(1000 * b + state["k"])
+            state["k"] += 1
+            return torch.randint(n, (it, 4), generator=g)
+        return fn
+    single = [pipe.multi_h(prep, b, maxCoarse=2, maskRegionTh=0.01, feats=feats, sample_fn=draws(b)) for b in range(3)]
+    per_pair = [draws(b) for b in range(3)]
+    batched = pipe.multi_h_batched(prep, maxCoarse=2, maskRegionTh=0.01, feats=feats,
+                                   sample_fn=lambda b, n, it: per_pair[b](n, it))
+    for b in range(3):
+        s, m = single[b], batched[b]
+        assert len(s["H"]) == len(m["H"]) >= 1, (b, len(s["H"]), len(m["H"]))
+        for k in range(len(s["H"])):
+            assert (s["H"][k] - m["H"][k]).abs().max() < 1e-6
+            assert (s["flowDown8"][k] - m["flowDown8"][k]).abs().max() < 1e-4
+            assert (s["matchDown8"][k] - m["matchDown8"][k]).abs().max() < 1e-4
+        assert float((s["mask"] != m["mask"]).float().mean()) < 1e-3
