@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--nb-scale", type=int, default=7)
     ap.add_argument("--nb-iter", type=int, default=1000)
+    ap.add_argument("--multi-h", action="store_true",
+                    help="BASELINE config 3 as literally worded: variant B (evalHpatch) multi-homography loop, coarseIter "
+                         "10 000, minSize 480, scaleR 2, PredFlowMask per homography (default: quick_start semantics, one H)")
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-prep", action="store_true",
@@ -191,8 +194,14 @@ def main():
     sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1),
                flow=weights.net_flow_coarse_sd(2), match=weights.net_matchability_sd(3))
     H, W, B = args.height, args.width, args.batch
-    pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
-                         variant="A", device=dev)
+    if args.multi_h:
+        sds["match"] = weights.net_matchability_sd(3, last_std=0.02)
+        pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=10000, tolerance=0.05, minSize=min(H, W), scaleR=2.0,
+                             variant="B", device=dev)
+        args.no_cpu_baseline = True     # the CPU leg times the quick_start path
+    else:
+        pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
+                             variant="A", device=dev)
     # this rank's shard of the synthetic stream: pair i -> rank i mod world
     pairs = [synth.make_pair(H, W, seed=rank + world * i) for i in range(B)]
     log("weights packed, synthetic pairs made")
@@ -207,6 +216,15 @@ def main():
 
     def step():
         p = prep if raw is None else pipe.prepare_device(*raw)
+        if args.multi_h:
+            outs = pipe.multi_h_batched(p, maxCoarse=10, maskRegionTh=0.01)
+            rec = torch.zeros((B, 10 + 11 * 9), dtype=torch.float32, device=dev)   # [9 unused | status | nbH-1 H matrices]
+            for b, o in enumerate(outs):
+                rec[b, 9] = 0.0 if o["H"] else 1.0
+                if o["H"]:
+                    hs = torch.stack(o["H"]).reshape(-1)
+                    rec[b, 10:10 + hs.numel()] = hs
+            return rdist.gather_records(rec, dist)
         res = pipe.align_prepared(p, fine=True)
         rec = rdist.pack_records(res)                       # (B, 9 + 1 + 2*h8*w8) float32 on device
         return rdist.gather_records(rec, dist)              # ONE all_gather per step (no-op copy when world == 1)
@@ -308,7 +326,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d %dx%d pairs per GPU per step, full pipeline: ResNet-50 conv4 feat x%d scales"
+            "config": {"workload": ("MULTI-H (variant B, 10 000 RANSAC iterations and PredFlowMask per homography, up to 11 "
+                                    "homographies per pair): " if args.multi_h else "") +
+                                   "batch of %d %dx%d pairs per GPU per step, full pipeline: ResNet-50 conv4 feat x%d scales"
                                    " + mutual NN + RANSAC(nbIter=%d, 4-pt DLT) + FeatureExtractor + 7x7 corr + NetFlowCoarse"
                                    " + grid_sample (BASELINE configs 2+3 at the metric's 480x640)" % (B, H, W, args.nb_scale, args.nb_iter),
                        "pairs_per_step_per_gpu": B, "nbIter": args.nb_iter, "nbScale": args.nb_scale,
