@@ -313,3 +313,27 @@ def test_assemble_restatement_matches_live_reference(seed, tmp_path):
     rf, rm = fc(5, str(fine), os.listdir(fine), str(coarse), str(maskp), True, 0.15)
     fg, mg, _ = restate.assemble_flow(t(flowDown), t(param), t(md), (hd * 8, wd * 8), 0.15, True, True)
     assert torch.equal(rf, fg) and torch.equal(rm[..., 0], mg)
+
+
+def test_conv_dispatch_table_is_stable():
+    """Host-side dispatch of rfx_conv2d_f32 (no GPU needed): which kernel instance a layer geometry gets.  Bits: 0-1 tile
+    variant, 2 = 1x1 specialisation, 3 = wave-specialised form (off by default), 4 = 16-byte pixel loads, 5 = direct 3x3
+    kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4)."""
+    lib = _lib.load()
+    kid = lambda N, Cin, Cout, k, s, p, Ho, Wo: lib.rfx_conv2d_kernel_id(N, Cin, Cout, k, k, s, p, Ho, Wo)
+    # direct 3x3 / stride 1: big layers -> 128-channel tiles, 8x16 patches
+    assert kid(128, 128, 128, 3, 1, 1, 120, 160) == 32
+    assert kid(128, 64, 64, 3, 1, 1, 240, 320) == 33                       # Cout = 64 -> 64-channel tiles
+    assert kid(64, 256, 256, 3, 1, 1, 30, 40) == 32 | 64                    # 30x40 pads least with 16x8 patches
+    assert kid(64, 256, 256, 3, 1, 1, 25, 33) == 32 | 128                   # 25x33 -> 32x4 patches
+    assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 0                           # Cin % 8 != 0 -> implicit GEMM, 128x128 tile
+    assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 2                            # ... a single image: 64x64 tiles fill the chip
+    assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 0                          # strided 3x3 -> implicit GEMM, 128x128 tile
+    # 1x1: 16-byte pixel loads only for stride 1 and H*W % 4 == 0
+    assert kid(64, 64, 256, 1, 1, 0, 120, 160) == 4 | 16
+    assert kid(64, 256, 1024, 1, 1, 0, 34, 45) == 4                         # 1530 pixels per plane: scalar pixel loads
+    assert kid(64, 256, 512, 1, 2, 0, 60, 80) == 4                          # strided 1x1
+    assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 4 | 16 | 1                # Cout = 64 -> 64-wide channel tile
+    # tiny problems fall back to the 64x64 tile
+    assert kid(1, 128, 49, 1, 1, 0, 12, 16) & 3 == 2
+    assert lib.rfx_conv2d_tile_variant(64, 256, 120, 160) == 0 and lib.rfx_conv2d_tile_variant(1, 64, 12, 16) == 2
