@@ -21,8 +21,10 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 
 // vertical == 0: out (N, rows, outW, C) from in (N, inH, inW, C), row y reads source row y + row_off
 // vertical == 1: out (N, outH, inW, C) from in (N, inH, inW, C)
+// CT = compile-time channel count (3 for RGB: unrolled channel loops, accumulators in registers); 0 = runtime C.
+template <int CT>
 __global__ __launch_bounds__(256) void lanczos_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                           long long total, int inH, int inW, int oH, int oW, int C,
+                                                           long long total, int inH, int inW, int oH, int oW, int Crt,
                                                            const int32_t* __restrict__ bounds,
                                                            const int32_t* __restrict__ kk, int ksize, int vertical,
                                                            int row_off) {
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void lanczos_pass_kernel(const uint8_t* __rest
         const long long r = idx / oW;
         const int oy = (int)(r % oH);
         const long long n = r / oH;
+        const int C = CT ? CT : Crt;
         const uint8_t* src = in + (size_t)n * inH * inW * C;
         const int o = vertical ? oy : ox;
         const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
@@ -42,18 +45,21 @@ __global__ __launch_bounds__(256) void lanczos_pass_kernel(const uint8_t* __rest
             for (int j = 0; j < cnt; ++j) {
                 const uint8_t* p = src + ((size_t)(lo + j) * inW + ox) * C;
                 const int w = k[j];
-                for (int c = 0; c < C; ++c) acc[c] += (int)p[c] * w;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < C) acc[c] += (int)p[c] * w;
             }
         } else {
             const uint8_t* row = src + (size_t)(oy + row_off) * inW * C;
             for (int j = 0; j < cnt; ++j) {
                 const uint8_t* p = row + (size_t)(lo + j) * C;
                 const int w = k[j];
-                for (int c = 0; c < C; ++c) acc[c] += (int)p[c] * w;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < C) acc[c] += (int)p[c] * w;
             }
         }
         uint8_t* dst = out + (size_t)idx * C;
-        for (int c = 0; c < C; ++c) dst[c] = clip8(acc[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) dst[c] = clip8(acc[c]);
     }
 }
 
@@ -91,8 +97,12 @@ extern "C" int rfx_lanczos_pass_u8(const uint8_t* in, uint8_t* out, int N, int i
         return RFX_E_ARG;
     if (vertical ? (outW != inW) : (outH + row_offset > inH)) return RFX_E_ARG;
     const long long total = (long long)N * outH * outW;
-    hipLaunchKernelGGL(lanczos_pass_kernel, dim3(grid_for(total)), dim3(256), 0, rfx_stream(stream), in, out, total, inH,
-                       inW, outH, outW, C, bounds, weights, ksize, vertical, row_offset);
+    if (C == 3)
+        hipLaunchKernelGGL(lanczos_pass_kernel<3>, dim3(grid_for(total)), dim3(256), 0, rfx_stream(stream), in, out, total, inH,
+                           inW, outH, outW, C, bounds, weights, ksize, vertical, row_offset);
+    else
+        hipLaunchKernelGGL(lanczos_pass_kernel<0>, dim3(grid_for(total)), dim3(256), 0, rfx_stream(stream), in, out, total, inH,
+                           inW, outH, outW, C, bounds, weights, ksize, vertical, row_offset);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
