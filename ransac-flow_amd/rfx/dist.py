@@ -22,16 +22,12 @@ def record_width(h8, w8):
 def pack_records(results):
     """List of per-pair result dicts (rfx.pipeline) -> (B, 9 + 1 + 2*h8*w8) float32 tensor:
     [H row-major (zeros if failed) | status (0 ok, 1 failed) | flowDown8 (2,h8,w8) flattened]."""
-    rows = []
-    for r in results:
-        fd = r["flowDown"].reshape(-1)
-        if r["H"] is not None:
-            head = torch.cat((r["H"].reshape(-1), torch.zeros(1, dtype=torch.float32, device=fd.device)))
-        else:
-            head = torch.cat((torch.zeros(9, dtype=torch.float32, device=fd.device),
-                              torch.ones(1, dtype=torch.float32, device=fd.device)))
-        rows.append(torch.cat((head, fd)))
-    return torch.stack(rows)
+    dev = results[0]["flowDown"].device
+    zero9 = torch.zeros(9, dtype=torch.float32, device=dev)
+    Hm = torch.stack([r["H"].reshape(9) if r["H"] is not None else zero9 for r in results])          # one kernel
+    status = torch.tensor([[0.0 if r["H"] is not None else 1.0] for r in results], dtype=torch.float32).to(dev, non_blocking=True)
+    fd = torch.cat([r["flowDown"].reshape(1, -1) for r in results], dim=0)                              # one kernel
+    return torch.cat((Hm, status, fd), dim=1)
 
 
 def gather_records(rec, dist=None):
