@@ -188,6 +188,40 @@ def script_functions(rel_path, names):
     return {n: ns[n] for n in names}
 
 
+def script_loop(rel_path, test_src, extra_ns=None):
+    """Compile ONE loop statement of a reference *script* -- the first ``while`` whose condition reads ``test_src``
+    (e.g. "nbCoarse <= args.maxCoarse" = the multi-homography driver of evaluation/evalHpatch/evaluation.py:211-243,
+    or "True" = evaluation/evalKITTI/evaluation.py:270-336) -- and return ``run(ns)``, which executes that statement,
+    from where it lies in the reference tree, in the caller's namespace ``ns`` (the variables the script's module level
+    would have set up before the loop).  Nothing is copied: the source is parsed and executed in place."""
+    import ast
+    _install_stubs()
+    path = os.path.join(REF_ROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    want = ast.dump(ast.parse(test_src, mode="eval").body)
+    loop = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.While) and ast.dump(node.test) == want:
+            loop = node
+            break
+    if loop is None:
+        raise KeyError("no `while %s` in %s" % (test_src, rel_path))
+    code = compile(ast.Module(body=[loop], type_ignores=[]), path, "exec")
+    from scipy import ndimage
+    measure = types.SimpleNamespace(
+        label=lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0])
+    base = {"np": np, "torch": torch, "F": torch.nn.functional, "os": os, "tgm": sys.modules["kornia.geometry"],
+            "measure": measure}
+    base.update(extra_ns or {})
+
+    def run(ns):
+        for k, v in base.items():
+            ns.setdefault(k, v)
+        exec(code, ns)
+        return ns
+    return run
+
+
 def quiet(fn, *a, **k):
     """Run fn with stdout silenced (the reference prints scaleList / 'Not initializing')."""
     with contextlib.redirect_stdout(io.StringIO()):

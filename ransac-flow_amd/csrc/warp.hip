@@ -159,31 +159,32 @@ __global__ __launch_bounds__(256) void merge_multi_h_kernel(const float* __restr
                                                            const float* __restrict__ inb, int n, long long HW, float th,
                                                            int multiH, float* __restrict__ flowG,
                                                            float* __restrict__ matchG, uint8_t* __restrict__ binary) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
-    int best = 0;
-    float mbest = 0.0f;
-    bool found = false;
+    // grid-stride: grid_for() caps the grid, images above 2^21 pixels take several trips
     const int last = multiH ? n : 1;
-    for (int i = 0; i < last; ++i) {
-        float v = m12[(long long)i * m12_stride + p];
-        if (cyc) v = v * cyc[(long long)i * HW + p];
-        if (inb) v = v * inb[(long long)i * HW + p];
-        if (i == 0) mbest = v;
-        if (v >= th) {
-            best = i;
-            mbest = v;
-            found = true;
-            break;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long long)gridDim.x * blockDim.x) {
+        int best = 0;
+        float mbest = 0.0f;
+        bool found = false;
+        for (int i = 0; i < last; ++i) {
+            float v = m12[(long long)i * m12_stride + p];
+            if (cyc) v = v * cyc[(long long)i * HW + p];
+            if (inb) v = v * inb[(long long)i * HW + p];
+            if (i == 0) mbest = v;
+            if (v >= th) {
+                best = i;
+                mbest = v;
+                found = true;
+                break;
+            }
         }
+        const float2 f = reinterpret_cast<const float2*>(flow)[(long long)best * HW + p];
+        float2 o;
+        o.x = fminf(fmaxf(f.x, -1.0f), 1.0f);
+        o.y = fminf(fmaxf(f.y, -1.0f), 1.0f);
+        reinterpret_cast<float2*>(flowG)[p] = o;
+        if (matchG) matchG[p] = mbest;
+        if (binary) binary[p] = found ? 1 : 0;
     }
-    const float2 f = reinterpret_cast<const float2*>(flow)[(long long)best * HW + p];
-    float2 o;
-    o.x = fminf(fmaxf(f.x, -1.0f), 1.0f);
-    o.y = fminf(fmaxf(f.y, -1.0f), 1.0f);
-    reinterpret_cast<float2*>(flowG)[p] = o;
-    if (matchG) matchG[p] = mbest;
-    if (binary) binary[p] = found ? 1 : 0;
 }
 
 // score = match12 (* cyc) (* inb), left to right: the "match" tensor of evaluation/evalKITTI/getResults.py:120, needed
@@ -191,13 +192,13 @@ __global__ __launch_bounds__(256) void merge_multi_h_kernel(const float* __restr
 __global__ __launch_bounds__(256) void match_score_kernel(const float* __restrict__ m12, long long m12_stride,
                                                          const float* __restrict__ cyc, const float* __restrict__ inb,
                                                          long long HW, long long total, float* __restrict__ out) {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= total) return;
-    const long long i = q / HW, p = q - i * HW;
-    float v = m12[i * m12_stride + p];
-    if (cyc) v = v * cyc[q];
-    if (inb) v = v * inb[q];
-    out[q] = v;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const long long i = q / HW, p = q - i * HW;
+        float v = m12[i * m12_stride + p];
+        if (cyc) v = v * cyc[q];
+        if (inb) v = v * inb[q];
+        out[q] = v;
+    }
 }
 
 }  // namespace

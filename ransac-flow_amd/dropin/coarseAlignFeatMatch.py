@@ -12,8 +12,8 @@ reference's scripts read are kept: ``It``, ``Is`` (PIL), ``IsTensor``, ``ItTenso
 All device work (ResNet-50 conv4 trunk, L2 norm, all-pairs correlation + mutual NN, RANSAC, mask resize)
 runs in librfx HIP kernels; PIL resizing and ToTensor/Normalize stay on the host like in the reference.
 ``imageNet=True`` wants torchvision's ImageNet weights: they are used when torchvision can provide them,
-otherwise (this offline image) a seeded random-init trunk of the same architecture is used and a notice is
-printed; ``trunk_state_dict=`` overrides both.
+otherwise the constructor raises (as the reference would) unless the caller opts in explicitly:
+``trunk_state_dict=``, ``RFX_TRUNK_WEIGHTS=<.pth>`` or ``RFX_ALLOW_RANDOM_TRUNK=1`` (seeded random-init trunk).
 """
 import os
 import sys
@@ -31,15 +31,31 @@ _TRUNK_KEYS = ("conv1.", "bn1.", "layer1.", "layer2.", "layer3.")
 
 
 def _trunk_state_dict(imageNet, explicit=None):
+    """Weights of conv1..layer3.  Like the reference (quick_start/coarseAlignFeatMatch.py:36), ``imageNet=True`` fails
+    loudly when torchvision's pretrained ResNet-50 cannot be had; the only ways around it are explicit:
+    ``trunk_state_dict=``, ``RFX_TRUNK_WEIGHTS=<state-dict .pth>`` or ``RFX_ALLOW_RANDOM_TRUNK=1`` (benchmarks and
+    smoke runs on this offline image; alignment with such a trunk is meaningless on real photographs)."""
     if explicit is not None:
         return explicit
+    pth = os.environ.get("RFX_TRUNK_WEIGHTS")
+    if pth:
+        sd = torch.load(pth, map_location="cpu")
+        sd = sd.get("model", sd) if isinstance(sd, dict) else sd
+        sd = {k.replace("module.", ""): v for k, v in sd.items()}
+        return {k: v for k, v in sd.items() if k.startswith(_TRUNK_KEYS)}
     if imageNet:
         try:
             import torchvision.models as models
             sd = models.resnet50(pretrained=True).state_dict()
             return {k: v for k, v in sd.items() if k.startswith(_TRUNK_KEYS)}
-        except Exception as e:  # torchvision or its weights are not available offline
-            print("[rfx] ImageNet ResNet-50 weights unavailable (%s): using a seeded random-init trunk" % type(e).__name__)
+        except (ImportError, OSError) as e:     # no torchvision / no network for the weight download
+            if os.environ.get("RFX_ALLOW_RANDOM_TRUNK", "0") != "1":
+                raise RuntimeError(
+                    "CoarseAlign(imageNet=True): torchvision's ImageNet ResNet-50 weights are unavailable (%s: %s). Pass "
+                    "trunk_state_dict=, point RFX_TRUNK_WEIGHTS at a ResNet-50 state dict, or set RFX_ALLOW_RANDOM_TRUNK=1 "
+                    "to run with a seeded random-init trunk (benchmark / smoke use only)." % (type(e).__name__, e)) from e
+            print("[rfx] RFX_ALLOW_RANDOM_TRUNK=1: seeded random-init ResNet-50 trunk (ImageNet weights unavailable: %s)"
+                  % type(e).__name__)
             return weights.resnet50_trunk_sd(seed=0)
     featPth = "../../model/pretrained/resnet50_moco.pth"
     param = torch.load(featPth, map_location="cpu")

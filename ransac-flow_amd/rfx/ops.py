@@ -1,11 +1,12 @@
 """Tensor-level wrappers over the librfx C ABI.
 
 PyTorch is used for device memory and streams only: every function takes ``torch`` tensors that already
-live on a HIP device, passes ``data_ptr()`` / sizes / ``torch.cuda.current_stream()`` to the C entry point
-and returns freshly allocated output tensors.  No op has a CPU or eager-PyTorch fallback.
+live on a HIP device, passes ``data_ptr()`` / sizes / that device's current torch stream to the C entry point
+(``_call``: device-guarded) and returns freshly allocated output tensors.  No op has a CPU or eager-PyTorch fallback.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -14,8 +15,75 @@ from . import _lib
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(dev=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _call(name, dev, *args):
+    """lib.<name>(*args, stream) on ``dev``: the stream is torch's current stream OF THAT DEVICE and the HIP
+    current device is switched for the launch when the tensors do not live on it (ctypes bypasses torch's
+    device guard)."""
+    fn = getattr(_lib.load(), name)
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = fn(*args, _stream(dev))
+    else:
+        rc = fn(*args, _stream())
+    _lib.check(rc, name)
+
+
+def _one_device(*tensors):
+    """All operands of an op must share one HIP device (foreign pointers fault or, worse, do not)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("rfx op operands live on different devices: %s and %s" % (dev, t.device))
+    return dev
+
+
+class Profiler:
+    """Explicit, thread-local launch profiler (bench.py): inside ``with ops.Profiler() as prof:`` every
+    convolution-class launch and every correlation launch of THIS thread is bracketed by two HIP events on the
+    launch stream; nothing is recorded -- and no event is created -- outside such a block.
+
+        prof.conv: list of (kernel_id, flops, ev0, ev1, shape, algorithmic_bytes)
+        prof.corr: list of (algorithmic_bytes, ev0, ev1)
+    """
+    _tls = threading.local()
+
+    def __init__(self):
+        self.conv, self.corr = [], []
+
+    def __enter__(self):
+        self._prev = getattr(Profiler._tls, "active", None)
+        Profiler._tls.active = self
+        return self
+
+    def __exit__(self, *exc):
+        Profiler._tls.active = self._prev
+        return False
+
+    @staticmethod
+    def active():
+        return getattr(Profiler._tls, "active", None)
+
+    @staticmethod
+    def begin():
+        if getattr(Profiler._tls, "active", None) is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    @staticmethod
+    def end(e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        return e1
 
 
 def _dev(t, name="tensor", dtype=torch.float32):
@@ -34,9 +102,6 @@ def _p(t):
 
 class ConvPlan:
     """Packed weights + folded BatchNorm of one convolution (see rfx_conv2d_f32 in include/rfx_api.h)."""
-
-    # bench.py sets this to a list to collect (variant, flops, start_event, end_event) per launch
-    timer = None
 
     def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5):
         # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None
@@ -88,22 +153,18 @@ class ConvPlan:
         res = _dev(residual, "residual") if residual is not None else None
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
-        lib = _lib.load()
-        tm = ConvPlan.timer
-        if tm is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        rc = lib.rfx_conv2d_f32(_p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift), _p(res),
-                                _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
-                                self.act if act is None else act, _stream())
-        _lib.check(rc, "rfx_conv2d_f32")
-        if tm is not None:
-            e1.record()
+        e0 = Profiler.begin()
+        _call("rfx_conv2d_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale),
+              _p(self.shift), _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
+              self.act if act is None else act)
+        if e0 is not None:
+            e1 = Profiler.end(e0)
+            lib = _lib.load()
             flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
             nbytes = 4.0 * (N * C * H * W + N * self.Cout * Ho * Wo * (2 if res is not None else 1)
                             + self.Cout * self.Cin * self.KH * self.KW)
-            tm.append((lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo), flops, e0, e1,
-                       (N, self.Cin, H, W, self.Cout, self.KH, self.stride), nbytes))
+            kid = lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo)
+            Profiler.active().conv.append((kid, flops, e0, e1, (N, self.Cin, H, W, self.Cout, self.KH, self.stride), nbytes))
         return out
 
 
@@ -126,20 +187,17 @@ def bottleneck_tail(x, plan2, plan3, residual=None):
     out = torch.empty((N, plan3.Cout, H, W), dtype=torch.float32, device=x.device)
     if res is not None and res.shape != out.shape:
         raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
-    tm = ConvPlan.timer
-    if tm is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(_lib.load().rfx_conv3x3_conv1x1_f32(_p(x), _p(plan2.wT), _p(plan2.scale), _p(plan2.shift), plan2.act,
-                                                  _p(plan3.quad_weights()), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
-                                                  _p(out), N, C, H, W, plan2.Cout, plan3.Cout, _stream()),
-               "rfx_conv3x3_conv1x1_f32")
-    if tm is not None:
-        e1.record()
+    e0 = Profiler.begin()
+    _call("rfx_conv3x3_conv1x1_f32", _one_device(x, res, plan2.wT, plan3.scale), _p(x), _p(plan2.wT), _p(plan2.scale),
+          _p(plan2.shift), plan2.act, _p(plan3.quad_weights()), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
+          _p(out), N, C, H, W, plan2.Cout, plan3.Cout)
+    if e0 is not None:
+        e1 = Profiler.end(e0)
         flops = 2.0 * N * H * W * (plan2.Cout * plan2.Cin * 9 + plan3.Cout * plan3.Cin)
         nbytes = 4.0 * N * H * W * (C + plan3.Cout * (2 if res is not None else 1))
         kid = _lib.load().rfx_conv2d_kernel_id(N, C, plan2.Cout, 3, 3, 1, 1, H, W)      # patch-shape bits of the 3x3 part
-        tm.append((512 | (kid & 192) | (1 if plan2.Cout == 64 else 0), flops, e0, e1, (N, C, H, W, plan3.Cout, 3, 1), nbytes))
+        Profiler.active().conv.append((512 | (kid & 192) | (1 if plan2.Cout == 64 else 0), flops, e0, e1,
+                                       (N, C, H, W, plan3.Cout, 3, 1), nbytes))
     return out
 
 
@@ -148,7 +206,7 @@ def maxpool2d(x, k, stride, pad=0):
     N, C, H, W = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rfx_maxpool2d_f32(_p(x), _p(out), N * C, H, W, k, stride, pad, _stream()), "rfx_maxpool2d_f32")
+    _call("rfx_maxpool2d_f32", x.device, _p(x), _p(out), N * C, H, W, k, stride, pad)
     return out
 
 
@@ -157,7 +215,7 @@ def blurpool2d(x, stride=2):
     N, C, H, W = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rfx_blurpool2d_f32(_p(x), _p(out), N * C, H, W, stride, _stream()), "rfx_blurpool2d_f32")
+    _call("rfx_blurpool2d_f32", x.device, _p(x), _p(out), N * C, H, W, stride)
     return out
 
 
@@ -167,7 +225,7 @@ def maxblurpool2d(x, stride=2):
     N, C, H, W = x.shape
     Ho, Wo = (H - 2) // stride + 1, (W - 2) // stride + 1
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rfx_maxblurpool2d_f32(_p(x), _p(out), N * C, H, W, stride, _stream()), "rfx_maxblurpool2d_f32")
+    _call("rfx_maxblurpool2d_f32", x.device, _p(x), _p(out), N * C, H, W, stride)
     return out
 
 
@@ -181,15 +239,12 @@ def stem_conv_maxblur(x, plan):
         raise ValueError("stem_conv_maxblur: not a 3x3/s1/p1 ReLU convolution of a 3-channel image")
     Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
     out = torch.empty((N, plan.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    timer = ConvPlan.timer
-    if timer is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(_lib.load().rfx_stem_conv3x3_maxblur_f32(_p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
-                                                       plan.Cout, _stream()), "rfx_stem_conv3x3_maxblur_f32")
-    if timer is not None:
-        e1.record()
-        timer.append((256, 2.0 * N * H * W * plan.Cout * 27, e0, e1, (N, 3, H, W, plan.Cout, 3, 1),
+    e0 = Profiler.begin()
+    _call("rfx_stem_conv3x3_maxblur_f32", _one_device(x, plan.wT), _p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
+                                                       plan.Cout)
+    if e0 is not None:
+        e1 = Profiler.end(e0)
+        Profiler.active().conv.append((256, 2.0 * N * H * W * plan.Cout * 27, e0, e1, (N, 3, H, W, plan.Cout, 3, 1),
                       4.0 * (N * 3 * H * W + N * plan.Cout * Ho * Wo)))
     return out
 
@@ -205,15 +260,12 @@ def stem_conv7_maxpool(x, plan):
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     out = torch.empty((N, plan.Cout, Hp, Wp), dtype=torch.float32, device=x.device)
-    timer = ConvPlan.timer
-    if timer is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(_lib.load().rfx_stem_conv7x7_maxpool_f32(_p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
-                                                       plan.Cout, _stream()), "rfx_stem_conv7x7_maxpool_f32")
-    if timer is not None:
-        e1.record()
-        timer.append((257, 2.0 * N * Hc * Wc * plan.Cout * 147, e0, e1, (N, 3, H, W, plan.Cout, 7, 2),
+    e0 = Profiler.begin()
+    _call("rfx_stem_conv7x7_maxpool_f32", _one_device(x, plan.wT), _p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
+                                                       plan.Cout)
+    if e0 is not None:
+        e1 = Profiler.end(e0)
+        Profiler.active().conv.append((257, 2.0 * N * Hc * Wc * plan.Cout * 147, e0, e1, (N, 3, H, W, plan.Cout, 7, 2),
                       4.0 * (N * 3 * H * W + N * plan.Cout * Hp * Wp)))
     return out
 
@@ -231,7 +283,7 @@ def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):
         if not out.is_cuda or out.dtype != torch.float32:
             raise TypeError("l2norm out must be a float32 device tensor")
         obs, ocs = out_batch_stride, out_chan_stride
-    _lib.check(_lib.load().rfx_l2norm_nchw_f32(_p(x), _p(out), N, C, HW, obs, ocs, _stream()), "rfx_l2norm_nchw_f32")
+    _call("rfx_l2norm_nchw_f32", _one_device(x, out), _p(x), _p(out), N, C, HW, obs, ocs)
     return out
 
 
@@ -241,7 +293,7 @@ def flow_head(logits, K=7):
     if C != K * K:
         raise ValueError("flow head expects %d logits, got %d" % (K * K, C))
     out = torch.empty((N, 2, R, Cc), dtype=torch.float32, device=logits.device)
-    _lib.check(_lib.load().rfx_flow_head_f32(_p(logits), _p(out), N, K, R, Cc, _stream()), "rfx_flow_head_f32")
+    _call("rfx_flow_head_f32", logits.device, _p(logits), _p(out), N, K, R, Cc)
     return out
 
 
@@ -250,8 +302,7 @@ def resize_bilinear(x, size, align_corners=False):
     N, C, H, W = x.shape
     Ho, Wo = int(size[0]), int(size[1])
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().rfx_resize_bilinear_f32(_p(x), _p(out), N * C, H, W, Ho, Wo, 1 if align_corners else 0,
-                                                  _stream()), "rfx_resize_bilinear_f32")
+    _call("rfx_resize_bilinear_f32", x.device, _p(x), _p(out), N * C, H, W, Ho, Wo, 1 if align_corners else 0)
     return out
 
 
@@ -275,13 +326,13 @@ def lanczos_resize_u8(img, out_w, out_h):
     cur, curH = img, H
     if p["need_h"]:
         tmp = torch.empty((N, p["rows_h"], out_w, C), dtype=torch.uint8, device=img.device)
-        _lib.check(lib.rfx_lanczos_pass_u8(_p(cur), _p(tmp), N, H, W, p["rows_h"], out_w, C, _p(tabs["bounds_h"]),
-                                           _p(tabs["kk_h"]), p["ks_h"], 0, p["y_first"], _stream()), "rfx_lanczos_pass_u8")
+        _call("rfx_lanczos_pass_u8", img.device, _p(cur), _p(tmp), N, H, W, p["rows_h"], out_w, C, _p(tabs["bounds_h"]),
+                                           _p(tabs["kk_h"]), p["ks_h"], 0, p["y_first"])
         cur, curH = tmp, p["rows_h"]
     if p["need_v"]:
         out = torch.empty((N, out_h, out_w, C), dtype=torch.uint8, device=img.device)
-        _lib.check(lib.rfx_lanczos_pass_u8(_p(cur), _p(out), N, curH, out_w, out_h, out_w, C, _p(tabs["bounds_v"]),
-                                           _p(tabs["kk_v"]), p["ks_v"], 1, 0, _stream()), "rfx_lanczos_pass_u8")
+        _call("rfx_lanczos_pass_u8", img.device, _p(cur), _p(out), N, curH, out_w, out_h, out_w, C, _p(tabs["bounds_v"]),
+                                           _p(tabs["kk_v"]), p["ks_v"], 1, 0)
         cur = out
     return cur
 
@@ -296,7 +347,7 @@ def u8_to_f32(img, mean=None, std=None, want_raw=True):
     norm = torch.empty((N, 3, H, W), dtype=torch.float32, device=img.device) if mean is not None else None
     m = (ctypes.c_float * 3)(*mean) if mean is not None else None
     s = (ctypes.c_float * 3)(*std) if std is not None else None
-    _lib.check(_lib.load().rfx_u8_to_f32_chw(_p(img), _p(raw), _p(norm), N, H, W, m, s, _stream()), "rfx_u8_to_f32_chw")
+    _call("rfx_u8_to_f32_chw", img.device, _p(img), _p(raw), _p(norm), N, H, W, m, s)
     return raw, norm
 
 
@@ -306,25 +357,18 @@ def corr_neigh(x, y, K=7):
         raise ValueError("corr_neigh: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
     N, C, H, W = x.shape
     out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
-    tm = corr_neigh.timer
-    if tm is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(_lib.load().rfx_corr_neigh_f32(_p(x), _p(y), _p(out), N, C, H, W, K, _stream()), "rfx_corr_neigh_f32")
-    if tm is not None:
-        e1.record()
-        tm.append(((2 * C + K * K) * 4.0 * N * H * W, e0, e1))  # algorithmic bytes, events
+    e0 = Profiler.begin()
+    _call("rfx_corr_neigh_f32", _one_device(x, y), _p(x), _p(y), _p(out), N, C, H, W, K)
+    if e0 is not None:
+        Profiler.active().corr.append(((2 * C + K * K) * 4.0 * N * H * W, e0, Profiler.end(e0)))  # algorithmic bytes
     return out
-
-
-corr_neigh.timer = None
 
 
 def warp_grid(Hm, h, w):
     Hm = _dev(Hm, "homography")
     B = Hm.shape[0]
     grid = torch.empty((B, h, w, 2), dtype=torch.float32, device=Hm.device)
-    _lib.check(_lib.load().rfx_warp_grid_f32(_p(Hm), _p(grid), B, h, w, _stream()), "rfx_warp_grid_f32")
+    _call("rfx_warp_grid_f32", Hm.device, _p(Hm), _p(grid), B, h, w)
     return grid
 
 
@@ -335,8 +379,8 @@ def grid_sample(inp, grid, align_corners=False):
         raise ValueError("grid must be (N,Ho,Wo,2)")
     Ho, Wo = grid.shape[1], grid.shape[2]
     out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=inp.device)
-    _lib.check(_lib.load().rfx_grid_sample_f32(_p(inp), _p(grid), _p(out), N, C, Hi, Wi, Ho, Wo,
-                                              1 if align_corners else 0, _stream()), "rfx_grid_sample_f32")
+    _call("rfx_grid_sample_f32", _one_device(inp, grid), _p(inp), _p(grid), _p(out), N, C, Hi, Wi, Ho, Wo,
+                                              1 if align_corners else 0)
     return out
 
 
@@ -347,8 +391,8 @@ def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up
     flow12 = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device)
     inb = torch.empty((N, H, W), dtype=torch.float32, device=flowDown.device) if want_inb else None
     fup = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device) if want_flow_up else None
-    _lib.check(_lib.load().rfx_compose_flow_f32(_p(flowDown), _p(coarseGrid), _p(flow12), _p(inb), _p(fup), N, hd, wd,
-                                               H, W, 1 if clamp else 0, _stream()), "rfx_compose_flow_f32")
+    _call("rfx_compose_flow_f32", _one_device(flowDown, coarseGrid), _p(flowDown), _p(coarseGrid), _p(flow12), _p(inb), _p(fup), N, hd, wd,
+                                               H, W, 1 if clamp else 0)
     return flow12, inb, fup
 
 
@@ -367,8 +411,7 @@ def match_score(match12, cyc=None, inb=None):
     c = _dev(cyc, "cyc") if cyc is not None else None
     b = _dev(inb, "inb") if inb is not None else None
     out = torch.empty((n, H, W), dtype=torch.float32, device=match12.device)
-    _lib.check(_lib.load().rfx_match_score_f32(match12.data_ptr(), stride, _p(c), _p(b), n, H * W, _p(out), _stream()),
-               "rfx_match_score_f32")
+    _call("rfx_match_score_f32", _one_device(match12, c, b), match12.data_ptr(), stride, _p(c), _p(b), n, H * W, _p(out))
     return out
 
 
@@ -384,9 +427,9 @@ def merge_multi_h(flow, match12, th, multiH, cyc=None, inb=None):
     fg = torch.empty((1, H, W, 2), dtype=torch.float32, device=flow.device)
     mg = torch.empty((1, H, W), dtype=torch.float32, device=flow.device)
     binary = torch.empty((1, H, W), dtype=torch.uint8, device=flow.device)
-    _lib.check(_lib.load().rfx_merge_multi_h_f32(_p(flow), match12.data_ptr(), stride, _p(c),
+    _call("rfx_merge_multi_h_f32", _one_device(flow, match12, c, b), _p(flow), match12.data_ptr(), stride, _p(c),
                                                 _p(b), n, HW, float(th), 1 if multiH else 0, _p(fg), _p(mg),
-                                                _p(binary), _stream()), "rfx_merge_multi_h_f32")
+                                                _p(binary))
     return fg, mg, binary.bool()
 
 
@@ -406,8 +449,8 @@ def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
     idx2 = torch.empty(cap, dtype=torch.int64, device=featA.device)
     count = torch.zeros(1, dtype=torch.int32, device=featA.device)
     m = _dev(maskB, "maskB") if maskB is not None else None
-    _lib.check(lib.rfx_mutual_nn_f32(_p(featA), ldA, nA, _p(featB), ldB, nB, C, _p(m), _p(idx1), _p(idx2), _p(count),
-                                     _p(ws), _stream()), "rfx_mutual_nn_f32")
+    _call("rfx_mutual_nn_f32", _one_device(featA, featB, m), _p(featA), ldA, nA, _p(featB), ldB, nB, C, _p(m), _p(idx1), _p(idx2), _p(count),
+                                     _p(ws))
     n = int(count.item())
     return idx1[:n], idx2[:n]
 
@@ -416,7 +459,7 @@ def dlt4_homography(X, Y):
     X, Y = _dev(X, "X"), _dev(Y, "Y")
     N = X.shape[0]
     H = torch.empty((N, 3, 3), dtype=torch.float32, device=X.device)
-    _lib.check(_lib.load().rfx_dlt4_homography(_p(X), _p(Y), N, _p(H), _stream()), "rfx_dlt4_homography")
+    _call("rfx_dlt4_homography", _one_device(X, Y), _p(X), _p(Y), N, _p(H))
     return H
 
 
@@ -425,8 +468,7 @@ def prediction(match1, match2, Hs):
     match1, match2, Hs = _dev(match1, "match1"), _dev(match2, "match2"), _dev(Hs, "H21")
     n, N = match1.shape[0], Hs.shape[0]
     err = torch.empty((N, n), dtype=torch.float32, device=match1.device)
-    _lib.check(_lib.load().rfx_prediction_f32(_p(match1), _p(match2), n, _p(Hs), N, _p(err), _stream()),
-               "rfx_prediction_f32")
+    _call("rfx_prediction_f32", _one_device(match1, match2, Hs), _p(match1), _p(match2), n, _p(Hs), N, _p(err))
     return err
 
 
@@ -438,8 +480,7 @@ def score_hypotheses(match1, match2, samples, tol):
     H = torch.empty((N, 3, 3), dtype=torch.float32, device=match1.device)
     counts = torch.empty(N, dtype=torch.int64, device=match1.device)
     ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=match1.device)
-    _lib.check(lib.rfx_score_hypotheses(_p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts), _p(ws),
-                                        _stream()), "rfx_score_hypotheses")
+    _call("rfx_score_hypotheses", _one_device(match1, match2, samples), _p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts), _p(ws))
     return H, counts
 
 
@@ -455,8 +496,8 @@ def ransac_h4(match1, match2, samples, tol):
     inl = torch.empty(n, dtype=torch.uint8, device=dev)
     res = torch.empty(4, dtype=torch.int32, device=dev)
     ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=dev)
-    _lib.check(lib.rfx_ransac_h4(_p(match1), _p(match2), n, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res),
-                                 _p(ws), _stream()), "rfx_ransac_h4")
+    _call("rfx_ransac_h4", _one_device(match1, match2, samples), _p(match1), _p(match2), n, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res),
+                                 _p(ws))
     return bestH, inl.bool(), res
 
 
@@ -467,9 +508,8 @@ def gather_matches(idx1, idx2, n, xa, ya, xb, yb):
     B, cap = idx1.shape
     m1 = torch.empty((B, cap, 3), dtype=torch.float32, device=idx1.device)
     m2 = torch.empty((B, cap, 3), dtype=torch.float32, device=idx1.device)
-    _lib.check(_lib.load().rfx_gather_matches_f32(_p(idx1), _p(idx2), _p(n), cap, _p(_dev(xa, "xa")), _p(_dev(ya, "ya")),
-                                                 _p(_dev(xb, "xb")), _p(_dev(yb, "yb")), _p(m1), _p(m2), B, _stream()),
-               "rfx_gather_matches_f32")
+    _call("rfx_gather_matches_f32", _one_device(idx1, idx2, n, xa, ya, xb, yb), _p(idx1), _p(idx2), _p(n), cap, _p(_dev(xa, "xa")), _p(_dev(ya, "ya")),
+                                                 _p(_dev(xb, "xb")), _p(_dev(yb, "yb")), _p(m1), _p(m2), B)
     return m1, m2
 
 
@@ -489,6 +529,6 @@ def ransac_h4_batched(match1, match2, n, samples, tol):
     inl = torch.empty((B, cap), dtype=torch.uint8, device=dev)
     res = torch.empty((B, 4), dtype=torch.int32, device=dev)
     ws = torch.empty(lib.rfx_ransac_batched_ws_bytes(cap, N, B), dtype=torch.uint8, device=dev)
-    _lib.check(lib.rfx_ransac_h4_batched(_p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
-                                         _p(res), _p(ws), B, _stream()), "rfx_ransac_h4_batched")
+    _call("rfx_ransac_h4_batched", _one_device(match1, match2, n, samples), _p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
+                                         _p(res), _p(ws), B)
     return bestH, inl.bool(), res

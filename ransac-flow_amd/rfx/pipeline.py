@@ -214,10 +214,9 @@ class AlignPipeline:
         if maskB is not None:
             mask = (torch.stack(list(maskB)) if not isinstance(maskB, torch.Tensor) else maskB).float().contiguous()
         ldA = feats.get("ldA", nA)
-        rc = lib.rfx_mutual_nn_batched_f32(ops._p(feats["featA"]), ldA, nA, 1024 * ldA, ops._p(feats["featB"]), nB, nB,
-                                           1024 * nB, 1024, ops._p(mask), ops._p(idx1), ops._p(idx2), ops._p(count),
-                                           ops._p(ws), B, ops._stream())
-        _lib.check(rc, "rfx_mutual_nn_batched_f32")
+        ops._call("rfx_mutual_nn_batched_f32", ops._one_device(feats["featA"], feats["featB"], mask), ops._p(feats["featA"]),
+                  ldA, nA, 1024 * ldA, ops._p(feats["featB"]), nB, nB, 1024 * nB, 1024, ops._p(mask), ops._p(idx1),
+                  ops._p(idx2), ops._p(count), ops._p(ws), B)
         return idx1, idx2, count
 
     # ---------------------------------------------------------------- fine stage

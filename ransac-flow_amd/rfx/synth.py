@@ -1,17 +1,37 @@
 """Synthetic smooth-texture image pairs (SURVEY.md 8d "Config N -> concrete"): a random low-resolution
 colour field is bicubic-upsampled; source and target are two crops offset by (12, 8) pixels, optionally
-with a seeded random homography applied to the target crop window."""
+(``homography=True``) with a seeded random homography applied to the target crop window."""
 import numpy as np
 import PIL.Image as Image
 
 
-def make_pair(H, W, seed=0):
-    """Returns (I1, I2) PIL RGB images of size W x H."""
+def random_homography(seed, amp=0.05):
+    """identity + amp * U(-1, 1) on the 8 free parameters, in normalised [-1, 1] coordinates
+    (row-major 3x3, h33 = 1).  Maps TARGET normalised coordinates to SOURCE normalised coordinates -- the direction
+    of the reference's own homographies (outil.Prediction: est = Y H^T, utils/outil.py:97-100)."""
+    rng = np.random.RandomState(1_000_003 + seed)
+    Hn = np.eye(3)
+    Hn.flat[:8] += amp * (rng.rand(8) * 2 - 1)
+    return Hn
+
+
+def make_pair(H, W, seed=0, homography=False, amp=0.05):
+    """Returns (I1, I2) PIL RGB images of size W x H.  I1 = crop of a smooth random texture; I2 = the same texture
+    seen through the window shifted by (12, 8) pixels and, with ``homography=True``, additionally warped by the
+    seeded ``random_homography(seed, amp)`` (so that a multi-homography driver has perspective to explain)."""
     rng = np.random.RandomState(seed)
     base = (rng.rand(H // 8 + 4, W // 8 + 4, 3) * 255).astype(np.uint8)
     big = Image.fromarray(base).resize((W + 32, H + 32), resample=Image.BICUBIC)
     I1 = big.crop((0, 0, W, H))
-    I2 = big.crop((12, 8, W + 12, H + 8))
+    if not homography:
+        return I1, big.crop((12, 8, W + 12, H + 8))
+    # pixel-space map target pixel (x, y) -> texture pixel: normalise, apply Hn, de-normalise, shift by the crop offset
+    Hn = random_homography(seed, amp)
+    N = np.array([[2.0 / W, 0, -1.0], [0, 2.0 / H, -1.0], [0, 0, 1.0]])        # pixel -> normalised
+    D = np.array([[W / 2.0, 0, W / 2.0 + 12], [0, H / 2.0, H / 2.0 + 8], [0, 0, 1.0]])   # normalised -> texture pixel
+    P = D @ Hn @ N
+    P = P / P[2, 2]
+    I2 = big.transform((W, H), Image.PERSPECTIVE, tuple(P.flatten()[:8]), resample=Image.BICUBIC)
     return I1, I2
 
 

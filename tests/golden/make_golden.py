@@ -242,10 +242,204 @@ def gen_assemble():
     print("assemble.npz:", sorted(k for k in out if not k.endswith("_cfg"))[:6], "...")
 
 
+def _ref_networks(match_std=0.02, randomize_bn=False, seeds=(1, 2, 3)):
+    """The reference's own four modules (model/model.py) carrying rfx.weights state dicts."""
+    R = ref_loader.load()
+    model = R["model"]
+    fe = ref_loader.quiet(model.FeatureExtractor)
+    fe.load_state_dict(weights.feature_extractor_sd(seed=seeds[0], randomize_bn=randomize_bn))
+    nf = ref_loader.quiet(model.NetFlowCoarse, 7)
+    nf.load_state_dict(weights.net_flow_coarse_sd(seed=seeds[1], randomize_bn=randomize_bn))
+    nm = ref_loader.quiet(model.NetMatchability, 7)
+    nm.load_state_dict(weights.net_matchability_sd(seed=seeds[2], randomize_bn=randomize_bn, last_std=match_std))
+    net = {"netFeatCoarse": fe, "netCorr": model.CorrNeigh(7), "netFlowCoarse": nf, "netMatch": nm}
+    for m in net.values():
+        m.eval()
+    return net
+
+
+def _ref_coarse_b(nbScale, nbIter, minSize, scaleR, trunk_seed=0):
+    """The reference's evaluation-side CoarseAlign (evaluation/evalHpatch/coarseAlignFeatMatch.py:35-179), trunk
+    weights from rfx.weights (argument order: nbScale, nbIter, tolerance, transform, minSize, segId, segFg, scaleR,
+    imageNet, segNet)."""
+    R = ref_loader.load()
+    ca = ref_loader.quiet(R["CoarseAlignB"], nbScale, nbIter, 0.05, "Homography", minSize, 2, False, scaleR, True, False)
+    names = ["conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3"]
+    remap = {}
+    for k, v in weights.resnet50_trunk_sd(seed=trunk_seed).items():
+        top, rest = k.split(".", 1)
+        remap["%d.%s" % (names.index(top), rest)] = v
+    ca.net.load_state_dict(remap)
+    ca.net.eval()
+    return ca
+
+
+def _grid(h, w):
+    return torch.cat((torch.linspace(-1, 1, w).view(1, 1, -1, 1).expand(1, h, w, 1),
+                      torch.linspace(-1, 1, h).view(1, -1, 1, 1).expand(1, h, w, 1)), dim=3)
+
+
+def gen_predflowmask():
+    """The reference's own PredFlowMask functions -- evaluation/evalHpatch/evaluation.py:23-55 and the KITTI variant
+    evaluation/evalKITTI/evaluation.py:49-81 -- compiled out of the two scripts and run on seeded inputs with the
+    reference's model.* modules.  Pins restate.pred_flow_mask / pred_flow_mask_kitti."""
+    R = ref_loader.load()
+    fh = ref_loader.script_functions("evaluation/evalHpatch/evaluation.py", ["PredFlowMask"])["PredFlowMask"]
+    fk = ref_loader.script_functions("evaluation/evalKITTI/evaluation.py", ["PredFlowMask", "remove_small_cc"])
+    net = _ref_networks(match_std=0.02, randomize_bn=True, seeds=(41, 42, 43))
+    out = dict(seeds=np.asarray([41, 42, 43]), match_std=np.asarray(0.02))
+    I1, I2 = synth.make_pair(96, 128, seed=5, homography=True)
+    tt = lambda im: torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)[None]
+    Is, It = tt(I1), tt(I2)
+    Hm = torch.tensor([[[1.03, 0.02, 0.04], [-0.02, 0.97, 0.05], [0.015, -0.01, 1.0]]])
+    h, w = 96, 128
+    grid = _grid(h, w)
+    with torch.no_grad():
+        flowCoarse = R["kornia_geometry"].HomographyWarper(h, w).warp_grid(Hm)
+        featt = F.normalize(net["netFeatCoarse"](It))
+        f12, match, fd8, md8 = fh(Is, featt, flowCoarse, grid, net)
+        out.update(hp_H=Hm.numpy(), hp_flow12=f12.numpy(), hp_match=match, hp_flowDown8=fd8, hp_matchDown8=md8)
+        # KITTI variant: both images already sampled; output grid LARGER than the input images (the second call of
+        # evalKITTI/evaluation.py:302 passes grid_org with resize-resolution tensors)
+        IsSample = F.grid_sample(Is, flowCoarse)
+        gh, gw = 120, 168
+        f12, match, fd8, md8 = fk["PredFlowMask"](IsSample, It, flowCoarse, _grid(gh, gw), net)
+        out.update(ki_flow12=f12.numpy(), ki_match=match, ki_flowDown8=fd8.numpy(), ki_matchDown8=md8.numpy(),
+                   ki_grid_hw=np.asarray([gh, gw]))
+    # remove_small_cc (evalKITTI/evaluation.py:85-100) on a seeded blob map
+    g = torch.Generator().manual_seed(9)
+    blob = F.avg_pool2d(torch.rand(1, 1, 66, 90, generator=g), 3, 1)[0, 0].numpy() * 1.9
+    blob = np.clip(blob, 0, 1).astype(np.float32)
+    out["cc_in"] = blob.copy()
+    out["cc_out"] = fk["remove_small_cc"](blob.copy(), 0.99, 0.002)
+    out["cc_cfg"] = np.asarray([0.99, 0.002])
+    np.savez_compressed(os.path.join(HERE, "predflowmask.npz"), **out)
+    print("predflowmask.npz", {k: np.asarray(v).shape for k, v in out.items()})
+
+
+def gen_coarse_b():
+    """The reference's variant-B CoarseAlign.setPair / getCoarse (evaluation/evalHpatch/coarseAlignFeatMatch.py:102-179)
+    on a config-1-sized pair with three different masks.  Pins restate.CoarseAlignOracle(variant="B")."""
+    I1, I2 = synth.make_pair(240, 320, seed=6, homography=True)
+    ca = _ref_coarse_b(nbScale=5, nbIter=400, minSize=240, scaleR=1.5)
+    ca.setPair(I1, I2)
+    h, w = ca.It.size[1], ca.It.size[0]
+    out = dict(cfg=np.asarray([5, 400, 240, 1.5]), hw=np.asarray([h, w]),
+               W1=ca.W1MutualMatch.numpy(), H1=ca.H1MutualMatch.numpy(), W2=ca.W2MutualMatch.numpy(),
+               H2=ca.H2MutualMatch.numpy(), W2I=ca.W2MutualMatchInt.numpy(), H2I=ca.H2MutualMatchInt.numpy())
+    masks = [np.zeros((h, w), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.float32),
+             np.ones((h, w), np.float32)]
+    masks[1][:, : w // 2] = 1                      # left half already explained
+    yy, xx = np.mgrid[0:h, 0:w]
+    masks[2][((yy - h / 2) ** 2 + (xx - w / 2) ** 2) < (h / 3) ** 2] = 1   # a disc
+    for k, Mt in enumerate(masks):
+        torch.manual_seed(300 + k)
+        Hb = ca.getCoarse(Mt)
+        out["mask_%d" % k] = Mt
+        out["H_%d" % k] = np.zeros((0,), np.float32) if Hb is None else Hb      # mask 3 excludes everything -> None
+    np.savez_compressed(os.path.join(HERE, "coarse_b.npz"), **out)
+    print("coarse_b.npz: matches", len(out["W1"]), "H0", out["H_0"].ravel()[:3], "none for full mask:", out["H_3"].size == 0)
+
+
+MULTIH_MATCH_STD = 3.0      # saturating matchability head: the explained-region mask of the multi-H loop grows
+
+
+def gen_multi_h():
+    """The reference's multi-homography driver loop itself -- the ``while nbCoarse <= args.maxCoarse`` statement of
+    evaluation/evalHpatch/evaluation.py:211-243, compiled out of the script and executed on the variables its module
+    level sets up (:172-208) -- with the reference's CoarseAlign (variant B), PredFlowMask and model.* modules.
+    Pins restate.multi_h_loop."""
+    import types
+    R = ref_loader.load()
+    pfm = ref_loader.script_functions("evaluation/evalHpatch/evaluation.py", ["PredFlowMask"])["PredFlowMask"]
+    loop = ref_loader.script_loop("evaluation/evalHpatch/evaluation.py", "nbCoarse <= args.maxCoarse")
+    net = _ref_networks(match_std=MULTIH_MATCH_STD)
+    out = dict(match_std=np.asarray(MULTIH_MATCH_STD))
+    for tag, seed, maxCoarse, th in (("a", 7, 2, 0.01), ("b", 8, 4, 0.02)):
+        I1, I2 = synth.make_pair(240, 320, seed=seed, homography=True)
+        ca = _ref_coarse_b(nbScale=3, nbIter=300, minSize=240, scaleR=1.2)
+        ca.setPair(I1, I2)
+        Itw, Ith = ca.It.size
+        with torch.no_grad():
+            featt = F.normalize(net["netFeatCoarse"](ca.ItTensor))
+            ns = dict(args=types.SimpleNamespace(maxCoarse=maxCoarse, maskRegionTh=th), coarseModel=ca, network=net,
+                      featt=featt, grid=_grid(Ith, Itw), warper=R["kornia_geometry"].HomographyWarper(Ith, Itw),
+                      It_bg=np.ones((Ith, Itw), dtype=np.float32), Mask=np.zeros((Ith, Itw), dtype=np.float32),
+                      Coarse_Flow_Tensor=[], Fine_Flow_Tensor=[], Fine_Mask_Tensor=[], nbCoarse=0, PredFlowMask=pfm)
+            torch.manual_seed(500 + seed)
+            loop(ns)
+        n = ns["nbCoarse"]
+        out["%s_cfg" % tag] = np.asarray([seed, maxCoarse, th, 500 + seed])
+        out["%s_nb" % tag] = np.asarray(n)
+        out["%s_H" % tag] = np.concatenate(ns["Coarse_Flow_Tensor"], axis=0)
+        out["%s_flowDown8" % tag] = np.concatenate(ns["Fine_Flow_Tensor"], axis=0)
+        out["%s_matchDown8" % tag] = np.concatenate(ns["Fine_Mask_Tensor"], axis=0)
+        out["%s_mask" % tag] = ns["Mask"]
+        print("multi_h %s: %d homographies, explained %.3f" % (tag, n, float(ns["Mask"].mean())))
+    np.savez_compressed(os.path.join(HERE, "multi_h.npz"), **out)
+
+
+def gen_kitti_loop():
+    """The reference's two-resolution KITTI driver itself -- the ``while True`` statement of
+    evaluation/evalKITTI/evaluation.py:270-336 compiled out of the script, with the script's own get_info / PredFlowMask
+    / remove_small_cc functions (:29-36, :49-81, :85-100), outil.resizeImg (utils/outil.py:6-19) and the reference's
+    CoarseAlign (variant B) -- on a KITTI-shaped (3.3:1) synthetic pair.  Pins restate.multi_h_loop_kitti (SURVEY 8f1,
+    BASELINE config 5)."""
+    import types
+    R = ref_loader.load()
+    fk = ref_loader.script_functions("evaluation/evalKITTI/evaluation.py", ["PredFlowMask", "remove_small_cc", "get_info"])
+    import torchvision.transforms as tvt                      # the stub of ref_loader
+    fk["get_info"].__globals__["transforms"] = tvt
+    loop = ref_loader.script_loop("evaluation/evalKITTI/evaluation.py", "True")
+    net = _ref_networks(match_std=MULTIH_MATCH_STD)
+    out = dict(match_std=np.asarray(MULTIH_MATCH_STD))
+    for tag, seed, fine, cc_th, th in (("a", 12, 128, 0.0, 0.01), ("b", 13, 112, 0.002, 0.02)):
+        Is, It = synth.make_pair(96, 312, seed=seed, homography=True, amp=0.03)
+        ca = _ref_coarse_b(nbScale=3, nbIter=300, minSize=160, scaleR=1.2)
+        get_info = fk["get_info"]
+        It_resize = R["outil"].resizeImg(It, 8, fine)
+        It_d2 = R["outil"].resizeImg(It, 8, fine // 2)
+        with torch.no_grad():
+            w_org, h_org, tensor_org, grid_org, warper_org = get_info(It)
+            _, _, tensor_s, _, _ = get_info(Is)
+            w_resize, h_resize, tensor_resize, grid_resize, warper_resize = get_info(It_resize)
+            w_d2, h_d2, tensor_d2, grid_d2, warper_d2 = get_info(It_d2)
+            ca.setPair(Is, It)
+        ns = dict(args=types.SimpleNamespace(cc_th=cc_th, maskRegionTh=th), coarseModel=ca, network=net,
+                  It_bg=np.ones((h_org, w_org), dtype=np.float32), Mask=np.zeros((h_org, w_org), dtype=np.float32),
+                  warper_d2=warper_d2, warper_resize=warper_resize, tensor_s=tensor_s, tensor_d2=tensor_d2,
+                  tensor_resize=tensor_resize, grid_d2=grid_d2, grid_resize=grid_resize, grid_org=grid_org,
+                  Homography=[], Org_D2=[], Finetune_D2=[], Org_Mask=[], Finetune_Mask=[], Org=[], Finetune=[], nbCoarse=0,
+                  PredFlowMask=fk["PredFlowMask"], remove_small_cc=fk["remove_small_cc"])
+        torch.manual_seed(700 + seed)
+        loop(ns)
+        n = ns["nbCoarse"]
+        cat = lambda lst: torch.cat(lst, dim=0).numpy().astype(np.float32)
+        out["%s_cfg" % tag] = np.asarray([seed, fine, cc_th, th, 700 + seed])
+        out["%s_sizes" % tag] = np.asarray([h_org, w_org, h_resize, w_resize, h_d2, w_d2])
+        out["%s_nb" % tag] = np.asarray(n)
+        out["%s_H" % tag] = cat(ns["Homography"])
+        out["%s_flowD2" % tag] = cat(ns["Finetune_D2"])
+        out["%s_flowDown8" % tag] = cat(ns["Finetune"])
+        out["%s_matchDown8" % tag] = cat(ns["Finetune_Mask"])
+        out["%s_mask" % tag] = ns["Mask"]
+        print("kitti loop %s: %d homographies, explained %.3f, sizes" % (tag, n, float(ns["Mask"].mean())), out["%s_sizes" % tag])
+    np.savez_compressed(os.path.join(HERE, "kitti_loop.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if only:                                   # python make_golden.py gen_multi_h gen_coarse_b ...
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     gen_ransac()
     gen_mutual()
     gen_nets()
     gen_config1()
     gen_assemble()
+    gen_predflowmask()
+    gen_coarse_b()
+    gen_multi_h()
+    gen_kitti_loop()

@@ -73,6 +73,24 @@ def test_merge_kernel_is_exact_on_given_scores(dev):
     assert torch.equal(sc.cpu(), m[:, 0] * cyc * inb)
 
 
+def test_merge_and_score_kernels_beyond_the_launch_cap(dev):
+    """n*HW and HW above 2^21 (the capped grid of 8192 x 256 threads): both kernels must walk the whole range
+    (KITTI assembly at 375x1242 with >= 5 homographies is n*HW = 2.33 M; a 1500x1500 evaluation image is HW = 2.25 M)."""
+    g = torch.Generator().manual_seed(6)
+    n, H, W = 5, 375, 1242                                     # n*HW = 2 328 750 > 2 097 152
+    m = torch.rand(n, 2, H, W, generator=g)
+    cyc = torch.rand(n, H, W, generator=g)
+    inb = (torch.rand(n, H, W, generator=g) > 0.2).float()
+    sc = ops.match_score(m.to(dev)[:, 0], cyc=cyc.to(dev), inb=inb.to(dev))
+    assert torch.equal(sc.cpu(), m[:, 0] * cyc * inb)
+    n, H, W = 3, 1500, 1500                                    # HW = 2 250 000 > 2 097 152
+    flow = (torch.rand(n, H, W, 2, generator=g) * 2.4 - 1.2)
+    m = torch.rand(n, H, W, generator=g)
+    fg, mg, b = ops.merge_multi_h(flow.to(dev), m.to(dev), 0.6, True)
+    rf, rm, rb = restate.merge_multi_h(flow.clamp(-1, 1), m, 0.6, True)
+    assert torch.equal(fg.cpu(), rf) and torch.equal(mg.cpu(), rm) and torch.equal(b.cpu(), rb)
+
+
 def test_assemble_full_size_properties(dev):
     """480x640 output, 11 homographies (the padded maximum of the result record): properties that need no oracle."""
     n, hd, wd = 11, 60, 80
