@@ -237,18 +237,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.ConvPlan.timer, ops.corr_neigh.timer = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with ops.Profiler() as prof:        # explicit, thread-local: two HIP events per conv / corr launch, on the launch stream
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     log("%d timed steps: %.3f s" % (args.steps, elapsed))
-    conv_t, corr_t = ops.ConvPlan.timer, ops.corr_neigh.timer
-    ops.ConvPlan.timer = ops.corr_neigh.timer = None
+    conv_t, corr_t = prof.conv, prof.corr
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

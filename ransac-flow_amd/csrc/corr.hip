@@ -8,35 +8,78 @@
 // registers (4 px x 28 / 21 taps per lane), so one LDS float feeds ~2.3 FMAs and the kernel sits on the
 // fp32 VALU, next to the HBM roofline (algorithmic intensity 11 FLOP/B).
 //
-// Workgroup = TR*8 threads = tile of TR (64/32/16) rows x 16 cols, two wavefronts (tap-row groups) per 16-row
-// strip; lane -> (tc = lane>>4: 4-pixel column group, r = lane&15: row inside the wave's 16-row strip).  LDS per channel: y halo tile [70][24] floats (row
-// stride 96 B: the 16-lane ds_read_b128 service groups hit 16 distinct 16-B slots -> conflict free),
-// x tile [TR][16].  Channels are streamed CK=2 at a time through a 3-deep LDS ring: one raw s_barrier
-// per chunk and a COUNTED s_waitcnt vmcnt(PPW), so the DMA of chunks s+1 and s+2 stays in flight across
-// the barrier while chunk s is on the VALU (a __syncthreads() would drain it with vmcnt(0)).
-// Channel sums are accumulated in channel order with fmaf (deterministic).
+// Tile = TR rows x 16*NCB columns per workgroup.  The tile shape decides the HBM traffic: the y operand needs a
+// 3-pixel halo, so a 16x16 tile fetches (22x24)/(16x16) = 2.06x its y pixels, while a tile that spans the whole
+// image width (NCB = W/16: the column halo lies outside the image and is zero-filled for free) only pays the
+// row halo, 22/16 -- and the rows above/below the image cost nothing either.  At the 60x80 maps of a 480x640 pair
+// the full-width 16-row tile moves 1.14x the algorithmic bytes instead of 1.37x.
+//
+// One wavefront = 16 rows x 16 columns x one group of window rows (taps i = 0..3: 112 accumulators / lane, or
+// i = 4..6: 84); lane -> (tc = lane>>4: 4-pixel column group, r = lane&15: row).  LDS per channel: y halo tile
+// [TR+6][16*NCB+8] floats (row stride 64*NCB+32 B = 6 mod 16 quads: the 16-lane ds_read_b128 service groups hit 16
+// distinct 16-B slots -> conflict free for every NCB), x tile [TR][16*NCB].  Channels are streamed CK at a time
+// through an NS-deep LDS ring: one raw s_barrier per chunk and a COUNTED s_waitcnt vmcnt, so the DMA of the next
+// NS-2 chunks stays in flight across the barrier while chunk s is on the VALU (a __syncthreads() would drain it
+// with vmcnt(0)).  Channel sums are accumulated in channel order with fmaf (deterministic); the translation unit
+// is built with -fno-slp-vectorize: the SLP vectoriser pairs the FMAs into v_pk_fma_f32 over register pairs that
+// are misaligned for half the taps and pays ~0.5 v_mov per FMA to re-pack them, while a plain v_fmac_f32 issues at
+// the full fp32 rate on gfx950's SIMD-32.
 //
 // Requires W % 4 == 0 for the 16-byte DMA path; other widths use the plain fallback kernel below.
 #include "common.h"
 
 namespace {
 
-constexpr int TC = 16;           // tile cols
-constexpr int YQ = 6;            // float4 per halo row (cols c0-4 .. c0+19)
-constexpr int CK = 2;            // channels per chunk
-constexpr int NS = 3;            // LDS ring depth: the DMA of chunks s+1 and s+2 is in flight while chunk s computes
+constexpr int TC = 16;           // columns per wavefront
 
-template <int TR>
-struct Geo {
-    static constexpr int NW = TR / 16 * 2;                     // waves per workgroup: 16-row strips x 2 tap-row groups
+// Kernel configuration: tile TR x 16*NCB, CK channels per chunk, NS-deep LDS ring, NG groups of window rows (one
+// wavefront per 16x16 block and group), PF = software-pipeline distance of the LDS reads in (channel, window row)
+// steps (0 = compiler-scheduled reads), DBG: 0 product, 1 DMA only, 2 compute only (experiments, wrong results),
+// SB: sched_barrier pinning of the step order, OPT: bit set of BAL / ZM / XPAD / PRIO below.
+template <int TR_, int NCB_, int CK_, int NS_, int NG_ = 2, int PF_ = 0, int DBG_ = 0, int SB_ = 0, int OPT_ = 0>
+struct Cfg {
+    static constexpr int TR = TR_, NCB = NCB_, CK = CK_, NS = NS_, NG = NG_, PF = PF_, DBG = DBG_, SB = SB_;
+    static constexpr bool BAL = OPT_ & 1;   // wave -> (block, tap group) map that equalises the FMA count per SIMD
+    static constexpr bool ZM = OPT_ & 2;    // halo / padding slots zeroed ONCE, DMA lanes that would fetch zeros masked off
+    static constexpr bool XPAD = OPT_ & 4;  // x rows padded to the y row stride (conflict-free ds_read_b128 of x)
+    static constexpr bool PRIO = OPT_ & 8;  // s_setprio 1 for the waves of the largest tap group
+    static constexpr int NW = TR / 16 * NCB * NG;              // waves per workgroup: strips x column blocks x tap-row groups
     static constexpr int YR = TR + 6;                          // halo rows
+    static constexpr int YQ = 4 * NCB + 2;                     // float4 per halo row (cols c0-4 .. c0+16*NCB+3)
+    static constexpr int XQ = XPAD ? 4 * NCB + 2 : 4 * NCB;    // float4 slots per x row (4*NCB used)
     static constexpr int Y_SLOTS = CK * YR * YQ;               // float4 slots of the y halo tile
     static constexpr int Y_PIECES = (Y_SLOTS + 63) / 64;
-    static constexpr int X_SLOTS = CK * TR * (TC / 4);
-    static constexpr int X_PIECES = X_SLOTS / 64;
+    static constexpr int X_SLOTS = CK * TR * XQ;
+    static constexpr int X_PIECES = (X_SLOTS + 63) / 64;
     static constexpr int PPW = (Y_PIECES + X_PIECES + NW - 1) / NW;   // DMA pieces per wave per chunk (padded)
     static constexpr int N_PIECES = PPW * NW;                  // incl. padding pieces (zero source, dump area)
     static constexpr int BUF_SLOTS = N_PIECES * 64;
+    // window rows of group g: [row_begin(g), row_begin(g+1))  -- 2 groups: 4+3, 3 groups: 3+2+2, 4 groups: 2+2+2+1
+    static constexpr int row_begin(int g) { return NG == 2 ? (g == 0 ? 0 : g == 1 ? 4 : 7)
+                                                   : NG == 3 ? (g == 0 ? 0 : g == 1 ? 3 : g == 2 ? 5 : 7)
+                                                             : (g >= 4 ? 7 : 2 * g); }
+    static constexpr int WAVES_PER_SIMD = NG == 2 ? 3 : 4;     // register budget: 168 / 128 VGPRs
+    // wave -> (16x16 block, tap group).  The hardware deals a workgroup's waves to the 4 SIMDs cyclically (w, w+4, w+8 ..
+    // share one), and the groups are unequal (4 vs 3 window rows; 3 vs 2 vs 2), so the plain map w -> (w / NG, w % NG)
+    // can stack three 4-row waves on one SIMD (672 FMAs per chunk against an average of 490).  The balanced maps put
+    // {L,L,L} {L,L,H} {H,H} {H,H} (NG = 2, 10 waves: worst SIMD 560) or 3 x {H,L,L,L} + {H,H,L} (NG = 3, 15 waves: 504).
+    static constexpr bool BALANCED = BAL && TR == 16 && NCB == 5 && (NG == 2 || NG == 3);
+    static constexpr int wave_group(int w) {
+        if (!BALANCED) return w % NG;
+        if (NG == 2) return (w == 2 || w == 3 || w == 6 || w == 7 || w == 9) ? 0 : 1;
+        return (w <= 3 || w == 7) ? 0 : ((w <= 6 || w == 8 || w == 9) ? 1 : 2);
+    }
+    static constexpr int wave_block(int w) {           // rank of w among the waves of its group
+        if (!BALANCED) return w / NG;
+        int r = 0;
+        for (int v = 0; v < w; ++v) r += wave_group(v) == wave_group(w);
+        return r;
+    }
+    static_assert(NG >= 2 && NG <= 4, "2..4 tap-row groups");
+    static_assert(PF >= 0 && PF <= 2, "LDS read pipeline distance 0..2 steps");
+    static_assert(NW * 64 <= 1024, "workgroup too large");
+    static_assert(NS >= 2 && NS <= 5 && 3 * PPW <= 63, "ring depth / vmcnt immediate out of range");
+    static_assert((size_t)NS * BUF_SLOTS * 16 <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
 __device__ __attribute__((aligned(16))) float rfx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -44,16 +87,77 @@ __device__ __attribute__((aligned(16))) float rfx_zero16[4] = {0.f, 0.f, 0.f, 0.
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// One wavefront = one 16-row strip of the tile x one group of window rows: group 0 accumulates taps i = 0..3
-// (112 accumulators / lane), group 1 taps i = 4..6 (84).  Splitting the 49 taps over two wavefronts halves the
-// register footprint (3 instead of 2 wavefronts per SIMD) and doubles the number of wavefronts a small batch
-// decomposes into; both groups read the same LDS tile, so the DMA traffic is unchanged.
-template <int TR, int I0, int I1>
-__device__ __forceinline__ void corr7_strip(f32x4 (*smem)[Geo<TR>::BUF_SLOTS], const float* xn, const float* yn,
-                                            const int* off, int wave, int strip, int lane, int nchunks, size_t HW,
-                                            float* __restrict__ out, int n, int row0, int c0, int H, int W) {
-    using G = Geo<TR>;
-    constexpr int NI = I1 - I0;
+// ---- LDS reads of the compute loop as inline assembly -------------------------------------------------------------
+// hipcc (ROCm 7.2) classifies global_load_lds as a FLAT access that may touch LDS and, while one is pending -- always, in
+// this kernel -- waits for EVERY outstanding ds_read with s_waitcnt lgkmcnt(0): a read issued one step ahead of its use
+// is then drained together with the newest ones and the prefetch distance collapses to zero.  The reads and their
+// COUNTED waits are therefore written by hand: ds_read_b128 with a compile-time byte offset, and s_waitcnt lgkmcnt(K)
+// carrying the registers it makes valid as in/out operands so that no use can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int K>
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(K));
+}
+
+// One (channel, window row) step of a chunk, ST = 0 .. CK*NI-1, recursively unrolled (the offsets must be immediates).
+template <class G, int I0, int I1, int ST>
+__device__ __forceinline__ void corr7_steps(f32x4 (&wq)[G::CK * (I1 - I0)][3], f32x4 (&xq)[G::CK], float (&acc)[4][(I1 - I0) * 7],
+                                            unsigned ya, unsigned xa) {
+    constexpr int NI = I1 - I0, NSTEP = G::CK * NI, PF = G::PF;
+    constexpr int YROW = G::YQ * 16, YCH = G::YR * G::YQ * 16, XCH = G::TR * G::XQ * 16;
+    if constexpr (ST == 0) {          // pipeline fill: steps 0 .. PF-1 (+ the x quad of channel 0)
+        lds_read128<0>(xq[0], xa);
+        lds_read128<I0 * YROW>(wq[0][0], ya);
+        lds_read128<I0 * YROW + 16>(wq[0][1], ya);
+        lds_read128<I0 * YROW + 32>(wq[0][2], ya);
+        if constexpr (PF >= 2 && NSTEP > 1) {
+            constexpr int o = (1 / NI) * YCH + (I0 + 1 % NI) * YROW;
+            if constexpr (1 % NI == 0) lds_read128<(1 / NI) * XCH>(xq[1 / NI], xa);
+            lds_read128<o>(wq[1][0], ya); lds_read128<o + 16>(wq[1][1], ya); lds_read128<o + 32>(wq[1][2], ya);
+        }
+        if constexpr (PF >= 3 && NSTEP > 2) {
+            constexpr int o = (2 / NI) * YCH + (I0 + 2 % NI) * YROW;
+            if constexpr (2 % NI == 0) lds_read128<(2 / NI) * XCH>(xq[2 / NI], xa);
+            lds_read128<o>(wq[2][0], ya); lds_read128<o + 16>(wq[2][1], ya); lds_read128<o + 32>(wq[2][2], ya);
+        }
+    }
+    constexpr int S2 = ST + PF;       // the step whose reads are issued now
+    if constexpr (S2 < NSTEP) {
+        constexpr int o = (S2 / NI) * YCH + (I0 + S2 % NI) * YROW;
+        if constexpr (S2 % NI == 0) lds_read128<(S2 / NI) * XCH>(xq[S2 / NI], xa);
+        lds_read128<o>(wq[S2][0], ya); lds_read128<o + 16>(wq[S2][1], ya); lds_read128<o + 32>(wq[S2][2], ya);
+    }
+    // reads issued after those of step ST: steps ST+1 .. min(ST+PF, NSTEP-1), 3 each + 1 for a step that opens a channel
+    constexpr int LAST = S2 < NSTEP ? S2 : NSTEP - 1;
+    constexpr int NEWER = 3 * (LAST - ST) + (LAST / NI - ST / NI);
+    constexpr int ch = ST / NI, r = ST % NI;
+    lds_wait<NEWER>(wq[ST][0], wq[ST][1], wq[ST][2], xq[ch]);
+    const f32x4 w0 = wq[ST][0], w1 = wq[ST][1], w2 = wq[ST][2], xv = xq[ch];
+    // element e = d+j+1 of the 12-float window, picked straight out of the three quads (an intermediate float[12] makes
+    // the optimiser re-load the window from the wq array with overlapping 48-byte loads, which pins wq in scratch)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int e = d + j + 1;
+            const float yv = e < 4 ? w0[e & 3] : (e < 8 ? w1[e & 3] : w2[e & 3]);
+            acc[d][r * 7 + j] = fmaf(xv[d], yv, acc[d][r * 7 + j]);
+        }
+    if constexpr (G::SB) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ST + 1 < NSTEP) corr7_steps<G, I0, I1, ST + 1>(wq, xq, acc, ya, xa);
+}
+
+// One wavefront = one 16-row strip x one 16-column block of the tile x one group of window rows I0..I1-1 (4 px x 7 x
+// (I1-I0) accumulators per lane).  Splitting the 49 taps over NG wavefronts divides the register footprint (3 or 4
+// instead of 2 wavefronts per SIMD); all groups read the same LDS tile, so the DMA traffic is unchanged.
+template <class G, int I0, int I1>
+__device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave,
+                                            int strip, int cb, int lane, int nchunks, size_t HW,
+                                            float* __restrict__ out, int n, int row0, int c0, int H, int W, int trv) {
+    constexpr int NI = I1 - I0, NS = G::NS, CK = G::CK, PF = G::PF, DBG = G::DBG, TR = G::TR;
     // every wave issues exactly PPW DMA instructions per chunk, so that the counted vmcnt below is uniform
     auto issue = [&](int chunk, int buf) {
         const size_t cbase = (size_t)chunk * CK * HW;
@@ -62,7 +166,8 @@ __device__ __forceinline__ void corr7_strip(f32x4 (*smem)[Geo<TR>::BUF_SLOTS], c
             const int pi = wave + G::NW * i;
             const float* base = (pi < G::Y_PIECES ? yn : xn) + cbase;
             const float* src = off[i] >= 0 ? base + off[i] : rfx_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&smem[buf][pi * 64]), 16, 0, 0);
+            if (!G::ZM || off[i] != -1)   // ZM: lanes of pre-zeroed slots are masked off (no fetch, no LDS write)
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
         }
     };
     float acc[4][NI * 7];
@@ -72,37 +177,57 @@ __device__ __forceinline__ void corr7_strip(f32x4 (*smem)[Geo<TR>::BUF_SLOTS], c
         for (int q = 0; q < NI * 7; ++q) acc[d][q] = 0.f;
     const int tc = lane >> 4;
     const int tr = strip * 16 + (lane & 15);
+    const int yoff = tr * G::YQ + cb * 4 + tc;        // slot of (row tr, this lane's first window quad) in a channel's y tile
+    const int xoff = tr * G::XQ + cb * 4 + tc;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;   // LDS byte address of the ring
 
-    issue(0, 0);
-    if (nchunks > 1) issue(1, 1);
+    // prologue: chunks 0 .. NS-2 in flight
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nchunks) issue(p, p);
     int buf = 0;
     for (int s = 0; s < nchunks; ++s) {
-        // chunk s must have landed; chunk s+1 (PPW DMAs of this wave) may stay in flight across the barrier
-        if (s + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk s must have landed; the (up to NS-2) younger chunks of this wave may stay in flight across the barrier
+        const int younger = DBG == 2 ? (s < NS - 1 ? NS - 2 - s : 0) : (nchunks - 1 - s < NS - 2 ? nchunks - 1 - s : NS - 2);
+        switch (younger) {   // wave-uniform; the immediate of s_waitcnt must be a constant
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PPW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G::PPW) : "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();  // all waves: chunk s visible, and everyone is done reading buffer (s-1)%NS
-        if (s + 2 < nchunks) issue(s + 2, buf == 0 ? 2 : buf - 1);  // (s+2)%NS == (s-1)%NS
-        const f32x4* yb = &smem[buf][0];
-        const f32x4* xb = &smem[buf][G::Y_PIECES * 64];
+        if (DBG != 2 && s + NS - 1 < nchunks) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);  // (s+NS-1)%NS == (s-1)%NS
+        if (DBG == 1) { buf = buf == NS - 1 ? 0 : buf + 1; continue; }   // experiments: DMA only
+        if constexpr (PF > 0) {
+            // hand-pipelined LDS reads (see lds_read128): byte addresses of this lane's first window quad / x quad
+            const unsigned ya = lds_base + (unsigned)(buf * G::BUF_SLOTS + yoff) * 16u;
+            const unsigned xa = lds_base + (unsigned)(buf * G::BUF_SLOTS + G::Y_PIECES * 64 + xoff) * 16u;
+            f32x4 wq[CK * NI][3];
+            f32x4 xq[CK];
+            corr7_steps<G, I0, I1, 0>(wq, xq, acc, ya, xa);
+        } else {
+            const f32x4* yb = smem + buf * G::BUF_SLOTS + yoff;
+            const f32x4* xb = smem + buf * G::BUF_SLOTS + G::Y_PIECES * 64 + xoff;
 #pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            const f32x4 xv = xb[ch * (TR * 4) + tr * 4 + tc];
+            for (int ch = 0; ch < CK; ++ch) {
+                const f32x4 xv = xb[ch * (TR * G::XQ)];
 #pragma unroll
-            for (int i = I0; i < I1; ++i) {
-                const f32x4* yrow = yb + ch * (G::YR * YQ) + (tr + i) * YQ + tc;
-                const f32x4 w0 = yrow[0], w1 = yrow[1], w2 = yrow[2];
-                const float yw[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+                for (int i = I0; i < I1; ++i) {
+                    const f32x4* yrow = yb + ch * (G::YR * G::YQ) + i * G::YQ;
+                    const f32x4 w0 = yrow[0], w1 = yrow[1], w2 = yrow[2];
+                    const float yw[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
+                    for (int d = 0; d < 4; ++d)
 #pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        acc[d][(i - I0) * 7 + j] = fmaf(xv[d], yw[d + j + 1], acc[d][(i - I0) * 7 + j]);
+                        for (int j = 0; j < 7; ++j)
+                            acc[d][(i - I0) * 7 + j] = fmaf(xv[d], yw[d + j + 1], acc[d][(i - I0) * 7 + j]);
+                }
             }
         }
         buf = buf == NS - 1 ? 0 : buf + 1;
     }
-    const int gr = row0 + tr, gc = c0 + 4 * tc;
-    if (gr < H && gc < W) {
+    const int gr = row0 + tr, gc = c0 + cb * TC + 4 * tc;
+    if (tr < trv && gr < H && gc < W) {
         float* o = out + (size_t)n * 49 * HW + (size_t)gr * W + gc;
 #pragma unroll
         for (int q = 0; q < NI * 7; ++q) {
@@ -112,12 +237,12 @@ __device__ __forceinline__ void corr7_strip(f32x4 (*smem)[Geo<TR>::BUF_SLOTS], c
     }
 }
 
-template <int TR>
-__global__ __launch_bounds__(TR * 8, 3) void corr7_dma_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                              float* __restrict__ out, int N, int C, int H, int W,
-                                                              int tilesR, int tilesC) {
-    using G = Geo<TR>;
-    __shared__ __attribute__((aligned(16))) f32x4 smem[NS][G::BUF_SLOTS];
+template <class G>
+__global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int C, int H, int W,
+    int tilesR, int tilesC, int trv) {
+    constexpr int TR = G::TR, NCB = G::NCB, NG = G::NG;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[G::NS * G::BUF_SLOTS];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -130,7 +255,9 @@ __global__ __launch_bounds__(TR * 8, 3) void corr7_dma_kernel(const float* __res
     }
     const int n = bid / tpi;
     const int tile = bid - n * tpi;
-    const int row0 = (tile / tilesC) * TR, c0 = (tile % tilesC) * TC;
+    // trv <= TR rows of the tile are real (H is split into equal tiles: 60 rows = 4 x 15, so that every workgroup streams
+    // the same amount of data; the last lanes of a strip idle instead of one workgroup in four being 25% short)
+    const int row0 = (tile / tilesC) * trv, c0 = (tile % tilesC) * (TC * NCB);
     const size_t HW = (size_t)H * W;
     const float* xn = x + (size_t)n * C * HW;
     const float* yn = y + (size_t)n * C * HW;
@@ -144,32 +271,62 @@ __global__ __launch_bounds__(TR * 8, 3) void corr7_dma_kernel(const float* __res
         if (pi < G::Y_PIECES) {
             const int s = pi * 64 + lane;
             if (s < G::Y_SLOTS) {
-                const int ch = s / (G::YR * YQ), rem = s - ch * (G::YR * YQ);
-                const int rr = rem / YQ, q = rem - rr * YQ;
+                const int ch = s / (G::YR * G::YQ), rem = s - ch * (G::YR * G::YQ);
+                const int rr = rem / G::YQ, q = rem - rr * G::YQ;
                 const int gr = row0 + rr - 3, gc = c0 - 4 + 4 * q;
-                if ((unsigned)gr < (unsigned)H && (unsigned)gc < (unsigned)W) o = (int)(ch * HW) + gr * W + gc;
+                if (rr < trv + 6 && (unsigned)gr < (unsigned)H && (unsigned)gc < (unsigned)W) o = (int)(ch * HW) + gr * W + gc;
             }
         } else if (pi < G::Y_PIECES + G::X_PIECES) {
             const int s = (pi - G::Y_PIECES) * 64 + lane;
-            const int ch = s / (TR * 4), rem = s - ch * (TR * 4);
-            const int rr = rem / 4, q = rem - rr * 4;
-            const int gr = row0 + rr, gc = c0 + 4 * q;
-            if (gr < H && gc < W) o = (int)(ch * HW) + gr * W + gc;
+            if (s < G::X_SLOTS) {
+                const int ch = s / (TR * G::XQ), rem = s - ch * (TR * G::XQ);
+                const int rr = rem / G::XQ, q = rem - rr * G::XQ;
+                const int gr = row0 + rr, gc = c0 + 4 * q;
+                if (q < 4 * NCB && rr < trv && gr < H && gc < W) o = (int)(ch * HW) + gr * W + gc;
+            }
+        }
+        if (G::ZM) {
+            // a piece none of whose lanes fetches image data still has to be ISSUED (every wave issues exactly PPW
+            // pieces per chunk: the vmcnt arithmetic counts on it): lane 0 alone keeps it alive, reading the zero block
+            if (__ballot(o >= 0) == 0ull && lane == 0) o = -2;
         }
         off[i] = o;
     }
-    const int strip = wave >> 1;
-    if ((wave & 1) == 0)
-        corr7_strip<TR, 0, 4>(smem, xn, yn, off, wave, strip, lane, C / CK, HW, out, n, row0, c0, H, W);
-    else
-        corr7_strip<TR, 4, 7>(smem, xn, yn, off, wave, strip, lane, C / CK, HW, out, n, row0, c0, H, W);
+    if (G::ZM) {
+        // zero the out-of-image / padding slots of every ring buffer ONCE: the DMA never writes them again
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i)
+            if (off[i] < 0) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < G::NS; ++b) smem[b * G::BUF_SLOTS + (wave + G::NW * i) * 64 + lane] = z;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw s_barrier of the main loop does not wait for ds_write
+    }
+    int sc = wave / NG, grp = wave - sc * NG;
+    if constexpr (G::BALANCED) {
+        constexpr unsigned long long gmap = []() { unsigned long long m = 0; for (int w = 0; w < G::NW; ++w) m |= (unsigned long long)G::wave_group(w) << (2 * w); return m; }();
+        constexpr unsigned long long bmap = []() { unsigned long long m = 0; for (int w = 0; w < G::NW; ++w) m |= (unsigned long long)G::wave_block(w) << (4 * w); return m; }();
+        grp = (int)((gmap >> (2 * wave)) & 3);
+        sc = (int)((bmap >> (4 * wave)) & 15);
+    }
+    const int strip = sc / NCB, cb = sc - strip * NCB;
+    const int nch = C / G::CK;
+#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, strip, cb, lane, nch, HW, out, n, row0, c0, H, W, trv)
+    if (G::PRIO && grp == 0) __builtin_amdgcn_s_setprio(1);   // the 4-/3-row group has the most FMAs per chunk: let it win VALU arbitration
+    if (grp == 0) RFX_STRIP(0);
+    else if (grp == 1) RFX_STRIP(1);
+    if constexpr (NG > 2) { if (grp == 2) RFX_STRIP(2); }
+    if constexpr (NG > 3) { if (grp == 3) RFX_STRIP(3); }
+#undef RFX_STRIP
 }
 
-template <int TR>
-static void launch_corr(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st) {
-    const int tilesR = (H + TR - 1) / TR, tilesC = (W + TC - 1) / TC;
-    hipLaunchKernelGGL((corr7_dma_kernel<TR>), dim3((unsigned)(N * tilesR * tilesC)), dim3(TR * 8), 0, st, x, y, out, N, C,
-                       H, W, tilesR, tilesC);
+template <class G>
+static void launch_corr(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st, bool even = false) {
+    const int tilesR = (H + G::TR - 1) / G::TR, tilesC = (W + TC * G::NCB - 1) / (TC * G::NCB);
+    const int trv = even ? (H + tilesR - 1) / tilesR : G::TR;      // equal row tiles (60 = 4 x 15) or full 16-row strips
+    hipLaunchKernelGGL((corr7_dma_kernel<G>), dim3((unsigned)(N * tilesR * tilesC)), dim3(G::NW * 64), 0, st, x, y, out, N,
+                       C, H, W, tilesR, tilesC, trv);
 }
 
 // Plain fallback for widths that are not a multiple of 4 (never hit by the reference's /8 feature maps of
@@ -196,24 +353,60 @@ __global__ __launch_bounds__(256) void corr7_plain_kernel(const float* __restric
     }
 }
 
+// Variant table (rfx_corr_neigh_variant_f32 / RFX_CORR_VARIANT; 0 = automatic).  All product variants are bit-identical.
+//   1: 64x16 tile   2: 32x16   3: 16x16          16-column tiles of round 1 (ring of 3, 2 tap groups)
+//   4: 16x80 plain (ring of 4, 2 tap groups, compiler-scheduled LDS reads)
+//   5: 16x80 TUNED  = 3 tap groups (15 waves, 128 VGPRs), hand-pipelined LDS reads one step ahead, SIMD-balanced wave map,
+//      zero slots written once + masked DMA lanes, conflict-free x rows, s_setprio for the 3-row group, equal row tiles
+//   6: as 5 with 2 tap groups (10 waves)      7: 16x48   8: 16x32   9: 32x32   (plain)
+//   21 / 22: variant 5 with the compute / the DMA removed -- WRONG RESULTS, for the roofline decomposition in
+//            scripts/ubench/corr_bench.py only (how long does each side take alone?)
+using CfgTuned = Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15>;
+static int launch_variant(int v, const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st) {
+    switch (v) {
+        case 1: launch_corr<Cfg<64, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
+        case 2: launch_corr<Cfg<32, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
+        case 3: launch_corr<Cfg<16, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
+        case 4: launch_corr<Cfg<16, 5, 2, 4>>(x, y, out, N, C, H, W, st); break;
+        case 5: launch_corr<CfgTuned>(x, y, out, N, C, H, W, st, true); break;
+        case 6: launch_corr<Cfg<16, 5, 2, 4, 2, 1, 0, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
+        case 7: launch_corr<Cfg<16, 3, 2, 4>>(x, y, out, N, C, H, W, st); break;
+        case 8: launch_corr<Cfg<16, 2, 2, 4>>(x, y, out, N, C, H, W, st); break;
+        case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
+        case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
+        case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
+        default: return RFX_E_ARG;
+    }
+    return RFX_OK;
+}
+
 }  // namespace
 
-extern "C" int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
-                                  void* stream) {
+extern "C" int rfx_corr_neigh_variant_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
+                                          int variant, void* stream) {
     if (!x || !y || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
     if (K != 7) return RFX_E_ARG;
     if ((long long)C * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
     hipStream_t st = rfx_stream(stream);
-    if (W % 4 == 0 && C % CK == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    if (W % 4 == 0 && C % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        // tile height by parallelism: enough workgroups to spread over all 256 CUs several times (the DMA ring
-        // hides latency best when other wavefronts can compute meanwhile); taller tiles amortise the 6-row halo
         const long long tc = (W + TC - 1) / TC;
-        const long long b64 = (long long)N * ((H + 63) / 64) * tc, b32 = (long long)N * ((H + 31) / 32) * tc;
         if ((long long)N * ((H + 15) / 16) * tc > 0x7fffffffLL) return RFX_E_LIMIT;
-        if (b64 >= 1024) launch_corr<64>(x, y, out, N, C, H, W, st);
-        else if (b32 >= 1024) launch_corr<32>(x, y, out, N, C, H, W, st);
-        else launch_corr<16>(x, y, out, N, C, H, W, st);
+        int v = variant;
+        if (v == 0) {
+            // Tile shape by traffic first, parallelism second.  A tile spanning the image width has no column halo and
+            // its row-halo re-reads hit the XCD's L2 (measured: 1.00x the algorithmic bytes leave L2 at 60x80, against
+            // 1.37x for 16x16 tiles); it is taken when the launch still gives most CUs a workgroup.  Otherwise 16-column
+            // tiles, as tall as the workgroup count allows (>= 1024 workgroups).
+            const long long r16 = (H + 15) / 16;
+            if (W <= 80 && W > 32 && (long long)N * r16 >= 128) v = 5;
+            else {
+                const long long b64 = (long long)N * ((H + 63) / 64) * tc, b32 = (long long)N * ((H + 31) / 32) * tc;
+                v = b64 >= 1024 ? 1 : (b32 >= 1024 ? 2 : 3);
+            }
+        }
+        const int rc = launch_variant(v, x, y, out, N, C, H, W, st);
+        if (rc != RFX_OK) return rc;
     } else {
         const long long NP = (long long)N * H * W;
         long long g = (NP + 255) / 256;
@@ -222,4 +415,9 @@ extern "C" int rfx_corr_neigh_f32(const float* x, const float* y, float* out, in
     }
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+extern "C" int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
+                                  void* stream) {
+    return rfx_corr_neigh_variant_f32(x, y, out, N, C, H, W, K, 0, stream);
 }

@@ -351,14 +351,17 @@ def u8_to_f32(img, mean=None, std=None, want_raw=True):
     return raw, norm
 
 
-def corr_neigh(x, y, K=7):
+def corr_neigh(x, y, K=7, variant=None):
+    """``variant``: force a tile shape of rfx_corr_neigh_variant_f32 (tuning / tests); default = RFX_CORR_VARIANT or
+    the library's automatic choice.  All variants are bit-identical."""
     x, y = _dev(x, "corr x"), _dev(y, "corr y")
     if x.shape != y.shape:
         raise ValueError("corr_neigh: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
     N, C, H, W = x.shape
     out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
     e0 = Profiler.begin()
-    _call("rfx_corr_neigh_f32", _one_device(x, y), _p(x), _p(y), _p(out), N, C, H, W, K)
+    v = int(os.environ.get("RFX_CORR_VARIANT", "0")) if variant is None else int(variant)
+    _call("rfx_corr_neigh_variant_f32", _one_device(x, y), _p(x), _p(y), _p(out), N, C, H, W, K, v)
     if e0 is not None:
         Profiler.active().corr.append(((2 * C + K * K) * 4.0 * N * H * W, e0, Profiler.end(e0)))  # algorithmic bytes (SURVEY.md 8d)
     return out

@@ -134,6 +134,25 @@ def test_corr_neigh_matches_cpu(dev, shape):
     assert same[0, 0, 0, 0] == 0                                     # zero padding
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 60, 80), (3, 16, 33, 44), (2, 8, 70, 100), (2, 8, 16, 48), (1, 8, 7, 32)])
+def test_corr_neigh_tile_variants_are_bit_identical(dev, shape):
+    """Every kernel configuration of rfx_corr_neigh_variant_f32 (16/32/64-row x 16-column tiles, full-width 16 x 80 plain
+    and tuned -- 3 / 2 tap groups, hand-pipelined LDS reads, masked DMA, equal row tiles --, 16x48, 16x32, 32x32)
+    accumulates each output in channel order -> bit-identical results, including on maps that are narrower / wider than
+    the tile and ragged in both directions; an unknown variant is refused."""
+    g = torch.Generator().manual_seed(shape[3])
+    x = F.normalize(torch.randn(*shape, generator=g), dim=1).to(dev)
+    y = F.normalize(torch.randn(*shape, generator=g), dim=1).to(dev)
+    ref = restate.corr_neigh(x.cpu(), y.cpu())
+    base = ops.corr_neigh(x, y, variant=3)
+    assert (base.cpu() - ref).abs().max() < 1e-5
+    for v in (0, 1, 2, 4, 5, 6, 7, 8, 9):
+        assert torch.equal(ops.corr_neigh(x, y, variant=v), base), v
+    from rfx import _lib
+    with pytest.raises(_lib.RfxError):
+        ops.corr_neigh(x, y, variant=77)
+
+
 def test_corr_neigh_golden(dev):
     g = gold("nets.npz")
     out = ops.corr_neigh(torch.from_numpy(g["fine_fa"]).to(dev), torch.from_numpy(g["fine_fb"]).to(dev)).cpu()
