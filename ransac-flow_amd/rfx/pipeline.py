@@ -146,10 +146,11 @@ class AlignPipeline:
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
-    def coarse(self, prep, feats=None, samples=None, maskB=None):
+    def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None):
         """Per pair: mutual NN -> matches -> RANSAC.  ``samples``: optional list of (nbIter,4) int64 CPU tensors
-        (explicit index draw); default = torch.randint on the CPU generator per pair, in pair order, which is
-        what utils/outil.py:120 draws on a CPU run.  Returns a list of per-pair dicts (device tensors)."""
+        (explicit index draw), or ``sample_fn(b, nMatch, nbIter)`` -> such a tensor; default = torch.randint on the
+        CPU generator per pair, in pair order, which is what utils/outil.py:120 draws on a CPU run.  Returns a list
+        of per-pair dicts (device tensors)."""
         feats = feats or self.features(prep)
         B = prep["B"]
         lib_out = []
@@ -163,7 +164,8 @@ class AlignPipeline:
         for b in range(B):
             n = counts[b]
             if n >= 4:
-                draws.append(samples[b] if samples is not None else torch.randint(n, (self.nbIter, 4)))
+                draws.append(samples[b] if samples is not None else
+                             (sample_fn(b, n, self.nbIter) if sample_fn is not None else torch.randint(n, (self.nbIter, 4))))
             else:
                 draws.append(torch.zeros((self.nbIter, 4), dtype=torch.int64))
         if len({tuple(d.shape) for d in draws}) != 1:       # explicit draws of different lengths: one launch chain per pair

@@ -99,11 +99,13 @@ def test_quick_start_align2images_replay(dev, launcher_env, tmp_path):
     ca.setTarget(I2)
     torch.manual_seed(7)
     r = ca.getCoarse(np.zeros((img2h, img2w)))
-    if np.array_equal(r["inlierMask"], inlierMask):
-        assert np.abs(r["H"] - bestPrm).max() <= 1e-6
+    # END TO END, no escape hatch: the oracle runs on ITS OWN homography.  On this pair the drop-in's match list is the
+    # oracle's (checked through what the API exposes: the inlier mask and H), so RANSAC is bit-identical.
+    assert np.array_equal(r["inlierMask"], inlierMask)
+    assert np.abs(r["H"] - bestPrm).max() <= 1e-6
     with torch.no_grad():
         st = restate.fine_step_quickstart(dict(feat=sds["netFeatCoarse"], flow=sds["netFlowCoarse"]), ca.IsTensor,
-                                          ca.ItTensor, restate.warp_grid(torch.from_numpy(bestPrm)[None], img2h, img2w))
+                                          ca.ItTensor, restate.warp_grid(torch.from_numpy(r["H"])[None], img2h, img2w))
     assert (st["flow12"] - flow12.cpu()).abs().max() < 1e-3
     assert (st["img1_fine"] - img1_fine.cpu()).abs().max() < 2e-3
     # sentinel: everything masked -> fewer than 4 matches -> (None, [])
@@ -112,7 +114,14 @@ def test_quick_start_align2images_replay(dev, launcher_env, tmp_path):
     # predFlowCoarse / predMatchability API (model/model.py:331-357)
     fg, fc = model.predFlowCoarse(corr12, network["netFlowCoarse"], grid, True)
     og, oc = restate.pred_flow_coarse(sds["netFlowCoarse"], st["corr12"], restate.identity_grid(img2h, img2w), True)
-    assert fg.shape == og.shape and (fc.cpu() - oc).abs().max() < 1e-3
+    assert fg.shape == og.shape == (1, 1, img2h - 1, img2w - 1) and (fc.cpu() - oc).abs().max() < 1e-3
+    assert (fg.cpu() - og).abs().max() < 1e-4                       # flowGrad VALUES (model/model.py:335-336), not just its shape
+    assert float(fc.max()) <= 1.0 and float(fc.min()) >= -1.0       # the clamp of :338
+    nc = model.predFlowCoarseNoGrad(corr12, network["netFlowCoarse"], grid, True)        # model/model.py:342-351: flow only
+    assert isinstance(nc, torch.Tensor) and torch.equal(nc, fc) and not nc.requires_grad
+    fg4, fc4 = model.predFlowCoarse(corr12, network["netFlowCoarse"], F.interpolate(grid.permute(0, 3, 1, 2), size=corr12.shape[2:],
+                                    mode="bilinear").permute(0, 2, 3, 1), False)          # up8X=False branch
+    assert fc4.shape == (1, corr12.shape[2], corr12.shape[3], 2) and fg4.shape[2:] == (corr12.shape[2] - 1, corr12.shape[3] - 1)
     m = model.predMatchability(corr12, network["netMatch"], True)
     assert (m.cpu() - restate.net_matchability(sds["netMatch"], st["corr12"], True)).abs().max() < 1e-4
 
@@ -195,3 +204,32 @@ def test_eval_hpatch_multi_homography_replay(dev, launcher_env, tmp_path):
     assert np.abs(Hs[0] - o["H"][0]).max() < 1e-5
     assert np.abs(fds[0] - o["flowDown8"][0]).max() < 1e-3
     assert len(Hs) == len(o["H"])
+
+
+def test_coarse_align_variant_c_yfcc(dev, launcher_env):
+    """Variant C (evaluation/evalYFCC/coarseAlignFeatMatch.py:35-196): its own argument order with ``use_cuda``, setSource /
+    setTarget, per-call mutual NN, (H, InlierMask) return -- same results as variant A given ResizeMinSize semantics and
+    the same index draw; ``use_cuda=False`` is refused (the reference's CPU path is broken by utils/outil.py:86)."""
+    os.environ["RFX_COARSE_VARIANT"] = "C"
+    launcher = importlib.import_module("run_reference_script")
+    launcher.setup("/x/RANSAC-Flow/evaluation/evalYFCC/evaluation.py")
+    import coarseAlignFeatMatch as cam
+    assert cam.CoarseAlign.__name__ == "CoarseAlignC"
+    trunk_sd = weights.resnet50_trunk_sd(0)
+    # (nbScale, nbIter, tolerance, transform, minSize, segId=1, segFg=True, use_cuda=True, imageNet=True, segNet=True, scaleR=2)
+    cm = cam.CoarseAlign(3, 300, 0.05, "Homography", 240, 1, True, True, True, False, 1.2, trunk_state_dict=trunk_sd)
+    I1, I2 = synth.make_pair(240, 320, seed=12)
+    cm.setSource(I1)
+    cm.setTarget(I2)
+    assert cm.It.size == (320, 240) and cm.featt.shape == (1, 1024, 15, 20)
+    torch.manual_seed(21)
+    Hc, mask = cm.getCoarse(np.zeros((240, 320)))
+    assert Hc.dtype == np.float32 and mask.shape == (15, 20) and mask.sum() >= 4
+    ca = restate.CoarseAlignOracle(trunk_sd, 3, 300, 0.05, 240, 1.2, variant="B")      # ResizeMinSize like C
+    ca.setPair(I1, I2)
+    torch.manual_seed(21)
+    r = ca.getCoarse(np.zeros((240, 320), dtype=np.float32))
+    assert np.abs(r["H"] - Hc).max() <= 1e-6
+    assert cm.getCoarse(np.ones((240, 320)))[0] is None
+    with pytest.raises(Exception):
+        cam.CoarseAlign(3, 300, 0.05, "Homography", 240, 1, True, False, True, False, 1.2, trunk_state_dict=trunk_sd)

@@ -39,20 +39,23 @@ def test_config1_against_reference_golden(dev):
     r = pipe.align_prepared(prep, fine=True)[0]
     ndiff, nref = _match_sets(r["index1"].cpu().numpy(), r["index2"].cpu().numpy(), g["index1"], g["index2"])
     print("config1: %d matches, %d differ from the reference" % (nref, ndiff))
-    assert ndiff <= max(2, nref // 50)
-    if ndiff == 0:
-        # identical match list + identical index draw -> bit-exact inliers, H to float32 round-off
-        assert r["status"] == 0
-        inl = r["inlier"].cpu().numpy()
-        i2 = r["index2"].cpu().numpy()[inl]
-        mask = np.zeros((15, 20), dtype=np.float32)
-        mask[i2 // 20, i2 % 20] = 1
-        assert np.array_equal(mask, g["inlierMask"])
-        assert np.abs(r["H"].cpu().numpy() - g["H"]).max() <= 1e-6
-        assert np.abs(r["flowDown"].cpu().numpy() - g["flowDown"]).max() < 1e-4
-        d = np.abs(r["flow12"][:, ::8, ::8].cpu().numpy() - g["flow12_sub"]).max()
-        print("config1: max-abs flow delta vs reference = %.3e" % d)
-        assert d < 1e-3                                                               # north-star tolerance
+    # no escape hatch: on this pair the device's match list IS the reference's (a flip here is a regression to look at;
+    # full-size pairs, where float near-ties do flip matches, are covered by tests/test_gpu_parity_sweep.py with a proof
+    # obligation per flipped match)
+    assert ndiff == 0
+    assert np.array_equal(r["index1"].cpu().numpy(), g["index1"]) and np.array_equal(r["index2"].cpu().numpy(), g["index2"])
+    # identical match list + identical index draw -> bit-exact inliers, H to float32 round-off
+    assert r["status"] == 0
+    inl = r["inlier"].cpu().numpy()
+    i2 = r["index2"].cpu().numpy()[inl]
+    mask = np.zeros((15, 20), dtype=np.float32)
+    mask[i2 // 20, i2 % 20] = 1
+    assert np.array_equal(mask, g["inlierMask"])
+    assert np.abs(r["H"].cpu().numpy() - g["H"]).max() <= 1e-6
+    assert np.abs(r["flowDown"].cpu().numpy() - g["flowDown"]).max() < 1e-4
+    d = np.abs(r["flow12"][:, ::8, ::8].cpu().numpy() - g["flow12_sub"]).max()
+    print("config1: max-abs flow delta vs reference = %.3e" % d)
+    assert d < 1e-3                                                                   # north-star tolerance
 
 
 def test_fine_stage_against_oracle_given_same_homography(dev):
