@@ -179,11 +179,13 @@ int rfx_grid_sample_f32(const float* in, const float* grid, float* out, int N, i
 /* Fused fine-flow composition (quick_start/align2images.py:92-95;
  * evaluation/evalHpatch/evaluation.py:40-45,51): up-sample flowDown (N,2,hd,wd) to (H,W) with
  * align_corners=False, add the linspace identity grid, optionally clamp to [-1,1], sample the coarse
- * grid (N,H,W,2) there (bilinear, zeros, align_corners=False) -> flow12 (N,H,W,2).  If inb != NULL it
+ * grid (N,Hc,Wc,2) there (bilinear, zeros, align_corners=False) -> flow12 (N,H,W,2).  (Hc,Wc) = (H,W) everywhere except in
+ * the full-resolution pass of the KITTI driver, which composes at the ORIGINAL image size on a coarse grid of the
+ * fine-stage size (evaluation/evalKITTI/evaluation.py:302 with :49-81).  If inb != NULL it
  * receives the in-bounds mask (N,H,W) = (-1<=fx<=1)&(-1<=fy<=1) as 0/1 floats; if flowUp != NULL it
  * receives the (clamped) sampling grid (N,H,W,2). */
 int rfx_compose_flow_f32(const float* flowDown, const float* coarseGrid, float* flow12, float* inb,
-                         float* flowUp, int N, int hd, int wd, int H, int W, int clamp, void* stream);
+                         float* flowUp, int N, int hd, int wd, int Hc, int Wc, int H, int W, int clamp, void* stream);
 
 /* Multi-homography merge of the offline flow assembly (evaluation/evalHpatch/getResults.py:48-61,
  * evaluation/evalCorr/getResults.py:121-134, evaluation/evalKITTI/getResults.py:126-138).

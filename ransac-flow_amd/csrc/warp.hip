@@ -105,9 +105,9 @@ __device__ __forceinline__ float src_index(float scale, int dst) {  // align_cor
 __global__ __launch_bounds__(256) void compose_flow_kernel(const float* __restrict__ flowDown,
                                                            const float* __restrict__ coarse, float* __restrict__ flow12,
                                                            float* __restrict__ inb, float* __restrict__ flowUp,
-                                                           long long NP, int hd, int wd, int H, int W, float sh, float sw,
-                                                           int clampf) {
-    const size_t HW = (size_t)H * W, hw = (size_t)hd * wd;
+                                                           long long NP, int hd, int wd, int Hc, int Wc, int H, int W,
+                                                           float sh, float sw, int clampf) {
+    const size_t HW = (size_t)H * W, hw = (size_t)hd * wd, HWc = (size_t)Hc * Wc;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < NP;
          p += (long long)gridDim.x * blockDim.x) {
         const long long n = p / (long long)HW;
@@ -135,15 +135,16 @@ __global__ __launch_bounds__(256) void compose_flow_kernel(const float* __restri
             float2 o; o.x = gx; o.y = gy;
             reinterpret_cast<float2*>(flowUp)[p] = o;
         }
-        // sample the coarse grid (N,H,W,2 == 2 channels interleaved) at (gx, gy)
-        const Corners c = corners(gx, gy, H, W, 0);
-        const float2* cg = reinterpret_cast<const float2*>(coarse) + (size_t)n * HW;
-        const long long o00 = (long long)c.y0 * W + c.x0;
+        // sample the coarse grid (N,Hc,Wc,2 == 2 channels interleaved; Hc x Wc = H x W except in the KITTI driver's
+        // full-resolution pass, evaluation/evalKITTI/evaluation.py:302) at (gx, gy)
+        const Corners c = corners(gx, gy, Hc, Wc, 0);
+        const float2* cg = reinterpret_cast<const float2*>(coarse) + (size_t)n * HWc;
+        const long long o00 = (long long)c.y0 * Wc + c.x0;
         float ox = 0.f, oy = 0.f;
         if (c.m_nw) { const float2 v = cg[o00]; ox += v.x * c.nw; oy += v.y * c.nw; }
         if (c.m_ne) { const float2 v = cg[o00 + 1]; ox += v.x * c.ne; oy += v.y * c.ne; }
-        if (c.m_sw) { const float2 v = cg[o00 + W]; ox += v.x * c.sw; oy += v.y * c.sw; }
-        if (c.m_se) { const float2 v = cg[o00 + W + 1]; ox += v.x * c.se; oy += v.y * c.se; }
+        if (c.m_sw) { const float2 v = cg[o00 + Wc]; ox += v.x * c.sw; oy += v.y * c.sw; }
+        if (c.m_se) { const float2 v = cg[o00 + Wc + 1]; ox += v.x * c.se; oy += v.y * c.se; }
         float2 o; o.x = ox; o.y = oy;
         reinterpret_cast<float2*>(flow12)[p] = o;
         if (inb) inb[p] = (ox >= -1.0f && ox <= 1.0f && oy >= -1.0f && oy <= 1.0f) ? 1.0f : 0.0f;
@@ -222,12 +223,14 @@ extern "C" int rfx_grid_sample_f32(const float* in, const float* grid, float* ou
 }
 
 extern "C" int rfx_compose_flow_f32(const float* flowDown, const float* coarseGrid, float* flow12, float* inb,
-                                    float* flowUp, int N, int hd, int wd, int H, int W, int clamp, void* stream) {
-    if (!flowDown || !coarseGrid || !flow12 || N <= 0 || hd <= 0 || wd <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
+                                    float* flowUp, int N, int hd, int wd, int Hc, int Wc, int H, int W, int clamp,
+                                    void* stream) {
+    if (!flowDown || !coarseGrid || !flow12 || N <= 0 || hd <= 0 || wd <= 0 || Hc <= 0 || Wc <= 0 || H <= 0 || W <= 0)
+        return RFX_E_ARG;
     const long long NP = (long long)N * H * W;
     const float sh = (float)hd / (float)H, sw = (float)wd / (float)W;
     hipLaunchKernelGGL(compose_flow_kernel, dim3(grid_for(NP, 256)), dim3(256), 0, rfx_stream(stream), flowDown,
-                       coarseGrid, flow12, inb, flowUp, NP, hd, wd, H, W, sh, sw, clamp);
+                       coarseGrid, flow12, inb, flowUp, NP, hd, wd, Hc, Wc, H, W, sh, sw, clamp);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -387,15 +387,18 @@ def grid_sample(inp, grid, align_corners=False):
     return out
 
 
-def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up=False):
+def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up=False, out_hw=None):
+    """flow12 = grid_sample(coarseGrid, [clamp](upsample(flowDown) + identity grid)).  ``out_hw``: output resolution when
+    it differs from the coarse grid's (KITTI full-resolution pass); default = the coarse grid's."""
     flowDown, coarseGrid = _dev(flowDown, "flowDown"), _dev(coarseGrid, "coarse grid")
     N, two, hd, wd = flowDown.shape
-    _, H, W, _ = coarseGrid.shape
+    _, Hc, Wc, _ = coarseGrid.shape
+    H, W = (Hc, Wc) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
     flow12 = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device)
     inb = torch.empty((N, H, W), dtype=torch.float32, device=flowDown.device) if want_inb else None
     fup = torch.empty((N, H, W, 2), dtype=torch.float32, device=flowDown.device) if want_flow_up else None
-    _call("rfx_compose_flow_f32", _one_device(flowDown, coarseGrid), _p(flowDown), _p(coarseGrid), _p(flow12), _p(inb), _p(fup), N, hd, wd,
-                                               H, W, 1 if clamp else 0)
+    _call("rfx_compose_flow_f32", _one_device(flowDown, coarseGrid), _p(flowDown), _p(coarseGrid), _p(flow12), _p(inb), _p(fup),
+          N, hd, wd, Hc, Wc, H, W, 1 if clamp else 0)
     return flow12, inb, fup
 
 

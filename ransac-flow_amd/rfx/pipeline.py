@@ -52,6 +52,25 @@ def cell_coords(n_rows, n_cols, device):
     return (W - 0.5) * 2, (Hh - 0.5) * 2
 
 
+def _remove_small_cc_scipy(match, match_th, cc_th):
+    """evaluation/evalKITTI/evaluation.py:85-100 on the host, as in the reference (skimage.measure.label there; scipy's
+    labelling with a full 3x3 structure = the same 8-connected components): zero every component of (match > match_th)
+    whose area fraction is <= cc_th."""
+    from scipy import ndimage
+    if cc_th == 0:
+        return match
+    lab, n = ndimage.label(match > match_th, structure=np.ones((3, 3), dtype=np.int32))
+    if n == 0:
+        return match
+    area = np.bincount(lab.ravel(), minlength=n + 1) / float(lab.size)
+    small = np.flatnonzero(area <= cc_th)
+    small = small[small != 0]
+    if small.size:
+        match = match.copy()
+        match[np.isin(lab, small)] = 0
+    return match
+
+
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
                  device="cuda", kernelSize=7):
@@ -254,9 +273,11 @@ class AlignPipeline:
         return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
                     match21Down8=match21Down8)
 
-    def pred_flow_mask_kitti(self, IsSample, ItSample, flowCoarse):
+    def pred_flow_mask_kitti(self, IsSample, ItSample, flowCoarse, out_hw=None):
         """evaluation/evalKITTI/evaluation.py:49-81: both images go through the FeatureExtractor here, and the
-        matchability is cycle-checked: match = match12 * grid_sample(match21, flowUp) * in-bounds(flow12)."""
+        matchability is cycle-checked: match = match12 * grid_sample(match21, flowUp) * in-bounds(flow12).
+        ``out_hw``: resolution of the identity grid the reference passes (``grid``): the coarse grid's own by default; the
+        ORIGINAL image size in the full-resolution pass of the KITTI driver (:302), where flowCoarse has the fine size."""
         B = IsSample.shape[0]
         f = ops.l2norm(self.feat(torch.cat((IsSample, ItSample), dim=0)))
         feats, featt = f[:B], f[B:]
@@ -265,10 +286,10 @@ class AlignPipeline:
         flowDown8 = self.flow(corr12, False)
         md = self.match(c, False)
         match12Down8, match21Down8 = md[:B], md[B:]
-        H, W = flowCoarse.shape[1], flowCoarse.shape[2]
+        H, W = (flowCoarse.shape[1], flowCoarse.shape[2]) if out_hw is None else out_hw
         m = ops.resize_bilinear(md, (H, W), align_corners=False)
         match12, match21 = m[:B], m[B:]
-        flow12, inb, flowUp = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True, want_flow_up=True)
+        flow12, inb, flowUp = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True, want_flow_up=True, out_hw=(H, W))
         match = match12 * ops.grid_sample(match21, flowUp) * inb.unsqueeze(1)
         return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
                     match21Down8=match21Down8)
@@ -383,6 +404,87 @@ class AlignPipeline:
         for b in range(B):
             outs[b]["mask"] = Mask[b]
         return outs
+
+    # ---------------------------------------------------------------- KITTI two-resolution driver (BASELINE config 5)
+    @staticmethod
+    def resize_img_dims(w, h, stride, min_size):
+        """outil.resizeImg (utils/outil.py:6-19): smaller side -> min_size, each side ROUNDED to a multiple of stride."""
+        ratio = min(w / min_size, h / min_size)
+        return int(round(w / ratio / stride) * stride), int(round(h / ratio / stride) * stride)
+
+    def multi_h_kitti(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, feats=None, prep=None,
+                      sample_fn=None, remove_small_cc=None):
+        """The per-pair driver of evaluation/evalKITTI/evaluation.py:222-336 for ONE pair of raw uint8 (1,H,W,3) device
+        images (self must be a variant-B pipeline built with the KITTI coarse parameters: minSize = coarseSize 800,
+        nbScale 3, scaleR 1.2, nbIter 50 000).  Per homography: getCoarse on the cached matches filtered by the
+        explained-region mask (:273) -> homography grids at the half and the full fine resolution (:281-282) -> source
+        (ORIGINAL resolution) warped to the half resolution (:284) -> PredFlowMask there (:290) -> its /8 flow composed
+        with the full-resolution homography grid (:294-297) -> source warped by it (:299) -> PredFlowMask whose outputs live
+        at the ORIGINAL target resolution (:302) -> small-component filter on the host, like the reference's skimage call
+        (:321; ``remove_small_cc(match ndarray, 0.99, cc_th)``, default scipy 8-connectivity labelling) -> accept iff
+        ((match > 0.9999) outside the mask).mean() > maskRegionTh or first homography (:322) -> mask update (:333).
+        The loop is the reference's ``while True``: it ends on the accept test or when fewer than 4 matches survive.
+        LANCZOS resizes (outil.resizeImg) run on the device, byte-exact vs Pillow.  Host syncs per homography: match count,
+        RANSAC status + accept statistic (+ one D2H/H2D of the h_org x w_org matchability map when cc_th > 0).
+        Returns dict(H=[...], flowD2=[...], flowDown8=[...], matchDown8=[...], mask)."""
+        dev = self.dev
+        if prep is None:
+            prep = self.prepare_device(src_u8, tgt_u8)
+        feats = feats or self.features(prep)
+        h_org, w_org = tgt_u8.shape[1], tgt_u8.shape[2]
+        w_r, h_r = self.resize_img_dims(w_org, h_org, 8, fineSize)
+        w_d2, h_d2 = self.resize_img_dims(w_org, h_org, 8, fineSize // 2)
+        tensor_s, _ = ops.u8_to_f32(src_u8)                                              # source at its ORIGINAL size
+        tensor_resize, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_r, h_r))
+        tensor_d2, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_d2, h_d2))
+        i1, i2 = ops.mutual_nn(feats["featA"][0], feats["featB"][0], ldA=feats.get("ldA"), nA=feats["nA"])
+        W1, H1 = feats["WA"][i1], feats["HA"][i1]
+        W2, H2 = feats["Wt"][i2], feats["Ht"][i2]
+        rt, ct = feats["rt"], feats["ct"]
+        r2, c2 = i2 // ct, i2 % ct
+        bg = torch.ones((h_org, w_org), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        Mask = torch.zeros((h_org, w_org), dtype=torch.float32, device=dev)
+        out = dict(H=[], flowD2=[], flowDown8=[], matchDown8=[])
+        draw = sample_fn or (lambda n, it: torch.randint(n, (it, 4)))
+        if cc_th > 0 and remove_small_cc is None:
+            remove_small_cc = _remove_small_cc_scipy
+        nb = 0
+        while True:
+            fg = ((Mask + (1 - bg)) > 0.5).float()
+            keep = ops.resize_bilinear((1 - fg)[None, None], (rt, ct), align_corners=False)[0, 0] > 0.5
+            valid = keep[r2, c2]
+            n = int(valid.sum().item())                                       # sync: size of the index draw
+            if n < 4:
+                break
+            ones = torch.ones(n, dtype=torch.float32, device=dev)
+            m1 = torch.stack((H1[valid], W1[valid], ones), dim=1)
+            m2 = torch.stack((H2[valid], W2[valid], ones), dim=1)
+            bestH, _, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol)
+            hom_d2 = ops.warp_grid(bestH[None], h_d2, w_d2)
+            hom_resize = ops.warp_grid(bestH[None], h_r, w_r)
+            Is_d2 = ops.grid_sample(tensor_s, hom_d2)
+            flow_d2 = self.pred_flow_mask_kitti(Is_d2, tensor_d2, hom_d2)["flowDown8"]
+            flowCoarse, _, _ = ops.compose_flow(flow_d2, hom_resize, clamp=True)
+            IsSample = ops.grid_sample(tensor_s, flowCoarse)
+            pm = self.pred_flow_mask_kitti(IsSample, tensor_resize, flowCoarse, out_hw=(h_org, w_org))
+            match = pm["match"][0, 0]
+            if cc_th > 0:
+                match = torch.from_numpy(remove_small_cc(match.cpu().numpy(), 0.99, cc_th)).to(dev)   # host, like :321
+            stat = torch.stack((((match > 0.9999).float() * (1 - fg)).mean(), res[0].float()))
+            gain, status = stat.cpu().tolist()                                # sync: acceptance statistic + status
+            if status != 0:
+                break
+            if gain > maskRegionTh or nb == 0:
+                out["H"].append(bestH)
+                out["flowD2"].append(flow_d2)
+                out["flowDown8"].append(pm["flowDown8"])
+                out["matchDown8"].append(torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1))
+                nb += 1
+                Mask = ((Mask + match * (1 - fg)) > 0.9999).float()
+            else:
+                break
+        out["mask"] = Mask
+        return out
 
     # ---------------------------------------------------------------- whole path
     def align_prepared(self, prep, fine=True, samples=None):

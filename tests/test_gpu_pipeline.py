@@ -249,3 +249,73 @@ def test_batched_multi_homography_equals_per_pair_driver(dev):
             assert (s["flowDown8"][k] - m["flowDown8"][k]).abs().max() < 1e-4
             assert (s["matchDown8"][k] - m["matchDown8"][k]).abs().max() < 1e-4
         assert float((s["mask"] != m["mask"]).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_kitti_two_resolution_driver_matches_reference_golden(dev, tag):
+    """pipeline.multi_h_kitti (SURVEY 8f1 / BASELINE config 5) against tests/golden/kitti_loop.npz -- the outputs of the
+    reference's own ``while True`` loop (evaluation/evalKITTI/evaluation.py:270-336) with its PredFlowMask / get_info /
+    remove_small_cc / resizeImg and CoarseAlign, produced by tests/golden/make_golden.py -- and against the oracle
+    restatement run here with the same index draws.  Half-resolution features are 8 x 26 / 7 x 23: W % 4 != 0 exercises
+    the plain correlation fallback; the cc-filter (case b) runs on the host as in the reference."""
+    g = np.load(os.path.join(GOLD, "kitti_loop.npz"))
+    seed, fine, cc_th, th, draw_seed = g["%s_cfg" % tag]
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=float(g["match_std"]))
+    Is, It = synth.make_pair(96, 312, seed=int(seed), homography=True, amp=0.03)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=160, scaleR=1.2, variant="B", device=dev)
+    raw = pipe.upload_raw([(Is, It)])
+    h_org, w_org, h_r, w_r, h_d2, w_d2 = (int(x) for x in g["%s_sizes" % tag])
+    assert pipe.resize_img_dims(w_org, h_org, 8, int(fine)) == (w_r, h_r)
+    assert pipe.resize_img_dims(w_org, h_org, 8, int(fine) // 2) == (w_d2, h_d2)
+    torch.manual_seed(int(draw_seed))
+    out = pipe.multi_h_kitti(raw[0], raw[1], fineSize=int(fine), maskRegionTh=float(th), cc_th=float(cc_th))
+    nb = int(g["%s_nb" % tag])
+    assert len(out["H"]) == nb >= 2
+    Hs = torch.stack(out["H"]).cpu().numpy()
+    assert np.abs(Hs[0] - g["%s_H" % tag][0]).max() < 1e-5                      # same matches, same draw -> same first H
+    assert np.abs(torch.cat(out["flowD2"]).cpu().numpy()[0] - g["%s_flowD2" % tag][0]).max() < 1e-3
+    assert np.abs(torch.cat(out["flowDown8"]).cpu().numpy()[0] - g["%s_flowDown8" % tag][0]).max() < 1e-3
+    # later homographies depend on the mask thresholded at 0.9999 (saturating sigmoid): compare everything, tolerantly
+    assert float((out["mask"].cpu().numpy() != g["%s_mask" % tag]).mean()) < 5e-3
+    if np.abs(Hs - g["%s_H" % tag]).max() < 1e-5:
+        assert np.abs(torch.cat(out["flowDown8"]).cpu().numpy() - g["%s_flowDown8" % tag]).max() < 1e-3
+        md = torch.cat(out["matchDown8"]).cpu().numpy()
+        assert np.mean(np.abs(md - g["%s_matchDown8" % tag]) > 1e-3) < 1e-3      # sigmoid of std-3 logits amplifies round-off
+    # the oracle restatement on this host agrees with the golden too (same code path as tests/test_oracle_pins.py)
+    ca = restate.CoarseAlignOracle(sds["trunk"], 3, 300, 0.05, 160, 1.2, variant="B")
+    ca.setPair(Is, It)
+    torch.manual_seed(int(draw_seed))
+    o = restate.multi_h_loop_kitti(ca, dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]), Is, It, int(fine),
+                                   mask_region_th=float(th), cc_th=float(cc_th))
+    assert len(o["H"]) == nb and np.abs(np.stack(o["H"]) - g["%s_H" % tag]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_multi_homography_driver_matches_reference_golden(dev, tag):
+    """pipeline.multi_h / multi_h_batched against tests/golden/multi_h.npz: the outputs of the reference's own
+    ``while nbCoarse <= args.maxCoarse`` loop (evaluation/evalHpatch/evaluation.py:211-243) with its CoarseAlign-B and
+    PredFlowMask, on a homography-warped pair with a saturating matchability head (the explained-region mask grows)."""
+    g = np.load(os.path.join(GOLD, "multi_h.npz"))
+    seed, maxCoarse, th, draw_seed = g["%s_cfg" % tag]
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=float(g["match_std"]))
+    I1, I2 = synth.make_pair(240, 320, seed=int(seed), homography=True)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev)
+    prep = pipe.prepare([(I1, I2)])
+    feats = pipe.features(prep)
+    nb = int(g["%s_nb" % tag])
+    for driver in ("single", "batched"):
+        torch.manual_seed(int(draw_seed))
+        if driver == "single":
+            out = pipe.multi_h(prep, 0, maxCoarse=int(maxCoarse), maskRegionTh=float(th), feats=feats)
+        else:
+            out = pipe.multi_h_batched(prep, maxCoarse=int(maxCoarse), maskRegionTh=float(th), feats=feats)[0]
+        assert len(out["H"]) == nb, (driver, len(out["H"]), nb)
+        Hs = torch.stack(out["H"]).cpu().numpy()
+        assert np.abs(Hs[0] - g["%s_H" % tag][0]).max() < 1e-5
+        assert np.abs(out["flowDown8"][0].cpu().numpy()[0] - g["%s_flowDown8" % tag][0]).max() < 1e-3
+        assert float((out["mask"].cpu().numpy() != g["%s_mask" % tag]).mean()) < 5e-3
+        if np.abs(Hs - g["%s_H" % tag]).max() < 1e-5:
+            fd = torch.cat(out["flowDown8"]).cpu().numpy()
+            assert np.abs(fd - g["%s_flowDown8" % tag]).max() < 1e-3
