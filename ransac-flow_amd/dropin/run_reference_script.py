@@ -2,6 +2,7 @@
 """Run one of the reference's entry scripts UNCHANGED on the MI355X path.
 
     python run_reference_script.py /path/to/RANSAC-Flow/quick_start/align2images.py [script args ...]
+    RFX_REFERENCE_ROOT=/mnt/RANSAC-Flow RFX_REFERENCE_SCRIPT=quick_start/align2images.py python run_reference_script.py [args]
 
 The reference's scripts import the hot path by bare module name after ``sys.path.append`` --
 ``from coarseAlignFeatMatch import CoarseAlign`` (quick_start/align2images.py:2), ``import outil`` (:5),
@@ -161,12 +162,21 @@ def setup(script_path):
 
 
 def main():
-    if len(sys.argv) < 2:
+    # the script path comes from argv or, for harnesses that cannot pass arguments, from RFX_REFERENCE_SCRIPT (absolute, or
+    # relative to RFX_REFERENCE_ROOT -- e.g. a reference tree mounted on the GPU box); its own arguments follow
+    argv = sys.argv[1:]
+    env_script = os.environ.get("RFX_REFERENCE_SCRIPT")
+    if env_script and (not argv or argv[0].startswith("-")):
+        root = os.environ.get("RFX_REFERENCE_ROOT", "")
+        argv = [env_script if os.path.isabs(env_script) else os.path.join(root, env_script)] + argv
+    if not argv:
         print(__doc__)
         sys.exit(2)
-    script = os.path.abspath(sys.argv[1])
+    script = os.path.abspath(argv[0])
+    if not os.path.isfile(script):
+        sys.exit("run_reference_script: no such script: %s" % script)
     setup(script)
-    sys.argv = [script] + sys.argv[2:]
+    sys.argv = [script] + argv[1:]
     os.chdir(os.path.dirname(script))
     runpy.run_path(script, run_name="__main__")
 

@@ -56,3 +56,28 @@ def test_shard_and_single_gather_world2():
         assert g[k, 10] == item                                # first flow element = item id
     assert rdist.shard_indices(7, 1, 3) == [1, 4]
     assert torch.equal(rdist.gather_records(g, None), g)       # single process: identity
+
+
+def test_bench_rank_code_self_spawns_two_gloo_ranks():
+    """bench.py's REAL rank code path -- `python bench.py --gpus 2` with no launcher environment must re-exec itself under
+    torch.distributed.run, build the process group, run warm-up + timed steps between barriers, gather the records with the
+    single all_gather, take the max time over ranks and print ONE JSON line with n_gpus = 2 -- rehearsed on CPU with
+    --dry-run (gloo, a stand-in step that fabricates rank-tagged records; everything around the kernels is the code the
+    driver's N > 1 runs execute)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1",
+                          "--batch", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                          # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["ranks_seen_in_gather"] == [0, 1] and j["config"]["gathered_records"] == 8
+    assert j["value"] > 0 and abs(j["value"] - 4 * 3 * 2 / (j["ms_per_step"] * 3e-3)) < 1e-2 * j["value"]
+    # a single rank stays a single process and says so
+    out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0", "--batch", "3"],
+                          capture_output=True, text=True, timeout=120, env=env)
+    j1 = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
+    assert j1["n_gpus"] == 1 and j1["config"]["ranks_seen_in_gather"] == [0] and j1["config"]["gathered_records"] == 3

@@ -131,3 +131,34 @@ def test_restatement_matches_live_reference():
         Hb, cnt, inl, _ = outil.RANSAC(450, m1, m2, 0.05, 4, outil.Homography)
         Ho, co, io, _ = restate.ransac(m1, m2, 0.05, samples)
         assert np.array_equal(Hb, Ho) and int(cnt) == int(co) and np.array_equal(inl, io)
+
+
+@pytest.mark.reference
+def test_unchanged_reference_script_runs_up_to_the_first_device_call(tmp_path):
+    """The REAL quick_start/align2images.py, unmodified, under dropin/run_reference_script.py in this GPU-less container:
+    every import of the script (coarseAlignFeatMatch, outil, model, kornia.geometry, torchvision, pandas, matplotlib ...)
+    must resolve to the drop-ins / stand-ins, its argument parser must run, the four drop-in modules must be constructed
+    (align2images.py:37-41) and the run must stop at the script's first ``.cuda()`` (:44) with the HIP-device error --
+    not with an ImportError, AttributeError or a silent CPU fallback."""
+    import subprocess
+    import ref_loader
+    from rfx import weights
+    script = os.path.join(ref_loader.REF_ROOT, "quick_start", "align2images.py")
+    ck = tmp_path / "ck.pth"
+    torch.save({"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+                "netMatch": weights.net_matchability_sd(3)}, str(ck))
+    launcher = os.path.join(ROOT, "ransac-flow_amd", "dropin", "run_reference_script.py")
+    for how in ("argv", "env"):
+        env = dict(os.environ, MPLBACKEND="Agg")
+        cmd = [sys.executable, launcher]
+        if how == "argv":
+            cmd.append(script)
+        else:
+            env.update(RFX_REFERENCE_ROOT=ref_loader.REF_ROOT, RFX_REFERENCE_SCRIPT="quick_start/align2images.py")
+        cmd += ["--resumePth", str(ck), "--outdir", str(tmp_path / "out")]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        err = out.stderr
+        assert out.returncode != 0
+        assert "ImportError" not in err and "ModuleNotFoundError" not in err and "AttributeError" not in err, err[-1500:]
+        assert "align2images.py" in err and ".cuda()" in err, err[-1500:]            # died inside the script, at a .cuda() call
+        assert any(k in err for k in ("No HIP GPUs are available", "Found no NVIDIA driver", "not compiled with CUDA", "HIP")), err[-800:]
