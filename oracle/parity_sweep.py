@@ -37,7 +37,7 @@ for p in (HERE, os.path.join(ROOT, "ransac-flow_amd")):
         sys.path.insert(0, p)
 
 DRAW_SEED = 10_000
-TIE_EPS = 2e-4          # a flip whose evidence exceeds this is NOT explained by round-off -> reported as a failure
+TIE_EPS = 2e-5          # feature round-off is <= 2e-5 per element: a flip whose evidence exceeds this is NOT explained by it -> failure
 
 CONFIGS = {
     # name: (variant, nbScale, scaleR, minSize rule, nbIter, match head init)
