@@ -148,6 +148,12 @@ int rfx_lanczos_pass_u8(const uint8_t* in, uint8_t* out, int N, int inH, int inW
 int rfx_u8_to_f32_chw(const uint8_t* in, float* raw, float* norm, int N, int H, int W, const float* mean3_host,
                       const float* std3_host, void* stream);
 
+/* Row-pitch change of a (rows, w_src) float32 matrix into (rows, w_dst): copies min(w_src, w_dst) columns per row and
+ * zero-fills the rest.  Used to run the correlation on zero-padded copies of maps whose width is not a multiple of 4 (the
+ * half-resolution pass of the KITTI driver, evaluation/evalKITTI/evaluation.py:290: 1072/8 = 134 columns) and to crop its
+ * output; zero padding on the right is exactly CorrNeigh's own padding (model/model.py:135,143), so results are unchanged. */
+int rfx_copy_cols_f32(const float* src, float* dst, long long rows, int w_src, int w_dst, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 7x7 local correlation volume (model/model.py:129-160, CorrNeigh.do_forward):
  *     out[n, i*K+j, r, c] = sum_ch x[n,ch,r,c] * y[n,ch,r+i-K/2,c+j-K/2]   (zero outside y)

@@ -413,3 +413,24 @@ extern "C" int rfx_resize_bilinear_f32(const float* in, float* out, int NC, int 
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
+
+// Row-pitch change: dst[r, 0:wd] = src[r, 0:min(ws, wd)], zero beyond (correlation on maps whose width is not a multiple
+// of 4 runs on zero-padded copies: the 7x7 window's own padding is zero, so the result is unchanged).
+static __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                               long long total, int ws, int wd) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long long)gridDim.x * blockDim.x) {
+        const long long r = p / wd;
+        const int c = (int)(p - r * wd);
+        dst[p] = c < ws ? src[r * ws + c] : 0.f;
+    }
+}
+
+extern "C" int rfx_copy_cols_f32(const float* src, float* dst, long long rows, int w_src, int w_dst, void* stream) {
+    if (!src || !dst || rows <= 0 || w_src <= 0 || w_dst <= 0) return RFX_E_ARG;
+    const long long total = rows * w_dst;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), src, dst, total, w_src,
+                       w_dst);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}

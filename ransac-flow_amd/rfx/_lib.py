@@ -28,6 +28,7 @@ SIGNATURES = {
     "rfx_resize_bilinear_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "rfx_lanczos_pass_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "rfx_u8_to_f32_chw": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 3),
+    "rfx_copy_cols_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "rfx_corr_neigh_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "rfx_corr_neigh_variant_f32": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),

@@ -351,6 +351,15 @@ def u8_to_f32(img, mean=None, std=None, want_raw=True):
     return raw, norm
 
 
+def copy_cols(src, w_dst):
+    """(rows, w_src) -> (rows, w_dst): copy min(w_src, w_dst) columns per row, zero-fill the rest."""
+    src = _dev(src, "matrix")
+    rows, ws = src.shape
+    dst = torch.empty((rows, int(w_dst)), dtype=torch.float32, device=src.device)
+    _call("rfx_copy_cols_f32", src.device, _p(src), _p(dst), rows, ws, int(w_dst))
+    return dst
+
+
 def corr_neigh(x, y, K=7, variant=None):
     """``variant``: force a tile shape of rfx_corr_neigh_variant_f32 (tuning / tests); default = RFX_CORR_VARIANT or
     the library's automatic choice.  All variants are bit-identical."""
@@ -358,6 +367,12 @@ def corr_neigh(x, y, K=7, variant=None):
     if x.shape != y.shape:
         raise ValueError("corr_neigh: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
     N, C, H, W = x.shape
+    if W % 4 != 0 and variant is None and os.environ.get("RFX_CORR_PAD", "1") == "1":
+        # the LDS-DMA kernels move 16-byte quads: run them on copies zero-padded to a multiple of 4 columns and crop -- the
+        # window's own padding is zero (model/model.py:135,143), so the result is the unpadded one, bit for bit
+        Wp = (W + 3) // 4 * 4
+        xp, yp = copy_cols(x.view(-1, W), Wp).view(N, C, H, Wp), copy_cols(y.view(-1, W), Wp).view(N, C, H, Wp)
+        return copy_cols(corr_neigh(xp, yp, K).view(-1, Wp), W).view(N, K * K, H, W)
     out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
     e0 = Profiler.begin()
     v = int(os.environ.get("RFX_CORR_VARIANT", "0")) if variant is None else int(variant)

@@ -10,6 +10,8 @@ hypotheses.  Semantics per pair are the reference's (variant A: ResizeMaxSize, o
 Host-side work that stays on the CPU: PIL LANCZOS pyramid + ToTensor/Normalize.
 ``prepare()`` does it and uploads; everything after runs on the device.
 """
+import os
+
 import numpy as np
 import torch
 import PIL.Image as Image
@@ -142,23 +144,48 @@ class AlignPipeline:
         nA = sum(r * c for r, c in dims)
         ldA = (nA + 3) // 4 * 4      # rows padded to 16 bytes: the mutual-NN kernel then stages with float4 loads
         featA = torch.empty((B, 1024, ldA), dtype=torch.float32, device=self.dev)
-        Ws, Hs = [], []
+        Ws, Hs, offs = [], [], []
         off = 0
-        tgt = prep["tgt"]
-        ft_raw = None
-        for x, (r, c) in zip(prep["src"], dims):
-            if ft_raw is None and x.shape == tgt.shape:
-                # the pyramid level of scale 1 has the target's size: one trunk pass over both (twice the batch, one
-                # launch tail less per layer); every sample is computed independently, bit-identical to two passes
-                f2 = self.trunk(torch.cat((x, tgt), dim=0))
-                f, ft_raw = f2[:B], f2[B:]
-            else:
-                f = self.trunk(x)
-            ops.l2norm(f, out=featA[:, :, off:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
+        for (r, c) in dims:
             W, Hh = cell_coords(r, c, self.dev)
             Ws.append(W)
             Hs.append(Hh)
+            offs.append(off)
             off += r * c
+        tgt = prep["tgt"]
+        # The pyramid levels are independent trunk passes.  With RFX_TRUNK_STREAMS = S > 1 they are dealt to S HIP streams
+        # (largest level first) so that the launch tails of one level -- the /16 maps of the small levels have few
+        # workgroups per layer -- overlap with the next level's kernels; every level still writes its own columns of featA.
+        nstream = max(1, int(os.environ.get("RFX_TRUNK_STREAMS", "1")))
+        main = torch.cuda.current_stream(self.dev)
+        if nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
+            self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstream)]
+        ft_raw = None
+        ready = torch.cuda.Event()
+        if nstream > 1:
+            ready.record(main)
+        done = []
+        for i, (x, (r, c)) in enumerate(zip(prep["src"], dims)):
+            st = self._streams[i % nstream] if nstream > 1 else main
+            with torch.cuda.stream(st):
+                if nstream > 1:
+                    st.wait_event(ready)
+                if ft_raw is None and x.shape == tgt.shape:
+                    # the pyramid level of scale 1 has the target's size: one trunk pass over both (twice the batch, one
+                    # launch tail less per layer); every sample is computed independently, bit-identical to two passes
+                    f2 = self.trunk(torch.cat((x, tgt), dim=0))
+                    f, ft_raw = f2[:B], f2[B:]
+                else:
+                    f = self.trunk(x)
+                ops.l2norm(f, out=featA[:, :, offs[i]:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
+                if nstream > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
+        if ft_raw is not None and nstream > 1:
+            ft_raw.record_stream(main)
         ft = ops.l2norm(ft_raw if ft_raw is not None else self.trunk(tgt))
         rt, ct = ft.shape[2], ft.shape[3]
         Wt, Ht = cell_coords(rt, ct, self.dev)
