@@ -34,7 +34,8 @@ constexpr int TC = 16;           // columns per wavefront
 
 // Kernel configuration: tile TR x 16*NCB, CK channels per chunk, NS-deep LDS ring, NG groups of window rows (one
 // wavefront per 16x16 block and group), PF = software-pipeline distance of the LDS reads in (channel, window row)
-// steps (0 = compiler-scheduled reads), DBG: 0 product, 1 DMA only, 2 compute only (experiments, wrong results),
+// steps (0 = compiler-scheduled reads), DBG: 0 product; experiments with wrong results: 1 DMA only, 2 compute only,
+// 5 no LDS reads, 6 no FMAs;
 // SB: sched_barrier pinning of the step order, OPT: bit set of BAL / ZM / XPAD / PRIO below.
 template <int TR_, int NCB_, int CK_, int NS_, int NG_ = 2, int PF_ = 0, int DBG_ = 0, int SB_ = 0, int OPT_ = 0>
 struct Cfg {
@@ -52,7 +53,7 @@ struct Cfg {
     static constexpr int X_SLOTS = CK * TR * XQ;
     static constexpr int X_PIECES = (X_SLOTS + 63) / 64;
     static constexpr int PPW = (Y_PIECES + X_PIECES + NW - 1) / NW;   // DMA pieces per wave per chunk (padded)
-    static constexpr int N_PIECES = PPW * NW;                  // incl. padding pieces (zero source, dump area)
+    static constexpr int N_PIECES = PPW * NW;                  // incl. padding pieces (dump area, never read)
     static constexpr int BUF_SLOTS = N_PIECES * 64;
     // window rows of group g: [row_begin(g), row_begin(g+1))  -- 2 groups: 4+3, 3 groups: 3+2+2, 4 groups: 2+2+2+1
     static constexpr int row_begin(int g) { return NG == 2 ? (g == 0 ? 0 : g == 1 ? 4 : 7)
@@ -78,7 +79,7 @@ struct Cfg {
     static_assert(NG >= 2 && NG <= 4, "2..4 tap-row groups");
     static_assert(PF >= 0 && PF <= 2, "LDS read pipeline distance 0..2 steps");
     static_assert(NW * 64 <= 1024, "workgroup too large");
-    static_assert(NS >= 2 && NS <= 5 && 3 * PPW <= 63, "ring depth / vmcnt immediate out of range");
+    static_assert(NS >= 2 && NS <= 5 && (NS - 2) * PPW <= 15, "ring depth / vmcnt immediate out of range (wait_vm)");
     static_assert((size_t)NS * BUF_SLOTS * 16 <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
@@ -93,13 +94,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // is then drained together with the newest ones and the prefetch distance collapses to zero.  The reads and their
 // COUNTED waits are therefore written by hand: ds_read_b128 with a compile-time byte offset, and s_waitcnt lgkmcnt(K)
 // carrying the registers it makes valid as in/out operands so that no use can be scheduled above it.
-template <int OFF>
+template <int OFF, bool REAL = true>
 __device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    if constexpr (REAL) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+    else asm volatile("; (experiment: LDS read removed)" : "=v"(d) : "v"(addr));
 }
-template <int K>
+template <int K, bool REAL = true>
 __device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(K));
+    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(K));
 }
 
 // One (channel, window row) step of a chunk, ST = 0 .. CK*NI-1, recursively unrolled (the offsets must be immediates).
@@ -107,39 +109,40 @@ template <class G, int I0, int I1, int ST>
 __device__ __forceinline__ void corr7_steps(f32x4 (&wq)[G::CK * (I1 - I0)][3], f32x4 (&xq)[G::CK], float (&acc)[4][(I1 - I0) * 7],
                                             unsigned ya, unsigned xa) {
     constexpr int NI = I1 - I0, NSTEP = G::CK * NI, PF = G::PF;
+    constexpr bool RD = G::DBG != 5, FMA = G::DBG != 6;   // experiments 5 / 6: the LDS reads / the FMAs removed (DMA kept)
     constexpr int YROW = G::YQ * 16, YCH = G::YR * G::YQ * 16, XCH = G::TR * G::XQ * 16;
     if constexpr (ST == 0) {          // pipeline fill: steps 0 .. PF-1 (+ the x quad of channel 0)
-        lds_read128<0>(xq[0], xa);
-        lds_read128<I0 * YROW>(wq[0][0], ya);
-        lds_read128<I0 * YROW + 16>(wq[0][1], ya);
-        lds_read128<I0 * YROW + 32>(wq[0][2], ya);
+        lds_read128<0, RD>(xq[0], xa);
+        lds_read128<I0 * YROW, RD>(wq[0][0], ya);
+        lds_read128<I0 * YROW + 16, RD>(wq[0][1], ya);
+        lds_read128<I0 * YROW + 32, RD>(wq[0][2], ya);
         if constexpr (PF >= 2 && NSTEP > 1) {
             constexpr int o = (1 / NI) * YCH + (I0 + 1 % NI) * YROW;
-            if constexpr (1 % NI == 0) lds_read128<(1 / NI) * XCH>(xq[1 / NI], xa);
-            lds_read128<o>(wq[1][0], ya); lds_read128<o + 16>(wq[1][1], ya); lds_read128<o + 32>(wq[1][2], ya);
+            if constexpr (1 % NI == 0) lds_read128<(1 / NI) * XCH, RD>(xq[1 / NI], xa);
+            lds_read128<o, RD>(wq[1][0], ya); lds_read128<o + 16, RD>(wq[1][1], ya); lds_read128<o + 32, RD>(wq[1][2], ya);
         }
         if constexpr (PF >= 3 && NSTEP > 2) {
             constexpr int o = (2 / NI) * YCH + (I0 + 2 % NI) * YROW;
-            if constexpr (2 % NI == 0) lds_read128<(2 / NI) * XCH>(xq[2 / NI], xa);
-            lds_read128<o>(wq[2][0], ya); lds_read128<o + 16>(wq[2][1], ya); lds_read128<o + 32>(wq[2][2], ya);
+            if constexpr (2 % NI == 0) lds_read128<(2 / NI) * XCH, RD>(xq[2 / NI], xa);
+            lds_read128<o, RD>(wq[2][0], ya); lds_read128<o + 16, RD>(wq[2][1], ya); lds_read128<o + 32, RD>(wq[2][2], ya);
         }
     }
     constexpr int S2 = ST + PF;       // the step whose reads are issued now
     if constexpr (S2 < NSTEP) {
         constexpr int o = (S2 / NI) * YCH + (I0 + S2 % NI) * YROW;
-        if constexpr (S2 % NI == 0) lds_read128<(S2 / NI) * XCH>(xq[S2 / NI], xa);
-        lds_read128<o>(wq[S2][0], ya); lds_read128<o + 16>(wq[S2][1], ya); lds_read128<o + 32>(wq[S2][2], ya);
+        if constexpr (S2 % NI == 0) lds_read128<(S2 / NI) * XCH, RD>(xq[S2 / NI], xa);
+        lds_read128<o, RD>(wq[S2][0], ya); lds_read128<o + 16, RD>(wq[S2][1], ya); lds_read128<o + 32, RD>(wq[S2][2], ya);
     }
     // reads issued after those of step ST: steps ST+1 .. min(ST+PF, NSTEP-1), 3 each + 1 for a step that opens a channel
     constexpr int LAST = S2 < NSTEP ? S2 : NSTEP - 1;
     constexpr int NEWER = 3 * (LAST - ST) + (LAST / NI - ST / NI);
     constexpr int ch = ST / NI, r = ST % NI;
-    lds_wait<NEWER>(wq[ST][0], wq[ST][1], wq[ST][2], xq[ch]);
+    lds_wait<NEWER, RD>(wq[ST][0], wq[ST][1], wq[ST][2], xq[ch]);
     const f32x4 w0 = wq[ST][0], w1 = wq[ST][1], w2 = wq[ST][2], xv = xq[ch];
     // element e = d+j+1 of the 12-float window, picked straight out of the three quads (an intermediate float[12] makes
     // the optimiser re-load the window from the wq array with overlapping 48-byte loads, which pins wq in scratch)
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < 4 && FMA; ++d)
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int e = d + j + 1;
@@ -150,26 +153,47 @@ __device__ __forceinline__ void corr7_steps(f32x4 (&wq)[G::CK * (I1 - I0)][3], f
     if constexpr (ST + 1 < NSTEP) corr7_steps<G, I0, I1, ST + 1>(wq, xq, acc, ya, xa);
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a constant): n = DMA instructions of this wave that may
+// stay in flight = younger chunks x pieces this wave issues per chunk.
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define RFX_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        RFX_VM(0) RFX_VM(1) RFX_VM(2) RFX_VM(3) RFX_VM(4) RFX_VM(5) RFX_VM(6) RFX_VM(7) RFX_VM(8) RFX_VM(9) RFX_VM(10) RFX_VM(11)
+        RFX_VM(12) RFX_VM(13) RFX_VM(14) RFX_VM(15)
+#undef RFX_VM
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative
+    }
+}
+
 // One wavefront = one 16-row strip x one 16-column block of the tile x one group of window rows I0..I1-1 (4 px x 7 x
 // (I1-I0) accumulators per lane).  Splitting the 49 taps over NG wavefronts divides the register footprint (3 or 4
 // instead of 2 wavefronts per SIMD); all groups read the same LDS tile, so the DMA traffic is unchanged.
 template <class G, int I0, int I1>
-__device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave,
+__device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave, int amask,
                                             int strip, int cb, int lane, int nchunks, size_t HW,
                                             float* __restrict__ out, int n, int row0, int c0, int H, int W, int trv) {
     constexpr int NI = I1 - I0, NS = G::NS, CK = G::CK, PF = G::PF, DBG = G::DBG, TR = G::TR;
-    // every wave issues exactly PPW DMA instructions per chunk, so that the counted vmcnt below is uniform
     auto issue = [&](int chunk, int buf) {
         const size_t cbase = (size_t)chunk * CK * HW;
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
             const int pi = wave + G::NW * i;
             const float* base = (pi < G::Y_PIECES ? yn : xn) + cbase;
-            const float* src = off[i] >= 0 ? base + off[i] : rfx_zero16;
-            if (!G::ZM || off[i] != -1)   // ZM: lanes of pre-zeroed slots are masked off (no fetch, no LDS write)
+            if constexpr (G::ZM) {
+                // slots outside the image were zeroed once: their lanes are masked off (no fetch, no LDS write) and a piece
+                // without any image data is not issued at all (amask / npieces are wave-uniform: the vmcnt arithmetic below
+                // counts THIS wave's issues).  No zero block, hence no scalar load in the loop: an SMEM op in flight would
+                // make the counted lgkmcnt waits of the LDS-read pipeline unsafe (scalar loads return out of order).
+                if ((amask >> i) & 1)
+                    if (off[i] >= 0)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
+            } else {
+                const float* src = off[i] >= 0 ? base + off[i] : rfx_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
+            }
         }
     };
+    const int npieces = G::ZM ? __builtin_popcount((unsigned)amask) : G::PPW;   // DMA instructions per chunk of this wave
     float acc[4][NI * 7];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -189,12 +213,7 @@ __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const 
     for (int s = 0; s < nchunks; ++s) {
         // chunk s must have landed; the (up to NS-2) younger chunks of this wave may stay in flight across the barrier
         const int younger = DBG == 2 ? (s < NS - 1 ? NS - 2 - s : 0) : (nchunks - 1 - s < NS - 2 ? nchunks - 1 - s : NS - 2);
-        switch (younger) {   // wave-uniform; the immediate of s_waitcnt must be a constant
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PPW) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G::PPW) : "memory"); break;
-        }
+        wait_vm(younger * npieces);
         __builtin_amdgcn_s_barrier();  // all waves: chunk s visible, and everyone is done reading buffer (s-1)%NS
         if (DBG != 2 && s + NS - 1 < nchunks) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);  // (s+NS-1)%NS == (s-1)%NS
         if (DBG == 1) { buf = buf == NS - 1 ? 0 : buf + 1; continue; }   // experiments: DMA only
@@ -264,6 +283,7 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
 
     // per-lane source offsets of the PPW DMA pieces this wave issues per chunk; -1 = 16-byte zero block
     int off[G::PPW];
+    int amask = 0;
 #pragma unroll
     for (int i = 0; i < G::PPW; ++i) {
         const int pi = wave + G::NW * i;
@@ -285,11 +305,7 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
                 if (q < 4 * NCB && rr < trv && gr < H && gc < W) o = (int)(ch * HW) + gr * W + gc;
             }
         }
-        if (G::ZM) {
-            // a piece none of whose lanes fetches image data still has to be ISSUED (every wave issues exactly PPW
-            // pieces per chunk: the vmcnt arithmetic counts on it): lane 0 alone keeps it alive, reading the zero block
-            if (__ballot(o >= 0) == 0ull && lane == 0) o = -2;
-        }
+        if (G::ZM && __ballot(o >= 0) != 0ull) amask |= 1 << i;     // wave-uniform: this piece carries image data
         off[i] = o;
     }
     if (G::ZM) {
@@ -312,7 +328,7 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
     }
     const int strip = sc / NCB, cb = sc - strip * NCB;
     const int nch = C / G::CK;
-#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, strip, cb, lane, nch, HW, out, n, row0, c0, H, W, trv)
+#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, amask, strip, cb, lane, nch, HW, out, n, row0, c0, H, W, trv)
     if (G::PRIO && grp == 0) __builtin_amdgcn_s_setprio(1);   // the 4-/3-row group has the most FMAs per chunk: let it win VALU arbitration
     if (grp == 0) RFX_STRIP(0);
     else if (grp == 1) RFX_STRIP(1);
@@ -359,8 +375,8 @@ __global__ __launch_bounds__(256) void corr7_plain_kernel(const float* __restric
 //   5: 16x80 TUNED  = 3 tap groups (15 waves, 128 VGPRs), hand-pipelined LDS reads one step ahead, SIMD-balanced wave map,
 //      zero slots written once + masked DMA lanes, conflict-free x rows, s_setprio for the 3-row group, equal row tiles
 //   6: as 5 with 2 tap groups (10 waves)      7: 16x48   8: 16x32   9: 32x32   (plain)
-//   21 / 22: variant 5 with the compute / the DMA removed -- WRONG RESULTS, for the roofline decomposition in
-//            scripts/ubench/corr_bench.py only (how long does each side take alone?)
+//   21 / 22 / 23 / 24: variant 5 with the compute / the DMA / the LDS reads / the FMAs removed -- WRONG RESULTS, for the
+//            roofline decomposition in scripts/ubench/corr_bench.py only (how long does each side take alone?)
 using CfgTuned = Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15>;
 static int launch_variant(int v, const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st) {
     switch (v) {
@@ -375,6 +391,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, int
         case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
+        case 23: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 5, 0, 15>>(x, y, out, N, C, H, W, st, true); break;   // DMA + FMAs, no LDS reads
+        case 24: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 6, 0, 15>>(x, y, out, N, C, H, W, st, true); break;   // DMA + LDS reads, no FMAs
         default: return RFX_E_ARG;
     }
     return RFX_OK;
