@@ -153,10 +153,14 @@ class AlignPipeline:
             offs.append(off)
             off += r * c
         tgt = prep["tgt"]
-        # The pyramid levels are independent trunk passes.  With RFX_TRUNK_STREAMS = S > 1 they are dealt to S HIP streams
+        # The pyramid levels are independent trunk passes.  With S > 1 streams (RFX_TRUNK_STREAMS) they are dealt to S HIP streams
         # (largest level first) so that the launch tails of one level -- the /16 maps of the small levels have few
         # workgroups per layer -- overlap with the next level's kernels; every level still writes its own columns of featA.
-        nstream = max(1, int(os.environ.get("RFX_TRUNK_STREAMS", "1")))
+        # Default: one stream per level for small batches (B <= 4: a layer of one level has too few workgroups to fill 256 CUs
+        # -- a single 480x640 pair drops from 15.9 to 10.6 ms), one stream otherwise (at batch 64 two streams give +2 %, but
+        # overlapping launches distort the per-kernel event timing bench.py's roofline is computed from).
+        env = os.environ.get("RFX_TRUNK_STREAMS")
+        nstream = max(1, int(env)) if env else (len(prep["src"]) if B <= 4 else 1)
         main = torch.cuda.current_stream(self.dev)
         if nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
             self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstream)]
