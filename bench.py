@@ -51,6 +51,7 @@ METRIC = "aligned image-pairs/sec @480×640, 1/2/4/8 MI355X; max-abs flow Δ vs 
 MULTIH_MATCH_STD = 3.0         # saturating matchability head (random init): the explained-region mask grows, pairs stop at
                                # different homography counts (tests/golden/make_golden.py uses the same value)
 T_START = time.perf_counter()
+FORCE_DIST = os.environ.get("RFX_BENCH_FORCE_DIST") == "1"
 
 
 def log(msg):
@@ -300,7 +301,7 @@ def timed_loop(step, args, dist, sync, prof_factory):
         t0 = time.perf_counter()
         out = None
         for _ in range(args.steps):
-            out = rdist.gather_records(step(), dist)    # ONE all_gather per step (identity when world == 1)
+            out = rdist.gather_records(step(), dist, force=FORCE_DIST)    # ONE all_gather per step (identity when world == 1)
         sync()
         if dist is not None:
             dist.barrier()
@@ -391,8 +392,12 @@ def main():
         torch.cuda.set_device(dev_index)
         dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RFX_BENCH_FORCE_DIST") == "1"   # world of ONE rank through RCCL anyway (1-GPU box check)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
@@ -423,6 +428,7 @@ def main():
             "config": dict(meta, config=args.config, pairs_per_step_per_gpu=B, weights="random-init",
                            parallelism="pairs sharded over %d rank(s) (pair i -> rank i mod N), one all_gather of result records per step" % world,
                            gathered_records=int(out.shape[0]), aligned_ok_last_step=ok_pairs,
+                           collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
                            preprocessing="host PIL, outside the timed region" if args.host_prep else
                            "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step")}
     if args.dry_run:

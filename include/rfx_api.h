@@ -165,7 +165,7 @@ int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C,
 /* Same operation with the kernel configuration forced (tuning / tests / roofline decomposition; variant 0 = the
  * automatic choice of rfx_corr_neigh_f32): 1..3 = 64/32/16-row x 16-column tiles, 4 = 16 rows x 80 columns (whole
  * 480x640-pair feature-map width) plain, 5 = the tuned 16x80 kernel (3 tap groups, hand-pipelined LDS reads, balanced wave
- * map, masked DMA, equal row tiles), 6 = 5 with 2 tap groups, 7 = 16x48, 8 = 16x32, 9 = 32x32.  Variants 1..9 give
+ * map, masked DMA, equal row tiles), 6 = 5 with 2 tap groups, 7 / 8 = the tuned kernel with 48- / 64-column tiles, 9 = 32x32.  Variants 1..9 give
  * bit-identical results (channel-ordered fmaf sums).  21 .. 24 = variant 5 with the compute / the DMA / the LDS reads / the FMAs
  * removed: WRONG results, timing experiments only.  Unknown variant -> RFX_E_ARG. */
 int rfx_corr_neigh_variant_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,

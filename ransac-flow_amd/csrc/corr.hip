@@ -374,10 +374,12 @@ __global__ __launch_bounds__(256) void corr7_plain_kernel(const float* __restric
 //   4: 16x80 plain (ring of 4, 2 tap groups, compiler-scheduled LDS reads)
 //   5: 16x80 TUNED  = 3 tap groups (15 waves, 128 VGPRs), hand-pipelined LDS reads one step ahead, SIMD-balanced wave map,
 //      zero slots written once + masked DMA lanes, conflict-free x rows, s_setprio for the 3-row group, equal row tiles
-//   6: as 5 with 2 tap groups (10 waves)      7: 16x48   8: 16x32   9: 32x32   (plain)
+//   6: as 5 with 2 tap groups (10 waves)      7 / 8: the tuned kernel with 48- / 64-column tiles      9: 32x32 (plain)
 //   21 / 22 / 23 / 24: variant 5 with the compute / the DMA / the LDS reads / the FMAs removed -- WRONG RESULTS, for the
 //            roofline decomposition in scripts/ubench/corr_bench.py only (how long does each side take alone?)
 using CfgTuned = Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15>;
+using CfgTuned4 = Cfg<16, 4, 2, 4, 3, 1, 0, 0, 14>;   // 64-column tiles: 12 waves, one of each tap group per SIMD by construction
+using CfgTuned3 = Cfg<16, 3, 2, 4, 3, 1, 0, 0, 14>;   // 48-column tiles: 9 waves
 static int launch_variant(int v, const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st) {
     switch (v) {
         case 1: launch_corr<Cfg<64, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
@@ -386,8 +388,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, int
         case 4: launch_corr<Cfg<16, 5, 2, 4>>(x, y, out, N, C, H, W, st); break;
         case 5: launch_corr<CfgTuned>(x, y, out, N, C, H, W, st, true); break;
         case 6: launch_corr<Cfg<16, 5, 2, 4, 2, 1, 0, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
-        case 7: launch_corr<Cfg<16, 3, 2, 4>>(x, y, out, N, C, H, W, st); break;
-        case 8: launch_corr<Cfg<16, 2, 2, 4>>(x, y, out, N, C, H, W, st); break;
+        case 7: launch_corr<CfgTuned3>(x, y, out, N, C, H, W, st, true); break;
+        case 8: launch_corr<CfgTuned4>(x, y, out, N, C, H, W, st, true); break;
         case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
@@ -417,8 +419,15 @@ extern "C" int rfx_corr_neigh_variant_f32(const float* x, const float* y, float*
             // 1.37x for 16x16 tiles); it is taken when the launch still gives most CUs a workgroup.  Otherwise 16-column
             // tiles, as tall as the workgroup count allows (>= 1024 workgroups).
             const long long r16 = (H + 15) / 16;
-            if (W <= 80 && W > 32 && (long long)N * r16 >= 128) v = 5;
-            else {
+            if (W > 32 && (long long)N * r16 * ((W + 79) / 80) >= 128) {
+                // tuned kernel: the tile width (80 / 64 / 48 columns) that pads the map width least; ties -> the widest
+                int best = 5, best_w = 1 << 30;
+                for (int ncb = 5; ncb >= 3; --ncb) {
+                    const int padded = (W + 16 * ncb - 1) / (16 * ncb) * (16 * ncb);
+                    if (padded < best_w) { best_w = padded; best = ncb; }
+                }
+                v = best == 5 ? 5 : (best == 4 ? 8 : 7);
+            } else {
                 const long long b64 = (long long)N * ((H + 63) / 64) * tc, b32 = (long long)N * ((H + 31) / 32) * tc;
                 v = b64 >= 1024 ? 1 : (b32 >= 1024 ? 2 : 3);
             }

@@ -30,10 +30,11 @@ def pack_records(results):
     return torch.cat((Hm, status, fd), dim=1)
 
 
-def gather_records(rec, dist=None):
+def gather_records(rec, dist=None, force=False):
     """One all_gather of the (B, width) record block; returns (world*B, width) on every rank, rank-major.
-    ``dist`` is torch.distributed (initialised) or None for a single process."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    ``dist`` is torch.distributed (initialised) or None for a single process.  ``force``: run the collective even in a
+    world of one rank (exercises the RCCL transport on a 1-GPU box)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return rec
     world = dist.get_world_size()
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)

@@ -319,3 +319,23 @@ def test_multi_homography_driver_matches_reference_golden(dev, tag):
         if np.abs(Hs - g["%s_H" % tag]).max() < 1e-5:
             fd = torch.cat(out["flowDown8"]).cpu().numpy()
             assert np.abs(fd - g["%s_flowDown8" % tag]).max() < 1e-3
+
+
+def test_rccl_transport_with_a_world_of_one_rank(dev):
+    """The 1-GPU box cannot run N > 1 over RCCL, but it can run the RCCL path itself: bench.py with RFX_BENCH_FORCE_DIST=1
+    initialises the "nccl" (= RCCL) process group for ONE rank and pushes the per-step result records through
+    all_gather_into_tensor and the elapsed time through all_reduce(MAX) -- library load, communicator init (with
+    HSA_ENABLE_IPC_MODE_LEGACY=0) and both collectives on the device, as the driver's N > 1 runs will."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RFX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-config3-leg"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["config"]["gathered_records"] == 8 and j["config"]["aligned_ok_last_step"] == 8
+    assert "nccl" in j["config"]["collective"]
