@@ -232,6 +232,7 @@ def summarise(cfg_name, records, n_requested, elapsed, H, W):
              inlier_indices_bit_exact=(all(r.get("inlier_indices_bit_exact", True) for r in ident) if ident else None),
              max_abs_H_delta_identical=max([r["max_abs_H_delta"] for r in ident if "max_abs_H_delta" in r], default=None),
              max_flow_delta_e2e_identical=max([r["max_abs_flow_delta_e2e"] for r in ident if "max_abs_flow_delta_e2e" in r], default=None),
+             max_flow_delta_e2e=max([r["max_abs_flow_delta_e2e"] for r in ident if "max_abs_flow_delta_e2e" in r], default=None),   # = _identical (the bound 1e-3 applies where both sides ran the same RANSAC)
              pairs_with_flips=len(diff), total_flipped_matches=sum(r["n_differing"] for r in diff),
              total_matches=sum(r["n_matches_oracle"] for r in done),
              max_tie_evidence=max([f["evidence"] for f in flips], default=None),
