@@ -138,7 +138,43 @@ class AlignPipeline:
     # ---------------------------------------------------------------- coarse stage
     def features(self, prep):
         """ResNet-50 conv4 features of every pyramid level and of the target, L2-normalised, written into
-        featA (B,1024,nA) / featB (B,1024,nB) (quick_start/coarseAlignFeatMatch.py:92-125)."""
+        featA (B,1024,nA) / featB (B,1024,nB) (quick_start/coarseAlignFeatMatch.py:92-125).
+
+        Small batches (B <= 4) are launch-bound: ~900 kernel launches of a few workgroups each per pair cost more host time
+        (Python + allocator + launch) than GPU time.  There the whole multi-stream trunk pass is captured ONCE per input
+        shape into a HIP graph (``torch.cuda.CUDAGraph``: our ctypes launches go to torch's current stream, which is the
+        capture stream) and replayed: one graph launch instead of ~900 (RFX_GRAPH=0 disables; never under ops.Profiler,
+        whose per-launch events cannot be recorded into a graph)."""
+        B = prep["B"]
+        if B <= 4 and os.environ.get("RFX_GRAPH", "1") != "0" and ops.Profiler.active() is None:
+            return self._features_graphed(prep)
+        return self._features_eager(prep)
+
+    def _features_graphed(self, prep):
+        key = (tuple(tuple(x.shape) for x in prep["src"]), tuple(prep["tgt"].shape))
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            self._features_eager(prep)                      # warm-up: lazily built state (packed weights ...) must exist
+            torch.cuda.synchronize(self.dev)
+            static = dict(src=[torch.empty_like(x) for x in prep["src"]], tgt=torch.empty_like(prep["tgt"]), B=prep["B"])
+            for d, x in zip(static["src"], prep["src"]):
+                d.copy_(x)
+            static["tgt"].copy_(prep["tgt"])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._features_eager(static)
+            ent = cache[key] = (g, static, out)
+        g, static, out = ent
+        for d, x in zip(static["src"], prep["src"]):
+            d.copy_(x)
+        static["tgt"].copy_(prep["tgt"])
+        g.replay()
+        res = dict(out)
+        res["featA"], res["featB"] = out["featA"].clone(), out["featB"].clone()   # the graph's own buffers are reused by the next replay
+        return res
+
+    def _features_eager(self, prep):
         B = prep["B"]
         dims = [(x.shape[2] // 16, x.shape[3] // 16) for x in prep["src"]]
         nA = sum(r * c for r, c in dims)
