@@ -102,6 +102,59 @@ def test_householder_dlt_is_lapack_sign_exact(tmp_path_factory):
     assert np.abs(Href - Hf[:64]).max() <= 1.2e-7
 
 
+def test_householder_dlt_on_degenerate_samples(tmp_path_factory):
+    """Fuzz of the 4-point DLT on the samples the coarse grid makes likely: three or four points of one grid
+    row or column (collinear), near-collinear points, and two sources sent to one target.  Where the 8x9
+    system keeps rank 8 the null vector must agree with numpy.linalg.svd (utils/outil.py:84-86) including
+    its sign; where it does not (the null space has dimension >= 2, LAPACK's pick is not a function of
+    the geometry) the header must still return a finite unit null vector, which is all the det(H)/inlier
+    gates downstream (utils/outil.py:108-113) need to reject it."""
+    lib = _host_dlt_lib(tmp_path_factory)
+    rng = np.random.default_rng(17)
+    rows, cols = 30, 40
+    W, Hh = restate.get_wh(rows, cols)
+    grid = torch.stack((Hh, W, torch.ones_like(W)), 1).numpy()          # (x, y, 1) as the match lists hold
+    N = 4000
+    idx = np.zeros((N, 4), dtype=np.int64)
+    kind = rng.integers(0, 4, N)
+    for k in range(N):
+        r, c = rng.integers(rows), rng.integers(cols)
+        if kind[k] == 0:        # four points of one grid row
+            idx[k] = r * cols + rng.choice(cols, 4, replace=False)
+        elif kind[k] == 1:      # three points of one grid column + one free point
+            idx[k, :3] = rng.choice(rows, 3, replace=False) * cols + c
+            idx[k, 3] = rng.integers(rows * cols)
+        elif kind[k] == 2:      # four points of one diagonal
+            t = rng.choice(min(rows, cols), 4, replace=False)
+            idx[k] = t * cols + t
+        else:                   # a generic sample
+            idx[k] = rng.choice(rows * cols, 4, replace=False)
+    X = grid[idx].astype(np.float32)
+    # targets: a mild homography of the sources plus grid-sized jitter; kind 1 also collapses two targets
+    Y = X.copy()
+    Y[..., :2] = X[..., :2] * 0.9 + 0.05 + rng.normal(0, 0.02, (N, 4, 2)).astype(np.float32)
+    Y[kind == 1, 1] = Y[kind == 1, 0]
+    X, Y = np.ascontiguousarray(X), np.ascontiguousarray(Y)
+    h = np.zeros((N, 9))
+    Hf = np.zeros((N, 9), dtype=np.float32)
+    vp = ctypes.c_void_p
+    lib.rfx_host_dlt4(X.ctypes.data_as(vp), Y.ctypes.data_as(vp), N, h.ctypes.data_as(vp), Hf.ctypes.data_as(vp))
+    A = restate.dlt_matrix(X, Y)
+    _, s, vh = np.linalg.svd(A)
+    ref = vh[:, 8]
+    assert np.isfinite(h).all()
+    assert np.abs(np.linalg.norm(h, axis=1) - 1).max() < 1e-12
+    # always a null vector of A (8 equations, 9 unknowns: one exists whatever the rank)
+    resid = np.abs(np.einsum("nij,nj->ni", A, h)).max(1)
+    assert (resid <= 1e-12 * np.maximum(s[:, 0], 1)).all()
+    rank8 = s[:, 7] > 1e-9 * s[:, 0]
+    assert rank8[kind == 3].mean() > 0.99 and (~rank8).sum() > 500      # both regimes are exercised
+    assert ((h * ref).sum(1)[rank8] > 0).all()
+    # agreement degrades with the gap to the 8th singular value and not faster
+    gap = s[:, 7] / s[:, 0]
+    assert (np.abs(h - ref).max(1)[rank8] <= 1e-15 / gap[rank8] + 1e-12).all()
+
+
 def test_identity_matches_give_identity_homography():
     """KAT: identical match lists -> H proportional to I, every match an inlier."""
     W, Hh = restate.get_wh(12, 16)
