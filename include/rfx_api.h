@@ -63,22 +63,32 @@ int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const 
  * caller attribute algorithmic FLOPs to the kernel instance rocprofv3 reports. */
 int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 
-/* Full kernel-instance id of the launch: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
+/* Full kernel-instance id a convolution of this geometry runs as: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
  * wave-specialised form (4 MFMA + 4 loader wavefronts), bit 4 = 16-byte pixel-side loads (1x1, stride 1):
  * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints.  Bit 5 = the direct 3x3 / stride 1 / pad 1 kernel
  * conv3x3_direct_kernel<TM, PT_C> (Cin % 8 == 0), TM = 2 if bits 0-1 are 0 else 1; bits 6-7 = output patch shape
- * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least). */
+ * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least).  Bit 5 set = the geometry is served by
+ * rfx_conv3x3_f32 below (the host mirrors call it then); rfx_conv2d_f32 itself always runs the implicit-GEMM kernel. */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
+
+/* 3x3 / stride 1 / pad 1 convolution, Cin % 8 == 0 (ResNet Bottleneck conv2 at stride 1, model/resnet50.py:75; the
+ * FeatureExtractor BasicBlocks, model/model.py:32-35; the NetFlowCoarse / NetMatchability stacks, model/model.py:170-181):
+ * the direct kernel that stages the raw input patch in LDS.  Same epilogue and the same result, bit for bit, as
+ * rfx_conv2d_f32; the weights come packed in the kernel's own LDS order so that staging is a straight copy:
+ *     wP[mt][s][h][m][kk] = w[mt*128 + m, c, kh, kw]   with k = (c*3 + kh)*3 + kw = s*72 + 2*kk + h,
+ *     mt < roundup(Cout,128)/128, s < Cin/8, h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout; 16-byte aligned. */
+int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
+                    float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 
 /* Bottleneck tail (model/resnet50.py:71-79, forward :93-103: conv2 3x3 -> bn2 -> relu -> conv3 1x1 -> bn3 -> += residual
  * -> relu) as ONE kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual).  The workgroup that computed a
  * 128-pixel tile of ALL Cmid channels of the 3x3 convolution keeps it in LDS and multiplies it with the expansion weights,
- * so the Cmid-channel map never goes to HBM.  in (N,Cin,H,W); wT2/scale2/shift2 = packed weights / folded BN of the 3x3
- * (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); scale3 / shift3 of the 1x1 (Cexp % 128 == 0) and its weights in
+ * so the Cmid-channel map never goes to HBM.  in (N,Cin,H,W); wP2/scale2/shift2 = weights (packed as for
+ * rfx_conv3x3_f32) / folded BN of the 3x3 (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); scale3 / shift3 of the 1x1 (Cexp % 128 == 0) and its weights in
  * "quad" order wQ3[q][h][m][j] = W3[m][8q + 2j + h] (q < Cmid/8, h < 2, m < Cexp, j < 4; 16-byte aligned): the four MFMA A
  * operands of a lane for four consecutive k-pairs are one 16-byte load, coalesced over the channels;
  * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.  Bit-identical to the two rfx_conv2d_f32 calls. */
-int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
+int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
                             const float* wQ3, const float* scale3, const float* shift3, const float* residual, int act3,
                             float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream);
 

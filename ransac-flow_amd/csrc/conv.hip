@@ -350,7 +350,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
     return RFX_OK;
 }
 
-int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
+int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
 int rfx_conv3x3_patch_cols(int H, int W);                                              // conv3x3.hip
@@ -378,10 +378,9 @@ static int conv_ws_env() {
 // (VECB), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
 // bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM, PT_C>, TM = 2 - (bits 0-1 != 0),
 // output patch 128/PT_C x PT_C with PT_C = 16 / 8 / 4 for bits 6-7 = 0 / 1 / 2).
-extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout,
-                                    int Wout) {
+static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct) {
     static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
-    if (direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
+    if (allow_direct && direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
         const int pc = rfx_conv3x3_patch_cols(Hout, Wout), pr = 128 / pc;
         const long long tiles = (long long)N * ((Hout + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
@@ -394,6 +393,26 @@ extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, in
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
     const bool vecb = vec_env && one && !ws && stride == 1 && ((long long)Hout * Wout) % 4 == 0;
     return variant | (one ? 4 : 0) | (ws ? 8 : 0) | (vecb ? 16 : 0);
+}
+
+extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout,
+                                    int Wout) {
+    return conv_kernel_id(N, Cin, Cout, KH, KW, stride, pad, Hout, Wout, true);
+}
+
+// The direct 3x3 kernel with the weights in its own packed order (conv3x3.hip); bit 5 of rfx_conv2d_kernel_id says when
+// it applies.  rfx_conv2d_f32 computes the same convolution, bit for bit, from the generic wT / ktab packing.
+extern "C" int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift,
+                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int act,
+                               void* stream) {
+    if (!in || !wP || !out || N <= 0 || Cin <= 0 || Cin % 8 != 0 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
+    if ((long long)Cin * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
+    const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true);
+    const int pc = rfx_conv3x3_patch_cols(H, W);
+    const int tm = (kid & 32) ? ((kid & 3) ? 1 : 2) : (Cout > 64 ? 2 : 1);   // RFX_CONV_DIRECT=0 only changes the host's choice
+    return rfx_conv3x3_direct_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, (Cout + 127) / 128 * 128, act,
+                                     tm, pc, rfx_stream(stream));
 }
 
 extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
@@ -419,10 +438,7 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     // The wave-specialised form pays off where the gather is the heavy part and the K loop is long: KxK (K > 1)
     // convolutions on the 128x128 tile (measured +5 % there, -5...-15 % on 1x1 and 64-wide tiles, which keep the
     // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
-    int kid = rfx_conv2d_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout);
-    if (kid & 32)
-        return rfx_conv3x3_direct_launch(in, wT, scale, shift, residual, out, N, Cin, Hin, Win, Cout, a.Mpad, act,
-                                         (kid & 3) ? 1 : 2, (kid & 128) ? 4 : ((kid & 64) ? 8 : 16), st);
+    int kid = conv_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout, false);
     if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;

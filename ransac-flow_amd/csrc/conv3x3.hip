@@ -8,10 +8,15 @@
 // image border) in LDS once per 8 input channels; the MFMA B operand for tap (c, kh, kw) of pixel (r, x) is then the
 // LDS word [c][r+kh][x+kw] -- fetched with one ds_read_b32 at a per-lane address that is precomputed ONCE (the 36
 // k-pair offsets of a K step repeat every step).  No per-element index arithmetic is left in the loop:
-//     per K step (72 = 8 channels x 9 taps): 12 float4 weight loads + 6 input loads per thread,
+//     per K step (72 = 8 channels x 9 taps): 9 float4 weight loads + 6 input loads per thread,
 //     then per wavefront 18 ds_read_b128 (A) + 72 ds_read_b32 (B) + 144 MFMAs.
-// A operand (weights) as in conv.hip: LDS image [k&1][m][k>>1] with 36 k-pairs per row (row stride 144 B: the
-// 16-lane ds_read_b128 groups hit 16 distinct bank quads without a swizzle because 9 is odd).
+// A operand (weights): LDS image [k&1][m][k>>1] with 36 k-pairs per row (row stride 144 B: the 16-lane ds_read_b128
+// groups hit 16 distinct bank quads without a swizzle because 9 is odd).  The host packs the weights ONCE in exactly
+// that order (rfx_api.h: "wP"), one contiguous 36 KB image per (128-channel tile, K step), so staging is a straight
+// 16-byte-per-lane copy: coalesced global loads, conflict-free ds_write_b128, no register transposes.
+// The global loads of step s+1 are not issued as one burst: they are dealt out two at a time between the 16-MFMA
+// chunks of step s, where they issue in the shadow of the matrix pipe (a burst in front of the MFMAs cost 13 % of
+// the kernel, the bank-conflicting transposed stores another 8 %: scripts/ubench/conv_bench.py, make c3dbgN).
 // B patch rows are 48 floats apart so that the two 16-pixel rows a 32-lane half reads fall on disjoint banks.
 // Numerics: k runs channel-major, taps row-major -- the same order as conv.hip / the packed weight matrix, so the
 // result is bit-identical to the implicit-GEMM kernel.
@@ -35,7 +40,8 @@ constexpr int KS = CH * 9;                   // 72 k per step
 constexpr int KK = KS / 2;                   // 36 k-pairs
 
 struct C3Args {
-    const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
+    const float* in; const float* wT;   // wT: the packed image wP (rfx_api.h)
+    const float* scale; const float* shift; const float* res; float* out;
     int N, Cin, H, W, Cout, act, Mpad;
     int tilesM, tilesH, tilesW;
     // FUSE: the 1x1 expansion that follows (Bottleneck conv3 + bn3 + residual + ReLU, model/resnet50.py:77-79,99-103)
@@ -45,6 +51,11 @@ struct C3Args {
     long long* trace;
 #endif
 };
+// experiments only (scripts/ubench/conv_bench.py): RFX_C3_DBG removes pieces of the main loop to price them
+//   1 no LDS stores in the loop   2 no global loads in the loop   3 neither   4 neither, no barriers   6 no output stores
+#ifndef RFX_C3_DBG
+#define RFX_C3_DBG 0
+#endif
 #ifdef RFX_TRACE
 #define RFX_STAMP(i) do { if (threadIdx.x == 0 && a.trace) a.trace[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
 extern "C" long long* rfx_debug_trace_ptr();
@@ -65,8 +76,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     constexpr int NB = (CH * PR * PC + 255) / 256;   // patch elements per thread (6; 7 for the 32x4 patch)
     static_assert(PC < BS, "the surplus staging slots live in the never-read padding columns");
     constexpr int BM = 64 * TM;
-    constexpr int A_MG = BM / 4;          // groups of 4 consecutive output channels
-    constexpr int A_THREADS = 6 * A_MG;   // 2 parities x 3 chunk-triples
     constexpr int AS_F = 2 * BM * KK, BS_F = CH * PR * BS, T2_F = FUSE ? BM * 128 : 0;
     constexpr int SMEM_F = AS_F + BS_F > T2_F ? AS_F + BS_F : T2_F;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_F];   // FUSE: the main-loop buffers are reused for the mid tile
@@ -101,13 +110,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     }
 
     // ---- staging roles ----
-    // weights: thread owns 4 consecutive m (one float4 per k row), parity hA, k-pairs [12*cq, 12*cq+12)
-    const int mg = t % A_MG, roleA = t / A_MG;
-    const bool a_on = t < A_THREADS;
-    const int hA = roleA & 1, cq = roleA >> 1;
-    // byte offset of this thread's first weight float4 inside a K step (uniform step base + 32-bit lane offset)
-    const unsigned woff0 = (unsigned)(((a_on ? hA + 24 * cq : 0) * a.Mpad + m0 + mg * 4) * 4);
-    const unsigned wrow2 = (unsigned)(2 * a.Mpad * 4);
+    // weights: the packed image of this tile and step is A_F4 consecutive float4 (TM = 2: the whole 36 KB image;
+    // TM = 1: the rows of this 64-channel half inside both parity planes); thread t copies float4 t, t+256, ...
+    // (TM = 1: the 128 surplus slots of the last round re-copy float4 0..127 -- same value to the same place).
+    constexpr int A_F4 = 2 * BM * KK / 4, NA = (A_F4 + 255) / 256;     // 2304 / 1152 float4, 9 / 5 per thread
+    constexpr int PLANE_B = 128 * KK * 4;                              // bytes of one parity plane of a packed image
+    unsigned aoff[NA];    // byte offset inside the packed image of a step
+    int alds[NA];         // float4 index inside As
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int L = t + 256 * j;
+        if (L >= A_F4) L -= A_F4;
+        alds[j] = L;
+        aoff[j] = TM == 2 ? (unsigned)(L * 16) : (unsigned)((L / (A_F4 / 2)) * PLANE_B + (L % (A_F4 / 2)) * 16);
+    }
+    const size_t step_b = (size_t)2 * PLANE_B;                         // bytes per (tile, step)
+    const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * (a.Cin / CH) * step_b +
+                        (TM == 1 ? ((m0 >> 6) & 1) * (PLANE_B / 2) : 0);
     // input patch: NB of the CH*PR*PC (1440 or 1632) patch elements per thread (the surplus slots land in the unused
     // columns of the last patch row, so that every load is consumed unconditionally: no divergent store).
     unsigned boffB[NB];   // byte offset inside one channel group (cl*HW + gy*W + gx)*4; 0 with bok=false -> zero
@@ -125,28 +144,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         blds[u] = real ? (cl * PR + pr) * BS + px : ((CH - 1) * PR + PR - 1) * BS + PC + (idx - CH * PR * PC) % (BS - PC);
     }
 
-    f32x4 ra[12];
+    f32x4 ra[NA];
     float rb[NB];
+    constexpr int NLD = NB + NA;                 // global loads per thread and step: patch first, then weights
+    constexpr int LPC = 2;                       // ... dealt out LPC per 16-MFMA chunk
+    static_assert(LPC * 8 >= NLD, "all loads of a step are issued before its last chunk");
+    auto load_one = [&](int id, const char* wstep, const char* base) {
+        if (id < NB) rb[id] = *reinterpret_cast<const float*>(base + boffB[id]);   // masked at store time
+        else if (id < NLD) ra[id - NB] = *reinterpret_cast<const f32x4*>(wstep + aoff[id - NB]);
+    };
     auto load_global = [&](int s) {
-        const char* wstep = reinterpret_cast<const char*>(a.wT + (size_t)s * KS * a.Mpad);
-        if (a_on) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) ra[j] = *reinterpret_cast<const f32x4*>(wstep + (woff0 + j * wrow2));
-        }
+        const char* wstep = wtile + (size_t)s * step_b;
         const char* base = reinterpret_cast<const char*>(inn + (size_t)s * CH * HW);
 #pragma unroll
-        for (int u = 0; u < NB; ++u) rb[u] = *reinterpret_cast<const float*>(base + boffB[u]);   // masked at store time
+        for (int id = 0; id < NLD; ++id) load_one(id, wstep, base);
     };
     auto store_lds = [&]() {
-        if (a_on) {
+        f32x4* a4 = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    f32x4 v = {ra[4 * c3][e], ra[4 * c3 + 1][e], ra[4 * c3 + 2][e], ra[4 * c3 + 3][e]};
-                    *reinterpret_cast<f32x4*>(&As[hA][mg * 4 + e][(3 * cq + c3) * 4]) = v;
-                }
-        }
+        for (int j = 0; j < NA; ++j) a4[alds[j]] = ra[j];
         float* bflat = &Bs[0][0][0];
 #pragma unroll
         for (int u = 0; u < NB; ++u) bflat[blds[u]] = bok[u] ? rb[u] : 0.0f;
@@ -178,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     RFX_STAMP(1);
     const float* bflat = &Bs[0][0][0];
     for (int s = 0; s < nsteps; ++s) {
-        load_global(s + 1 < nsteps ? s + 1 : s);   // in flight during the 144 MFMAs below
+        const int sn = s + 1 < nsteps ? s + 1 : s;     // the last step re-loads its own tile: harmless
+        const char* wstep = wtile + (size_t)sn * step_b;
+        const char* base = reinterpret_cast<const char*>(inn + (size_t)sn * CH * HW);
         // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
         f32x4 af[2][TM];
         float bv[2][8];
@@ -197,6 +215,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         for (int q = 0; q < 9; ++q) {
             const int cur = q & 1;
             if (q + 1 < 9) read_chunk(q + 1, cur ^ 1);
+            if (RFX_C3_DBG != 2 && RFX_C3_DBG != 3 && RFX_C3_DBG != 4) {
+#pragma unroll
+                for (int i = 0; i < LPC; ++i) load_one(q * LPC + i, wstep, base);   // tile s+1, in the MFMA shadow
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -207,9 +229,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();   // everyone is done reading the tile
-        store_lds();       // tile s+1 (the last step rewrites its own tile: harmless)
-        __syncthreads();
+        if (RFX_C3_DBG != 4) __syncthreads();   // everyone is done reading the tile
+        if (RFX_C3_DBG != 1 && RFX_C3_DBG != 3 && RFX_C3_DBG != 4)
+            store_lds();   // tile s+1
+        else if (RFX_C3_DBG == 1) {   // keep the loads alive (and waited for) without the LDS stores
+#pragma unroll
+            for (int j = 0; j < NA; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+            for (int u = 0; u < NB; ++u) asm volatile("" ::"v"(rb[u]));
+        }
+        if (RFX_C3_DBG != 4) __syncthreads();
+    }
+    if (RFX_C3_DBG == 6) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f) a.out[t] = sacc;
+        return;
     }
 
     RFX_STAMP(2);
@@ -328,11 +368,11 @@ static int launch_direct(C3Args& a, hipStream_t st) {
 
 // Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 3x3, stride 1, pad 1,
 // Cin % 8 == 0.  tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; patch_cols in {16, 8, 4}.
-int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* scale, const float* shift,
+int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st) {
     C3Args a;
-    a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.in = in; a.wT = wP; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
     a.wT3 = a.scale3 = a.shift3 = nullptr; a.Cexp = a.Mpad3 = a.act3 = 0;
 #ifdef RFX_TRACE
@@ -353,15 +393,15 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wT, const float* sca
 // Bottleneck tail in one kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual)  (model/resnet50.py:71-79,93-103).
 // The 3x3 convolution must be direct-eligible (stride 1, pad 1, Cin % 8 == 0) with Cmid in {64, 128} so that one workgroup
 // tile holds all of its channels; Cexp % 128 == 0.
-extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wT2, const float* scale2, const float* shift2, int act2,
+extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
                                        const float* wQ3, const float* scale3, const float* shift3, const float* residual,
                                        int act3, float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream) {
-    if (!in || !wT2 || !wQ3 || !scale3 || !shift3 || !out || N <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
+    if (!in || !wP2 || !wQ3 || !scale3 || !shift3 || !out || N <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
     if (Cin <= 0 || Cin % 8 != 0 || (Cmid != 64 && Cmid != 128) || Cexp <= 0 || Cexp % 128 != 0) return RFX_E_ARG;
     if (reinterpret_cast<uintptr_t>(wQ3) & 15) return RFX_E_ARG;
     if (act2 == RFX_ACT_SIGMOID || act3 == RFX_ACT_SIGMOID) return RFX_E_ARG;
     C3Args a;
-    a.in = in; a.wT = wT2; a.scale = scale2; a.shift = shift2; a.res = residual; a.out = out;
+    a.in = in; a.wT = wP2; a.scale = scale2; a.shift = shift2; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cmid; a.act = act2; a.Mpad = 128;
     a.wT3 = wQ3; a.scale3 = scale3; a.shift3 = shift3; a.Cexp = Cexp; a.Mpad3 = Cexp; a.act3 = act3;
 #ifdef RFX_TRACE

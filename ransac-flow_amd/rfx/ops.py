@@ -114,6 +114,13 @@ class ConvPlan:
         wT[:K, :self.Cout] = w.reshape(self.Cout, K).t()
         self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
         self._wq = None
+        self.wP = None
+        if self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.Cin % 8 == 0:
+            # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]
+            wp = torch.zeros(Mpad, K, dtype=torch.float32)
+            wp[:self.Cout] = w.reshape(self.Cout, K)
+            wp = wp.view(Mpad // 128, 128, K // 72, 36, 2).permute(0, 2, 4, 1, 3).contiguous()
+            self.wP = wp.to(device or "cuda")
         k = torch.arange(K)
         c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)
         ktab = torch.full((Kpad,), -1, dtype=torch.int32)
@@ -153,13 +160,18 @@ class ConvPlan:
         res = _dev(residual, "residual") if residual is not None else None
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
+        lib = _lib.load()
+        direct = self.wP is not None and (lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, 3, 3, 1, 1, Ho, Wo) & 32) != 0
         e0 = Profiler.begin()
-        _call("rfx_conv2d_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale),
-              _p(self.shift), _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
-              self.act if act is None else act)
+        if direct:
+            _call("rfx_conv3x3_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
+                  _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
+        else:
+            _call("rfx_conv2d_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale),
+                  _p(self.shift), _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad,
+                  self.act if act is None else act)
         if e0 is not None:
             e1 = Profiler.end(e0)
-            lib = _lib.load()
             flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
             nbytes = 4.0 * (N * C * H * W + N * self.Cout * Ho * Wo * (2 if res is not None else 1)
                             + self.Cout * self.Cin * self.KH * self.KW)
@@ -188,7 +200,7 @@ def bottleneck_tail(x, plan2, plan3, residual=None):
     if res is not None and res.shape != out.shape:
         raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
     e0 = Profiler.begin()
-    _call("rfx_conv3x3_conv1x1_f32", _one_device(x, res, plan2.wT, plan3.scale), _p(x), _p(plan2.wT), _p(plan2.scale),
+    _call("rfx_conv3x3_conv1x1_f32", _one_device(x, res, plan2.wP, plan3.scale), _p(x), _p(plan2.wP), _p(plan2.scale),
           _p(plan2.shift), plan2.act, _p(plan3.quad_weights()), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
           _p(out), N, C, H, W, plan2.Cout, plan3.Cout)
     if e0 is not None:

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q 2>&1 | tail -5
+OUT=gpurun_out/conv_new.jsonl
+rm -f $OUT
+timeout 600 python scripts/ubench/conv_bench.py --out $OUT 2>&1 | grep -v Warning

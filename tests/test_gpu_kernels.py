@@ -79,6 +79,28 @@ def test_conv2d_matches_cpu(dev, case):
     assert relerr(out, ref) < 2e-5, relerr(out, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 19, 21, 64), (8, 128, 60, 80, 256), (1, 8, 5, 3, 130), (64, 16, 25, 33, 128),
+                                   (48, 16, 30, 40, 256), (3, 24, 28, 37, 40), (5, 72, 33, 47, 192)])
+def test_direct_3x3_equals_implicit_gemm_bit_for_bit(dev, shape):
+    """rfx_conv3x3_f32 (weights packed in the kernel's LDS order, include/rfx_api.h) == rfx_conv2d_f32 (generic wT / ktab
+    packing) on the same layer, bit for bit: same k order in both kernels."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bnd = dict(weight=1 + 0.3 * torch.randn(Cout, generator=g), bias=0.2 * torch.randn(Cout, generator=g),
+               running_mean=0.2 * torch.randn(Cout, generator=g), running_var=0.5 + torch.rand(Cout, generator=g))
+    r = torch.randn(N, Cout, H, W, generator=g).to(dev)
+    plan = ops.ConvPlan(w, bnd, 1, 1, ops.ACT_RELU, dev)
+    assert plan.wP is not None
+    direct = plan(x, residual=r)
+    generic = torch.empty_like(direct)
+    ops._call("rfx_conv2d_f32", x.device, ops._p(x), ops._p(plan.wT), ops._p(plan.ktab), ops._p(plan.scale), ops._p(plan.shift),
+              ops._p(r), ops._p(generic), N, Cin, H, W, Cout, 3, 3, 1, 1, ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(direct, generic)
+
+
 def test_pools_norm_head_resize(dev):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 5, 19, 26, generator=g)
