@@ -354,6 +354,9 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
 int rfx_conv3x3_patch_cols(int H, int W);                                              // conv3x3.hip
+int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
+                              float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
+                              hipStream_t st);                                          // conv1x1.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -376,6 +379,7 @@ static int conv_ws_env() {
 // Kernel instance rfx_conv2d_f32 launches for this geometry: bits 0-1 tile variant (0: <2,2>, 1: <1,2>, 2: <1,1>),
 // bit 2 = 1x1 specialisation (ONE), bit 3 = wave-specialised form (WS), bit 4 = vectorised pixel-side loads
 // (VECB), i.e. the template arguments of conv2d_mfma_kernel<TM,TN,ONE,WS,VECB> that rocprofv3 prints.
+// bit 10 = the k-major 1x1 / stride 1 kernel of conv1x1.hip (conv1x1_kmajor_kernel<TM, VEC>, TM = 2 - (bits 0-1), VEC = bit 4).
 // bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM, PT_C>, TM = 2 - (bits 0-1 != 0),
 // output patch 128/PT_C x PT_C with PT_C = 16 / 8 / 4 for bits 6-7 = 0 / 1 / 2).
 static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct) {
@@ -388,6 +392,9 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
+    static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
+    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && variant != 2 && (long long)N * Hout * Wout >= 4)
+        return 1024 | 4 | variant | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0);   // conv1x1.hip
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env > 0);  // off by default: since the branch-free epilogue the single-role kernel is as fast
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
@@ -440,6 +447,9 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     // single-role kernel with two independent workgroups per CU).  RFX_CONV_WS=0/1 forces it off/on for A/B runs.
     int kid = conv_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout, false);
     if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
+    if (kid & 1024)
+        return rfx_conv1x1_kmajor_launch(in, wT, scale, shift, residual, out, N, Cin, Hin * Win, Cout, a.Mpad, act,
+                                         (kid & 3) ? 1 : 2, (kid & 16) != 0, st);
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;
     const bool vecb = (kid & 16) != 0;

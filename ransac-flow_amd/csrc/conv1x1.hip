@@ -1,0 +1,244 @@
+// conv1x1.hip -- 1x1 / stride 1 convolution (+ folded BatchNorm, residual, ReLU) on the fp32 MFMA: the Bottleneck conv1 /
+// conv3 / downsample-free projections of the ResNet-50 trunk (model/resnet50.py:71-79,93-103), a third of the conv time
+// of the path.
+//
+// A 1x1 convolution in NCHW is the plain GEMM  out[m][p] = sum_k W[m][k] * in[k][p]  with BOTH operands already k-major
+// in memory: the packed weights wT[k][Mpad] and the input planes in[n][k][hw].  A lane of v_mfma_f32_32x32x2_f32 supplies
+// ONE float per operand -- A[m = lane&31][k = lane>>5], B[k = lane>>5][p = lane&31] -- so with k-major LDS images
+// As[k][m], Bs[k][p] the operand of a lane is a single ds_read_b32 at an immediate offset, 32 consecutive lanes read 32
+// consecutive floats (no bank conflict by construction), and staging is a straight 16-byte copy global -> register ->
+// LDS: no transpose, no swizzle, no validity mask (a pixel column of B only feeds the same column of the output, so the
+// columns past the last pixel may hold anything; their loads are clamped to a valid address).
+// conv.hip's generic kernel transposes both operands into [row][k-pair] images to read them back with ds_read_b128; the
+// 4x4 register transposes and the bank-conflicting transposed stores cost it ~20 % of the matrix pipe on these layers.
+//
+// Pipeline (256 threads = 2x2 wavefronts, tile 64*TM channels x 128 pixels, BK = 32, LDS double buffered, ONE barrier
+// per step): while the 16 k-pairs of tile s run on the matrix pipe, tile s+1 goes registers -> LDS (other buffer) in the
+// shadow of the first MFMA chunks and the global loads of tile s+2 are issued in the shadow of the last ones -- never
+// as a burst in front of the MFMAs (that cost the direct 3x3 kernel 13 %, scripts/ubench/conv_bench.py).
+// k runs in the same pairs and the same order as in conv.hip: bit-identical results.
+#include "common.h"
+#include "conv_epilogue.h"
+
+// experiments only (scripts/ubench/conv_bench.py, make c1dbgN): RFX_C1_DBG removes pieces of the main loop to price them
+//   1 no LDS stores in the loop   2 no global loads in the loop   3 neither   4 neither, no barrier   6 no output stores
+#ifndef RFX_C1_DBG
+#define RFX_C1_DBG 0
+#endif
+
+namespace {
+
+struct C1Args {
+    const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
+    int Cin, HW, Cout, act, Mpad;
+    long long P;   // N*HW
+    int tilesM, tilesP;
+};
+
+template <int TM, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
+    constexpr int BM = 64 * TM, BN = 128, BK = 32;
+    constexpr int A_C4 = BM / 4;                 // float4 per A row: 32 / 16
+    constexpr int A_RS = 256 / A_C4;             // rows covered by one round of the 256 threads: 8 / 16
+    constexpr int NA = BK / A_RS;                // float4 per thread and step: 4 / 2
+    constexpr int NBV = 4;                       // VEC: float4 per thread and step (32 float4 per row, 8 rows a round)
+    constexpr int NBS = 16;                      // scalar: floats per thread and step (128 pixels per row, 2 rows a round)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    __shared__ float s_scale[BM], s_shift[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    const int nwg = a.tilesM * a.tilesP;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap, m-tile fastest: the workgroups that share one pixel tile sit on one L2
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int m0 = (bid % a.tilesM) * BM;
+    const long long n0 = (long long)(bid / a.tilesM) * BN;
+    if (t < BM) {
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
+    const size_t HW = (size_t)a.HW;
+
+    // ---- staging roles ----
+    const int ar = t / A_C4, ac = t % A_C4;                                  // A: rows ar + A_RS*j, float4 column ac
+    const float* wsrc = a.wT + (size_t)ar * a.Mpad + m0 + ac * 4;            // + (k0 + A_RS*j) * Mpad
+    const float* bsrc;                                                        // + (k0 + row) * HW
+    int brow, bcol;                                                           // B: rows brow + 8*j (VEC) / brow + 2*i (scalar)
+    {
+        long long p;
+        if (VEC) { brow = t >> 5; bcol = (t & 31) * 4; p = n0 + bcol; if (p >= a.P) p = a.P - 4; }
+        else     { brow = t >> 7; bcol = t & 127;      p = n0 + bcol; if (p >= a.P) p = a.P - 1; }
+        const long long n = p / a.HW;
+        bsrc = a.in + (size_t)n * a.Cin * HW + (size_t)(p - n * a.HW) + (size_t)brow * HW;
+    }
+    f32x4 ra[NA];
+    f32x4 rv[VEC ? NBV : 1];
+    float rb[VEC ? 1 : NBS];
+    auto load_a = [&](int k0, int j) { ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(k0 + A_RS * j) * a.Mpad); };
+    auto load_b = [&](int k0, int j) {
+        if (VEC) rv[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * HW);
+        else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * HW];
+    };
+    auto store_a = [&](int buf, int j) { *reinterpret_cast<f32x4*>(&As[buf][ar + A_RS * j][ac * 4]) = ra[j]; };
+    auto store_b = [&](int buf, int j) {
+        if (VEC) *reinterpret_cast<f32x4*>(&Bs[buf][brow + 8 * j][bcol]) = rv[j];
+        else     Bs[buf][brow + 2 * j][bcol] = rb[j];
+    };
+    constexpr int NB = VEC ? NBV : NBS;
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = a.Cin / BK;
+    // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(0, j);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) load_b(0, j);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) store_a(0, j);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) store_b(0, j);
+    {
+        const int k1 = nk > 1 ? BK : 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) load_a(k1, j);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) load_b(k1, j);
+    }
+    __syncthreads();
+
+    // per-lane operand addresses inside a buffer: row 2*kk + lrow, column (32-wide sub-tile) + lcol
+    const float* arow = &As[0][lrow][wm * TM * 32 + lcol];
+    const float* brow_p = &Bs[0][lrow][wn * 64 + lcol];
+    for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1;
+        const float* ap = arow + cur * (BK * BM);
+        const float* bp = brow_p + cur * (BK * BN);
+        const int k2 = (s + 2 < nk ? s + 2 : nk - 1) * BK;   // the tail re-loads the last tile: harmless
+        // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
+        float af[2][4][TM], bf[2][4][2];
+        auto read_chunk = [&](int c, int slot) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = c * 4 + e;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[slot][e][i] = ap[2 * kk * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[slot][e][j] = bp[2 * kk * BN + j * 32];
+            }
+        };
+        read_chunk(0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) read_chunk(c + 1, (c + 1) & 1);
+            // tile s+1: registers -> the other LDS buffer (chunks 0, 1); tile s+2: global -> registers (chunks 2, 3)
+            constexpr bool ST = RFX_C1_DBG != 1 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
+            constexpr bool LD = RFX_C1_DBG != 2 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
+            if (c == 0) {
+                if (ST) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) store_a(cur ^ 1, j);
+#pragma unroll
+                    for (int j = 0; j < NB / 2; ++j) store_b(cur ^ 1, j);
+                } else if (LD) {   // keep the loads alive (and waited for) without the LDS stores
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) asm volatile("" ::"v"(ra[j]));
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) { if (VEC) asm volatile("" ::"v"(rv[VEC ? j : 0])); else asm volatile("" ::"v"(rb[VEC ? 0 : j])); }
+                }
+            } else if (c == 1) {
+                if (ST) {
+#pragma unroll
+                    for (int j = NB / 2; j < NB; ++j) store_b(cur ^ 1, j);
+                }
+            } else if (c == 2) {
+                if (LD) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) load_a(k2, j);
+#pragma unroll
+                    for (int j = 0; j < NB / 2; ++j) load_b(k2, j);
+                }
+            } else {
+                if (LD) {
+#pragma unroll
+                    for (int j = NB / 2; j < NB; ++j) load_b(k2, j);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (RFX_C1_DBG != 4) __syncthreads();   // tile s+1 is complete in the other buffer; everyone is done reading this one
+    }
+    if (RFX_C1_DBG == 6) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f) a.out[t] = sacc;
+        return;
+    }
+
+    // ---- epilogue (conv_epilogue.h) ----
+    size_t pix_off[2];
+    bool pix_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        long long pp = n0 + wn * 64 + j * 32 + lcol;
+        pix_ok[j] = pp < a.P;
+        if (!pix_ok[j]) pp = a.P - 1;
+        const long long n = pp / a.HW;
+        pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pp - n * a.HW);
+    }
+    conv_epilogue<TM, 2, false>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok,
+                                m0 + BM <= a.Cout);
+}
+
+template <int TM, bool VEC>
+int launch_1x1(C1Args& a, hipStream_t st) {
+    a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
+    a.tilesP = (int)((a.P + 127) / 128);
+    const long long nwg = (long long)a.tilesM * a.tilesP;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+}  // namespace
+
+// Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 1x1, stride 1, pad 0,
+// Cin % 32 == 0, N*HW >= 4; tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; vec: HW % 4 == 0 and `in` 16-byte
+// aligned (16-byte pixel loads).
+int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
+                              float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
+                              hipStream_t st) {
+    C1Args a;
+    a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.Cin = Cin; a.HW = HW; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
+    a.P = (long long)N * HW;
+    if (tm == 2) return vec ? launch_1x1<2, true>(a, st) : launch_1x1<2, false>(a, st);
+    return vec ? launch_1x1<1, true>(a, st) : launch_1x1<1, false>(a, st);
+}

@@ -49,6 +49,10 @@ CONV_CASES = [
     (64, 16, 25, 33, 128, 3, 1, 1, True, False, 1),   # direct 3x3 <2, 4>
     (48, 16, 30, 40, 256, 3, 1, 1, True, True, 1),    # direct 3x3 <2, 8>: 16x8 patch
     (3, 24, 28, 37, 40, 3, 1, 1, False, False, 0),    # direct 3x3 <1, 8>, Cout not a multiple of the tile
+    (40, 64, 34, 45, 256, 1, 1, 0, True, True, 1),    # k-major 1x1 <2, false>: odd plane, scalar pixel loads
+    (8, 96, 34, 45, 72, 1, 1, 0, True, False, 1),     # k-major 1x1 <1, false>: three K steps, ragged channel tile
+    (9, 32, 30, 40, 64, 1, 1, 0, False, True, 0),     # k-major 1x1 <1, true>: ONE K step, ragged pixel tile
+    (66, 128, 16, 20, 130, 1, 1, 0, True, True, 1),   # k-major 1x1 <2, true>: ragged channel + pixel tiles
 ]
 
 
@@ -460,6 +464,8 @@ def test_fused_resnet_stem_equals_conv_then_maxpool(dev, shape):
     (3, 128, 19, 21, 128, 512, True),     # layer2-like, 8x16 patch, ragged
     (1, 64, 16, 48, 64, 128, False),      # no residual, single pass
     (1, 8, 5, 3, 128, 384, True),         # one K step of the 3x3, three passes of the 1x1
+    (24, 64, 30, 40, 64, 256, True),      # big enough for the unfused 1x1 to run on the k-major kernel (conv1x1.hip)
+    (20, 128, 17, 23, 128, 512, True),    # ... with an odd plane (scalar pixel loads)
 ])
 def test_fused_bottleneck_tail_equals_two_convs(dev, case):
     """rfx_conv3x3_conv1x1_f32 == rfx_conv2d_f32(3x3) -> rfx_conv2d_f32(1x1 + residual), bit for bit."""

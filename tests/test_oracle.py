@@ -371,7 +371,7 @@ def test_assemble_restatement_matches_live_reference(seed, tmp_path):
 def test_conv_dispatch_table_is_stable():
     """Host-side dispatch of rfx_conv2d_f32 (no GPU needed): which kernel instance a layer geometry gets.  Bits: 0-1 tile
     variant, 2 = 1x1 specialisation, 3 = wave-specialised form (off by default), 4 = 16-byte pixel loads, 5 = direct 3x3
-    kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4)."""
+    kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4), 10 = k-major 1x1 kernel."""
     lib = _lib.load()
     kid = lambda N, Cin, Cout, k, s, p, Ho, Wo: lib.rfx_conv2d_kernel_id(N, Cin, Cout, k, k, s, p, Ho, Wo)
     # direct 3x3 / stride 1: big layers -> 128-channel tiles, 8x16 patches
@@ -383,10 +383,12 @@ def test_conv_dispatch_table_is_stable():
     assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 2                            # ... a single image: 64x64 tiles fill the chip
     assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 0                          # strided 3x3 -> implicit GEMM, 128x128 tile
     # 1x1: 16-byte pixel loads only for stride 1 and H*W % 4 == 0
-    assert kid(64, 64, 256, 1, 1, 0, 120, 160) == 4 | 16
-    assert kid(64, 256, 1024, 1, 1, 0, 34, 45) == 4                         # 1530 pixels per plane: scalar pixel loads
-    assert kid(64, 256, 512, 1, 2, 0, 60, 80) == 4                          # strided 1x1
-    assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 4 | 16 | 1                # Cout = 64 -> 64-wide channel tile
+    # ... on the k-major kernel of conv1x1.hip (bit 10) when Cin % 32 == 0 and the tile is not the 64x64 one
+    assert kid(64, 64, 256, 1, 1, 0, 120, 160) == 1024 | 4 | 16
+    assert kid(64, 256, 1024, 1, 1, 0, 34, 45) == 1024 | 4                  # 1530 pixels per plane: scalar pixel loads
+    assert kid(64, 256, 512, 1, 2, 0, 60, 80) == 4                          # strided 1x1 -> generic kernel
+    assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 1024 | 4 | 16 | 1         # Cout = 64 -> 64-wide channel tile
+    assert kid(64, 48, 256, 1, 1, 0, 120, 160) == 4 | 16                    # Cin % 32 != 0 -> generic kernel
     # tiny problems fall back to the 64x64 tile
     assert kid(1, 128, 49, 1, 1, 0, 12, 16) & 3 == 2
     assert lib.rfx_conv2d_tile_variant(64, 256, 120, 160) == 0 and lib.rfx_conv2d_tile_variant(1, 64, 12, 16) == 2
