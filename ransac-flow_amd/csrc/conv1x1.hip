@@ -14,8 +14,8 @@
 //
 // Pipeline (256 threads = 2x2 wavefronts, tile 64*TM channels x 128 pixels, BK = 32, LDS double buffered, ONE barrier
 // per step): while the 16 k-pairs of tile s run on the matrix pipe, tile s+1 goes registers -> LDS (other buffer) in the
-// shadow of the first MFMA chunks and the global loads of tile s+2 are issued in the shadow of the last ones -- never
-// as a burst in front of the MFMAs (that cost the direct 3x3 kernel 13 %, scripts/ubench/conv_bench.py).
+// shadow of the first MFMA chunks and each register is re-loaded with tile s+2 right behind its store -- never as a burst
+// in front of the MFMAs (that cost the direct 3x3 kernel 13 %, scripts/ubench/conv_bench.py).
 // k runs in the same pairs and the same order as in conv.hip: bit-identical results.
 #include "common.h"
 #include "conv_epilogue.h"
@@ -147,34 +147,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
             // tile s+1: registers -> the other LDS buffer (chunks 0, 1); tile s+2: global -> registers (chunks 2, 3)
             constexpr bool ST = RFX_C1_DBG != 1 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
             constexpr bool LD = RFX_C1_DBG != 2 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
-            if (c == 0) {
-                if (ST) {
+            // a register is re-loaded (tile s+2) right after it was stored (tile s+1), in chunks 0 / 1: the loads get the rest
+            // of the step to land (with the loads in chunks 2 / 3 the next step's first store waits for them: -5 % in
+            // scripts/ubench/mfma_mix.hip, variants g and g/1)
+            {
+                if (c == 0) {
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) store_a(cur ^ 1, j);
+                    for (int j = 0; j < NA; ++j) {
+                        if (ST) store_a(cur ^ 1, j); else if (LD) asm volatile("" ::"v"(ra[j]));
+                    }
 #pragma unroll
-                    for (int j = 0; j < NB / 2; ++j) store_b(cur ^ 1, j);
-                } else if (LD) {   // keep the loads alive (and waited for) without the LDS stores
+                    for (int j = 0; j < NA; ++j) if (LD) load_a(k2, j);
+                } else if (c == 1) {
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) asm volatile("" ::"v"(ra[j]));
+                    for (int j = 0; j < NB; ++j) {
+                        if (ST) store_b(cur ^ 1, j);
+                        else if (LD) { if (VEC) asm volatile("" ::"v"(rv[VEC ? j : 0])); else asm volatile("" ::"v"(rb[VEC ? 0 : j])); }
+                    }
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) { if (VEC) asm volatile("" ::"v"(rv[VEC ? j : 0])); else asm volatile("" ::"v"(rb[VEC ? 0 : j])); }
-                }
-            } else if (c == 1) {
-                if (ST) {
-#pragma unroll
-                    for (int j = NB / 2; j < NB; ++j) store_b(cur ^ 1, j);
-                }
-            } else if (c == 2) {
-                if (LD) {
-#pragma unroll
-                    for (int j = 0; j < NA; ++j) load_a(k2, j);
-#pragma unroll
-                    for (int j = 0; j < NB / 2; ++j) load_b(k2, j);
-                }
-            } else {
-                if (LD) {
-#pragma unroll
-                    for (int j = NB / 2; j < NB; ++j) load_b(k2, j);
+                    for (int j = 0; j < NB; ++j) if (LD) load_b(k2, j);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

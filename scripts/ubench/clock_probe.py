@@ -21,7 +21,7 @@ from conv_bench import SHAPES  # noqa: E402
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c128_120x160"
     secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
-    N, Cin, H, W, Cout, k, stride, _ = SHAPES[name]
+    N, Cin, H, W, Cout, k, stride, _ = SHAPES[name][:8]
     dev = torch.device("cuda:0")
     w = torch.randn(Cout, Cin, k, k) * 0.05
     plan = ops.ConvPlan(w, None, stride=stride, pad=k // 2, act=ops.ACT_RELU, device=dev)

@@ -27,7 +27,10 @@ SHAPES = {
     "l3_256_34x45": (64, 256, 34, 45, 256, 3, 1, 0),
     "tail64_120x160": (128, 64, 120, 160, 64, 3, 1, 256),    # layer1 conv2 + conv3 fused
     "tail128_60x80": (128, 128, 60, 80, 128, 3, 1, 512),     # layer2 conv2 + conv3 fused
-    "pw256_1024_30x40": (128, 256, 30, 40, 1024, 1, 1, 0),   # layer3 conv3
+    "pw256_1024_30x40": (128, 256, 30, 40, 1024, 1, 1, 0),   # layer3 conv3 (without its residual)
+    "pw256_1024_30x40_res": (128, 256, 30, 40, 1024, 1, 1, 0, True),   # layer3 conv3 + bn3 + residual + relu, as in the trunk
+    "pw256_1024_36x48_res": (64, 256, 36, 48, 1024, 1, 1, 0, True),
+    "pw256_1024_34x45_res": (64, 256, 34, 45, 1024, 1, 1, 0, True),
     "pw1024_256_30x40": (128, 1024, 30, 40, 256, 1, 1, 0),   # layer3 conv1
     "pw256_1024_34x45": (64, 256, 34, 45, 1024, 1, 1, 0),    # odd plane (scalar pixel path)
     "pw512_128_60x80": (128, 512, 60, 80, 128, 1, 1, 0),
@@ -47,7 +50,8 @@ def main():
     rows = []
     warm = False
     for name in a.shapes:
-        N, Cin, H, W, Cout, k, stride, Cexp = SHAPES[name]
+        N, Cin, H, W, Cout, k, stride, Cexp = SHAPES[name][:8]
+        with_res = len(SHAPES[name]) > 8 and SHAPES[name][8]
         g = torch.Generator().manual_seed(7)
         w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
         bn = dict(weight=torch.rand(Cout, generator=g) + 0.5, bias=torch.randn(Cout, generator=g) * 0.1,
@@ -65,8 +69,9 @@ def main():
             Ho, Wo = H, W
             flops = 2.0 * N * H * W * (Cout * Cin * 9 + Cexp * Cout)
         else:
-            run = lambda x: plan(x)                                     # noqa: E731
             Ho, Wo = plan.out_hw(H, W)
+            r1 = torch.randn(N, Cout, Ho, Wo, device=dev, generator=gd) if with_res else None
+            run = lambda x: plan(x, residual=r1)                        # noqa: E731
             flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         out = run(xs[0])
         torch.cuda.synchronize()
