@@ -89,6 +89,9 @@ int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const 
  * "quad" order wQ3[q][h][m][j] = W3[m][8q + 2j + h] (q < Cmid/8, h < 2, m < Cexp, j < 4; 16-byte aligned): the four MFMA A
  * operands of a lane for four consecutive k-pairs are one 16-byte load, coalesced over the channels;
  * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.  Bit-identical to the two rfx_conv2d_f32 calls. */
+/* Kernel instance of the launch below (conv3x3_direct_kernel<TM, PT_C, true> as rocprofv3 prints it): bit 9 set, bit 0 =
+ * 64-channel mid tile (TM = 1), bits 6-7 = output patch shape as in rfx_conv2d_kernel_id. */
+int rfx_conv3x3_conv1x1_kernel_id(int N, int H, int W, int Cmid);
 int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
                             const float* wQ3, const float* scale3, const float* shift3, const float* residual, int act3,
                             float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream);

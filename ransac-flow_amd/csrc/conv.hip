@@ -353,7 +353,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
-int rfx_conv3x3_patch_cols(int H, int W);                                              // conv3x3.hip
+int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused);                                       // conv3x3.hip
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
                               hipStream_t st);                                          // conv1x1.hip
@@ -385,8 +385,8 @@ static int conv_ws_env() {
 static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct) {
     static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
     if (allow_direct && direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
-        const int pc = rfx_conv3x3_patch_cols(Hout, Wout), pr = 128 / pc;
-        const long long tiles = (long long)N * ((Hout + pr - 1) / pr) * ((Wout + pc - 1) / pc);
+        const int pc = rfx_conv3x3_patch_cols(N, Hout, Wout, false), pr = 128 / pc;
+        const long long tiles = (((long long)N * (Hout + 1) + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
         return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128));
     }
@@ -416,7 +416,7 @@ extern "C" int rfx_conv3x3_f32(const float* in, const float* wP, const float* sc
     if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
     if ((long long)Cin * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
     const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true);
-    const int pc = rfx_conv3x3_patch_cols(H, W);
+    const int pc = rfx_conv3x3_patch_cols(N, H, W, false);
     const int tm = (kid & 32) ? ((kid & 3) ? 1 : 2) : (Cout > 64 ? 2 : 1);   // RFX_CONV_DIRECT=0 only changes the host's choice
     return rfx_conv3x3_direct_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, (Cout + 127) / 128 * 128, act,
                                      tm, pc, rfx_stream(stream));

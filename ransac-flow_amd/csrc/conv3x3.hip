@@ -29,6 +29,11 @@ namespace {
 // the fewest pixels on the image at hand: the trunk runs on 25x33 ... 36x48 maps at its small scales).  A 32-lane half
 // of a B read covers 32/PT_C patch rows; the LDS row stride BS puts those rows on disjoint banks:
 //   PT_C 16 -> 2 rows,  BS 48 (row offsets 0,16);  PT_C 8 -> 4 rows, BS 24 (0,24,16,8);  PT_C 4 -> 8 rows, BS 12 (0,12,24,4,16,28,8,20).
+// The images of a batch are tiled as ONE tall map: image n occupies rows n*(H+1) .. n*(H+1)+H-1 of a stack whose row
+// n*(H+1)+H is a virtual all-zero row -- at once the bottom halo of image n and the top halo of image n+1.  Patches tile
+// the stack, so a patch may straddle two (or, on tiny maps, several) images and only the LAST patch row of the whole batch
+// is ragged: a 25x33 map costs 26/25 instead of 32/25 in the row direction (the 7-level pyramid puts a quarter of the
+// 3x3 work on such maps).  Outputs that fall on a virtual row are computed and dropped (1/(H+1) of the work).
 template <int PT_C_> struct Patch {
     static constexpr int PT_C = PT_C_, PT_R = 128 / PT_C_;
     static constexpr int PR = PT_R + 2, PC = PT_C + 2;        // input patch incl. halo
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
 
-    const int tilesP = a.N * a.tilesH * a.tilesW;
+    const int tilesP = a.tilesH * a.tilesW;     // tilesH counts patch rows of the whole stack
     const int nwg = a.tilesM * tilesP;
     int bid = blockIdx.x;
     RFX_STAMP(0);
@@ -96,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int m0 = (bid % a.tilesM) * BM;
-    int pt = bid / a.tilesM;
-    const int n = pt / (a.tilesH * a.tilesW);
-    pt -= n * a.tilesH * a.tilesW;
-    const int oh0 = (pt / a.tilesW) * PT_R, ow0 = (pt % a.tilesW) * PT_C;
+    const int pt = bid / a.tilesM;
+    const int R0 = (pt / a.tilesW) * PT_R, ow0 = (pt % a.tilesW) * PT_C;    // first stack row / column of the patch
+    const int Hs = a.H + 1, Rtot = a.N * Hs;                                 // stack period, stack height
     const size_t HW = (size_t)a.H * a.W;
-    const float* inn = a.in + (size_t)n * a.Cin * HW;
+    const int nbase = (R0 > 0 ? R0 - 1 : 0) / Hs;                            // image of the first input row of the patch
+    const float* inn = a.in + (size_t)nbase * a.Cin * HW;                    // 32-bit patch offsets are relative to it
 
     if (t < BM) {
         const int m = m0 + t;
@@ -138,9 +143,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
         const bool real = idx < CH * PR * PC;
         const int cl = idx / (PR * PC), rem = idx - cl * (PR * PC);
         const int pr = rem / PC, px = rem - pr * PC;
-        const int gy = oh0 - 1 + pr, gx = ow0 - 1 + px;
-        bok[u] = real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        boffB[u] = bok[u] ? (unsigned)(((int)(cl * HW) + gy * a.W + gx) * 4) : 0u;
+        const int Rin = R0 - 1 + pr, gx = ow0 - 1 + px;                      // stack row -> (image, row); row H is virtual
+        const int ni = (Rin >= 0 ? Rin : 0) / Hs, gy = Rin - ni * Hs;
+        bok[u] = real && Rin >= 0 && Rin < Rtot && gy < a.H && (unsigned)gx < (unsigned)a.W;
+        boffB[u] = bok[u] ? ((unsigned)((ni - nbase) * a.Cin + cl) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : 0u;
         blds[u] = real ? (cl * PR + pr) * BS + px : ((CH - 1) * PR + PR - 1) * BS + PC + (idx - CH * PR * PC) % (BS - PC);
     }
 
@@ -259,9 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
     const int Cfinal = FUSE ? a.Cexp : a.Cout;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int oh = oh0 + wn * 2 * RH + j * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
-        pix_ok[j] = oh < a.H && ow < a.W;
-        pix_off[j] = (size_t)n * Cfinal * HW + (size_t)(pix_ok[j] ? oh : 0) * a.W + (pix_ok[j] ? ow : 0);
+        const int R = R0 + wn * 2 * RH + j * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
+        const int n = R / Hs, oh = R - n * Hs;
+        pix_ok[j] = R < Rtot && oh < a.H && ow < a.W;
+        pix_off[j] = pix_ok[j] ? (size_t)n * Cfinal * HW + (size_t)oh * a.W + ow : 0;
     }
     if constexpr (!FUSE) {
         const bool full = m0 + BM <= a.Cout;
@@ -342,14 +349,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 
 }  // namespace
 
-// Patch shape with the fewest padded pixels for an H x W map (ties: the widest, whose stores coalesce best).
-int rfx_conv3x3_patch_cols(int H, int W) {
+// Patch shape for a batch of N H x W maps stacked as above: the fewest padded pixels (ties: the widest, whose row segments
+// coalesce best).  The fused Bottleneck tail writes Cexp channels per pixel from a narrow patch in short row segments:
+// measured on equal work its 16x8 patch is ~5 % and its 32x4 patch ~40 % slower than 8x16, while the plain 3x3 kernel is
+// indifferent (scripts/ubench/conv_bench.py on the 25x33 ... 112x148 maps of the pyramid) -- hence the weights.
+int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     int best = 16;
-    long long best_area = -1;
+    long long best_cost = -1;
     for (int pc = 16; pc >= 4; pc >>= 1) {
         const int pr = 128 / pc;
-        const long long area = (long long)((H + pr - 1) / pr) * ((W + pc - 1) / pc);
-        if (best_area < 0 || area < best_area) { best_area = area; best = pc; }
+        const long long area = (((long long)N * (H + 1) + pr - 1) / pr) * ((W + pc - 1) / pc);
+        const long long cost = area * (!fused || pc == 16 ? 100 : (pc == 8 ? 105 : 140));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pc; }
     }
     return best;
 }
@@ -357,10 +368,14 @@ int rfx_conv3x3_patch_cols(int H, int W) {
 template <int TM, int PTC, bool FUSE = false>
 static int launch_direct(C3Args& a, hipStream_t st) {
     using G = Patch<PTC>;
-    a.tilesH = (a.H + G::PT_R - 1) / G::PT_R;
+    const long long rows = (long long)a.N * (a.H + 1);
+    a.tilesH = (int)((rows + G::PT_R - 1) / G::PT_R);
     a.tilesW = (a.W + G::PT_C - 1) / G::PT_C;
-    const long long nwg = (long long)a.tilesM * a.N * a.tilesH * a.tilesW;
-    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    const long long nwg = (long long)a.tilesM * a.tilesH * a.tilesW;
+    if (nwg > 0x7fffffffLL || rows > 0x7fffffffLL) return RFX_E_LIMIT;
+    // 32-bit byte offsets inside the images one input patch can touch
+    const long long span = (G::PR + a.H) / (a.H + 1) + 1;
+    if (span * a.Cin * a.H * a.W * 4 > 0xffffffffLL) return RFX_E_LIMIT;
     hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
@@ -393,6 +408,13 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
 // Bottleneck tail in one kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual)  (model/resnet50.py:71-79,93-103).
 // The 3x3 convolution must be direct-eligible (stride 1, pad 1, Cin % 8 == 0) with Cmid in {64, 128} so that one workgroup
 // tile holds all of its channels; Cexp % 128 == 0.
+// Kernel instance rfx_conv3x3_conv1x1_f32 launches (for a profiler-side caller, as rfx_conv2d_kernel_id): bit 9 = fused
+// tail, bit 0 = 64-channel mid tile (TM = 1), bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4).
+extern "C" int rfx_conv3x3_conv1x1_kernel_id(int N, int H, int W, int Cmid) {
+    const int pc = rfx_conv3x3_patch_cols(N, H, W, true);
+    return 512 | (Cmid == 64 ? 1 : 0) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128));
+}
+
 extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
                                        const float* wQ3, const float* scale3, const float* shift3, const float* residual,
                                        int act3, float* out, int N, int Cin, int H, int W, int Cmid, int Cexp, void* stream) {
@@ -409,7 +431,7 @@ extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const 
 #endif
     a.tilesM = 1;
     hipStream_t st = rfx_stream(stream);
-    const int pc = rfx_conv3x3_patch_cols(H, W);
+    const int pc = rfx_conv3x3_patch_cols(N, H, W, true);
     if (Cmid == 128) {
         if (pc == 16) return launch_direct<2, 16, true>(a, st);
         if (pc == 8) return launch_direct<2, 8, true>(a, st);

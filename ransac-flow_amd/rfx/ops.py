@@ -207,8 +207,8 @@ def bottleneck_tail(x, plan2, plan3, residual=None):
         e1 = Profiler.end(e0)
         flops = 2.0 * N * H * W * (plan2.Cout * plan2.Cin * 9 + plan3.Cout * plan3.Cin)
         nbytes = 4.0 * N * H * W * (C + plan3.Cout * (2 if res is not None else 1))
-        kid = _lib.load().rfx_conv2d_kernel_id(N, C, plan2.Cout, 3, 3, 1, 1, H, W)      # patch-shape bits of the 3x3 part
-        Profiler.active().conv.append((512 | (kid & 192) | (1 if plan2.Cout == 64 else 0), flops, e0, e1,
+        kid = _lib.load().rfx_conv3x3_conv1x1_kernel_id(N, H, W, plan2.Cout)
+        Profiler.active().conv.append((kid, flops, e0, e1,
                                        (N, C, H, W, plan3.Cout, 3, 1), nbytes))
     return out
 

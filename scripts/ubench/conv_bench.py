@@ -27,6 +27,13 @@ SHAPES = {
     "l3_256_34x45": (64, 256, 34, 45, 256, 3, 1, 0),
     "tail64_120x160": (128, 64, 120, 160, 64, 3, 1, 256),    # layer1 conv2 + conv3 fused
     "tail128_60x80": (128, 128, 60, 80, 128, 3, 1, 512),     # layer2 conv2 + conv3 fused
+    "tail64_100x132": (64, 64, 100, 132, 64, 3, 1, 256),     # ... at the small pyramid levels
+    "tail64_112x148": (64, 64, 112, 148, 64, 3, 1, 256),
+    "tail128_50x66": (64, 128, 50, 66, 128, 3, 1, 512),
+    "tail128_62x84": (64, 128, 62, 84, 128, 3, 1, 512),
+    "l3_256_26x35": (64, 256, 26, 35, 256, 3, 1, 0),
+    "l3_256_28x37": (64, 256, 28, 37, 256, 3, 1, 0),
+    "l3_256_31x42": (64, 256, 31, 42, 256, 3, 1, 0),
     "pw256_1024_30x40": (128, 256, 30, 40, 1024, 1, 1, 0),   # layer3 conv3 (without its residual)
     "pw256_1024_30x40_res": (128, 256, 30, 40, 1024, 1, 1, 0, True),   # layer3 conv3 + bn3 + residual + relu, as in the trunk
     "pw256_1024_36x48_res": (64, 256, 36, 48, 1024, 1, 1, 0, True),
@@ -35,6 +42,9 @@ SHAPES = {
     "pw256_1024_34x45": (64, 256, 34, 45, 1024, 1, 1, 0),    # odd plane (scalar pixel path)
     "pw512_128_60x80": (128, 512, 60, 80, 128, 1, 1, 0),
     "s2_64_128_240x320": (128, 64, 240, 320, 128, 3, 2, 0),
+    "s2_128_128_120x160": (128, 128, 120, 160, 128, 3, 2, 0),  # layer2.0 conv2 (stride 2): generic implicit-GEMM kernel
+    "ds_256_512_s2_120x160": (128, 256, 120, 160, 512, 1, 2, 0),   # layer2.0 downsample (1x1 stride 2)
+    "head49_512_60x80": (64, 49, 60, 80, 512, 3, 1, 0),         # NetFlowCoarse conv1 (Cin = 49)
 }
 
 
