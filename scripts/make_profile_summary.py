@@ -76,6 +76,10 @@ for cfg, n in (("ev", 64), ("qs", 64)):
     p = os.path.join(src, "parity_sweep_%s_%d.json" % (cfg, n))
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_parity_sweep_%s_%dpairs.json" % (RND, cfg, n)))
+for name, out in (("conv_bench_all.txt", "_conv_bench.txt"), ("mfma_mix.txt", "_mfma_mix.txt")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, RND + out))
 p = os.path.join(src, "corr_variants.json")
 if os.path.exists(p):
     shutil.copy(p, os.path.join(dst, RND + "_corr_variants.json"))
