@@ -193,6 +193,7 @@ def self_spawn(args):
 
 def build_workload(args, dev, rank, world):
     """Returns (step() -> (B, width) float32 record tensor on ``dev``, meta dict, extras for the parity leg)."""
+    import torch
     from rfx import weights, synth
     from rfx.pipeline import AlignPipeline
     from rfx import dist as rdist
@@ -238,11 +239,16 @@ def build_workload(args, dev, rank, world):
     pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", device=dev)
     raws = [pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True, amp=0.02)]) for s in seeds]
 
+    raw_all = (torch.cat([r[0] for r in raws]), torch.cat([r[1] for r in raws]))
+    lock_step = os.environ.get("RFX_KITTI_LOCKSTEP", "1") != "0"     # 0: the per-pair driver, pair after pair
+
     def step():
+        if lock_step:
+            return _multi_h_records(pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01), dev)
         return _multi_h_records([pipe.multi_h_kitti(r[0], r[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01) for r in raws], dev)
     wl = ("BASELINE config 5: %d evalKITTI-shaped %dx%d pairs per GPU per step (coarseSize 800 -> 2640x800 target, 3 scales "
           "x1.2, nA = 25 747, coarseIter 50 000; fineSize 650: two-resolution fine pass, cycle-checked matchability, "
-          "cc-filter 0.01 on the host, maskRegionTh 0.005), per-pair driver" % (B, W, H))
+          "cc-filter 0.01 on the host, maskRegionTh 0.005), %s" % (B, W, H, "lock-step driver over the batch" if lock_step else "per-pair driver"))
     return step, dict(workload=wl, nbIter=50000, nbScale=3, matchability_init_std=MULTIH_MATCH_STD), dict(pipe=pipe, seeds=seeds)
 
 

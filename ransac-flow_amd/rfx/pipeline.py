@@ -553,6 +553,85 @@ class AlignPipeline:
         out["mask"] = Mask
         return out
 
+    def multi_h_kitti_batched(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, sample_fn=None,
+                              remove_small_cc=None):
+        """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
+        computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
+        the match filtering, RANSAC (rfx_ransac_h4_batched), the two warps and both PredFlowMask passes over the active
+        pairs, ONE device->host->device round trip of their matchability maps for the host cc-filter, and two host syncs per
+        round (match counts; acceptance statistics) instead of two per pair and homography.  Per pair the arithmetic and the
+        accept / stop rule are multi_h_kitti()'s (evaluation/evalKITTI/evaluation.py:257-336); batch-1 fine passes become
+        batch-a ones, which is where the time goes (the 3x3 kernels run at 0.59 of the matrix peak at batch 1, 0.8 at batch 8).
+        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor (default: torch.randint, active pairs in ascending order).
+        Returns a list of dicts like multi_h_kitti()."""
+        dev = self.dev
+        B, h_org, w_org = tgt_u8.shape[0], tgt_u8.shape[1], tgt_u8.shape[2]
+        prep = self.prepare_device(src_u8, tgt_u8)
+        feats = self.features(prep)
+        w_r, h_r = self.resize_img_dims(w_org, h_org, 8, fineSize)
+        w_d2, h_d2 = self.resize_img_dims(w_org, h_org, 8, fineSize // 2)
+        tensor_s, _ = ops.u8_to_f32(src_u8)                                              # sources at their ORIGINAL size
+        tensor_resize, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_r, h_r))
+        tensor_d2, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_d2, h_d2))
+        rt, ct = feats["rt"], feats["ct"]
+        idx1, idx2, cnt = self._mutual_batched(feats, B)
+        cap = idx1.shape[1]
+        slot_ok = torch.arange(cap, device=dev)[None, :] < cnt[:, None]
+        cell2 = torch.where(slot_ok, idx2, torch.zeros_like(idx2))
+        bg = torch.ones((B, h_org, w_org), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        Mask = torch.zeros((B, h_org, w_org), dtype=torch.float32, device=dev)
+        outs = [dict(H=[], flowD2=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
+        nb = [0] * B
+        draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
+        if cc_th > 0 and remove_small_cc is None:
+            remove_small_cc = _remove_small_cc_scipy
+        eye = torch.eye(3, device=dev)
+        active = list(range(B))
+        while active:
+            A = torch.tensor(active, device=dev)
+            fg = ((Mask[A] + (1 - bg[A])) > 0.5).float()
+            keep = ops.resize_bilinear((1 - fg)[:, None], (rt, ct), align_corners=False)[:, 0] > 0.5
+            valid = keep.flatten(1).gather(1, cell2[A]) & slot_ok[A]
+            n_dev = valid.sum(1).to(torch.int32)
+            n_host = n_dev.cpu().tolist()                                               # sync: sizes of the index draws
+            order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)
+            M1, M2 = ops.gather_matches(idx1[A].gather(1, order), idx2[A].gather(1, order), n_dev, feats["HA"], feats["WA"],
+                                        feats["Ht"], feats["Wt"])
+            smp = torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
+                               for b, n in zip(active, n_host)]).to(dev, non_blocking=True)
+            bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            ok = (res[:, 0] == 0)
+            Hs = torch.where(ok[:, None, None], bestH, eye)                             # failed pairs: any finite warp
+            hom_d2 = ops.warp_grid(Hs, h_d2, w_d2)
+            hom_resize = ops.warp_grid(Hs, h_r, w_r)
+            Is_d2 = ops.grid_sample(tensor_s[A], hom_d2)
+            flow_d2 = self.pred_flow_mask_kitti(Is_d2, tensor_d2[A], hom_d2)["flowDown8"]
+            flowCoarse, _, _ = ops.compose_flow(flow_d2, hom_resize, clamp=True)
+            IsSample = ops.grid_sample(tensor_s[A], flowCoarse)
+            pm = self.pred_flow_mask_kitti(IsSample, tensor_resize[A], flowCoarse, out_hw=(h_org, w_org))
+            match = pm["match"][:, 0]
+            if cc_th > 0:                                                               # host, like :321 -- one round trip per round
+                mh = match.cpu().numpy()
+                match = torch.from_numpy(np.stack([remove_small_cc(mh[k], 0.99, cc_th) for k in range(len(active))])).to(dev)
+            gainv = ((match > 0.9999).float() * (1 - fg)).mean(dim=(1, 2))
+            stat = torch.stack((gainv, res[:, 0].float()), dim=1).cpu().tolist()        # sync: acceptance statistics
+            nxt = []
+            for k, b in enumerate(active):
+                gain, status = stat[k]
+                if n_host[k] < 4 or status != 0 or not (gain > maskRegionTh or nb[b] == 0):
+                    continue
+                outs[b]["H"].append(bestH[k])
+                outs[b]["flowD2"].append(flow_d2[k:k + 1])
+                outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
+                outs[b]["matchDown8"].append(torch.cat((pm["match12Down8"][k:k + 1], pm["match21Down8"][k:k + 1]), dim=1))
+                nb[b] += 1
+                Mask[b] = ((Mask[b] + match[k] * (1 - fg[k])) > 0.9999).float()
+                nxt.append(b)
+            active = nxt
+        for b in range(B):
+            outs[b]["mask"] = Mask[b]
+        return outs
+
     # ---------------------------------------------------------------- whole path
     def align_prepared(self, prep, fine=True, samples=None):
         res = self.coarse(prep, samples=samples)

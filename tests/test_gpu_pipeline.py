@@ -291,6 +291,43 @@ def test_kitti_two_resolution_driver_matches_reference_golden(dev, tag):
     assert len(o["H"]) == nb and np.abs(np.stack(o["H"]) - g["%s_H" % tag]).max() < 1e-5
 
 
+def test_kitti_lock_step_driver_equals_the_per_pair_driver(dev):
+    """pipeline.multi_h_kitti_batched (throughput form of the KITTI driver: the k-th homography of all active pairs in one
+    launch chain) == pipeline.multi_h_kitti pair by pair, given the same index draws: same number of homographies per
+    pair, same H, flows and masks up to batch-size-dependent float32 round-off (none: the kernels are batch-invariant)."""
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=3.0)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=160, scaleR=1.2, variant="B", device=dev)
+    pairs = [synth.make_pair(96, 312, seed=s, homography=True, amp=0.03) for s in (11, 12, 13)]
+    raw = pipe.upload_raw(pairs)
+
+    def draws(b, k, n, it):
+        return torch.randint(n, (it, 4), generator=torch.Generator().manual_seed(1000 * b + k))
+    single = []
+    for b in range(len(pairs)):
+        calls = [0]
+
+        def fn(n, it, b=b, calls=calls):
+            calls[0] += 1
+            return draws(b, calls[0], n, it)
+        single.append(pipe.multi_h_kitti(raw[0][b:b + 1], raw[1][b:b + 1], fineSize=200, maskRegionTh=0.005, cc_th=0.01, sample_fn=fn))
+    ncall = [0] * len(pairs)
+
+    def fnb(b, n, it):
+        ncall[b] += 1
+        return draws(b, ncall[b], n, it)
+    batched = pipe.multi_h_kitti_batched(raw[0], raw[1], fineSize=200, maskRegionTh=0.005, cc_th=0.01, sample_fn=fnb)
+    assert max(len(o["H"]) for o in single) >= 2
+    for b, (s1, m) in enumerate(zip(single, batched)):
+        assert len(s1["H"]) == len(m["H"]), (b, len(s1["H"]), len(m["H"]))
+        for k in range(len(s1["H"])):
+            assert (s1["H"][k] - m["H"][k]).abs().max() < 1e-6
+            assert (s1["flowD2"][k] - m["flowD2"][k]).abs().max() < 1e-5
+            assert (s1["flowDown8"][k] - m["flowDown8"][k]).abs().max() < 1e-5
+            assert (s1["matchDown8"][k] - m["matchDown8"][k]).abs().max() < 1e-5
+        assert float((s1["mask"] != m["mask"]).float().mean()) < 1e-4
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_multi_homography_driver_matches_reference_golden(dev, tag):
     """pipeline.multi_h / multi_h_batched against tests/golden/multi_h.npz: the outputs of the reference's own
