@@ -14,7 +14,7 @@ Workloads (``--config``; BASELINE.json ``configs``):
                 (maxCoarse 10, maskRegionTh 0.01) with a PredFlowMask per homography (evaluation/evalHpatch/evaluation.py:193-243).
   4             evalHpatch-shaped stream: 960x720 pairs, minSize 720, 5 scales x2, coarseIter 50 000, multi-H on.
   5             evalKITTI-shaped stream: 1242x376 pairs, coarseSize 800, 3 scales x1.2, coarseIter 50 000, fineSize 650,
-                two-resolution fine pass, cycle-checked matchability, cc-filter on the host (evaluation/evalKITTI/evaluation.py).
+                two-resolution fine pass, cycle-checked matchability, cc-filter on the device (evaluation/evalKITTI/evaluation.py).
 The default run also times a short config-3 leg (``extra.config3_multi_h``) and, on rank 0 at N = 1, the CPU legs below.
 
 N > 1: ``python bench.py --gpus N`` re-launches itself under ``torch.distributed.run`` (one rank per GPU, RCCL); when the
@@ -248,7 +248,7 @@ def build_workload(args, dev, rank, world):
         return _multi_h_records([pipe.multi_h_kitti(r[0], r[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01) for r in raws], dev)
     wl = ("BASELINE config 5: %d evalKITTI-shaped %dx%d pairs per GPU per step (coarseSize 800 -> 2640x800 target, 3 scales "
           "x1.2, nA = 25 747, coarseIter 50 000; fineSize 650: two-resolution fine pass, cycle-checked matchability, "
-          "cc-filter 0.01 on the host, maskRegionTh 0.005), %s" % (B, W, H, "lock-step driver over the batch" if lock_step else "per-pair driver"))
+          "cc-filter 0.01 (device union-find labelling), maskRegionTh 0.005), %s" % (B, W, H, "lock-step driver over the batch" if lock_step else "per-pair driver"))
     return step, dict(workload=wl, nbIter=50000, nbScale=3, matchability_init_std=MULTIH_MATCH_STD), dict(pipe=pipe, seeds=seeds)
 
 

@@ -225,6 +225,16 @@ int rfx_merge_multi_h_f32(const float* flow, const float* match12, long long mat
 int rfx_match_score_f32(const float* match12, long long match12_stride, const float* cyc, const float* inb, int n,
                         long long HW, float* score, void* stream);
 
+/* The small-component filter of the KITTI scripts (evaluation/evalKITTI/evaluation.py:85-100 online -- remove_small_cc(match,
+ * 0.99, cc_th) at :321 -- and evaluation/evalKITTI/getResults.py:66-84 offline, :122), which the reference runs on the host
+ * with skimage.measure.label: out = in with every 8-connected component of (in > match_th) of at most max_area pixels set to
+ * zero, per image of the (N,H,W) batch.  max_area = the largest pixel count a with a / (H*W) <= cc_th in float64 (the host
+ * mirrors compute it so; the reference's test is on the area FRACTION).  ws: rfx_remove_small_cc_ws_bytes(N,H,W) bytes.
+ * Exact: the result of a labelling does not depend on the label numbering.  in and out may be the same buffer. */
+size_t rfx_remove_small_cc_ws_bytes(int N, int H, int W);
+int rfx_remove_small_cc_f32(const float* in, float* out, int N, int H, int W, float match_th, int max_area, void* ws,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * All-pairs correlation + mutual nearest neighbours (utils/outil.py:32-45, mutualMatching).
  * featA: (C, nA) and featB: (C, nB), column = one cell ("K-major": element (k,i) at k*ld+i).

@@ -39,6 +39,8 @@ SIGNATURES = {
     "rfx_merge_multi_h_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_float, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "rfx_match_score_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "rfx_remove_small_cc_ws_bytes": (c_size_t, [c_int] * 3),
+    "rfx_remove_small_cc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "rfx_mutual_nn_ws_bytes": (c_size_t, [c_int, c_int]),
     "rfx_mutual_nn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "rfx_mutual_nn_batched_f32": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_int, c_longlong, c_int]

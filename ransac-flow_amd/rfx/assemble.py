@@ -9,7 +9,7 @@ ONE dense flow (and confidence) at the evaluation resolution:
 Reference: evaluation/evalHpatch/getResults.py:16-63, evaluation/evalCorr/getResults.py:78-136,
 evaluation/evalKITTI/getResults.py:95-141.  Device work = librfx kernels (rfx_warp_grid_f32, rfx_compose_flow_f32,
 rfx_resize_bilinear_f32, rfx_grid_sample_f32, rfx_match_score_f32, rfx_merge_multi_h_f32); reading the ``.npy`` files
-and KITTI's connected-component filter / nearest-neighbour fill stay on the host like in the reference (scipy).
+KITTI's connected-component filter runs on the device (rfx_remove_small_cc_f32); its nearest-neighbour fill stays on the host like in the reference (scipy).
 
 On-disk formats (written by evaluation/evalHpatch/evaluation.py:254-260 and friends):
     <fine>/flow_{id}_{n}H.npy   (n,2,h/8,w/8) float   fine flow, stride 8
@@ -52,21 +52,8 @@ def assemble(flowDown, param, matchDown, out_hw, th, multiH, cycle, device="cuda
 
 
 def remove_small_cc(score, cc_th, match_th=0.99):
-    """evalKITTI/getResults.py:66-84 on the host (scipy 8-connected labelling = skimage.measure.label's default)."""
-    if cc_th == 0:
-        return score
-    from scipy import ndimage
-    m = score.cpu().numpy().copy()
-    st = np.ones((3, 3), dtype=np.int32)
-    for j in range(m.shape[0]):
-        lab, k = ndimage.label(m[j] > match_th, structure=st)
-        if k == 0:
-            continue
-        area = np.bincount(lab.ravel(), minlength=k + 1) / float(lab.size)
-        small = np.nonzero(area[1:] <= cc_th)[0] + 1
-        if len(small):
-            m[j][np.isin(lab, small)] = 0
-    return torch.from_numpy(m).to(score.device)
+    """evalKITTI/getResults.py:66-84 (skimage.measure.label on the host there) on the device: rfx_remove_small_cc_f32."""
+    return ops.remove_small_cc(score, cc_th, match_th)
 
 
 def interpolate_flow_match(flowGlobal, binary):

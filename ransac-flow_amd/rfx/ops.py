@@ -466,6 +466,34 @@ def merge_multi_h(flow, match12, th, multiH, cyc=None, inb=None):
     return fg, mg, binary.bool()
 
 
+def cc_max_area(size, cc_th):
+    """Largest pixel count a with ``a / float(size) <= cc_th`` in float64 -- the reference's test
+    (``np.mean(lab == i) <= cc_th`` / ``area <= cc_th`` on area fractions, evalKITTI/evaluation.py:96) as an integer bound."""
+    a = int(cc_th * size)
+    while (a + 1) / float(size) <= cc_th:
+        a += 1
+    while a > 0 and a / float(size) > cc_th:
+        a -= 1
+    return a
+
+
+def remove_small_cc(match, cc_th, match_th=0.99):
+    """evaluation/evalKITTI/evaluation.py:85-100 / getResults.py:66-84 on the device: zero every 8-connected component of
+    (match > match_th) whose area fraction is <= cc_th.  match (N,H,W) or (H,W) float32; returns a new tensor."""
+    m = _dev(match, "match map")
+    if cc_th == 0:
+        return m
+    squeeze = m.dim() == 2
+    m3 = (m[None] if squeeze else m).contiguous()
+    N, H, W = m3.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.rfx_remove_small_cc_ws_bytes(N, H, W), dtype=torch.uint8, device=m3.device)
+    out = torch.empty_like(m3)
+    _call("rfx_remove_small_cc_f32", _one_device(m3), _p(m3), _p(out), N, H, W, float(match_th), cc_max_area(H * W, float(cc_th)),
+          _p(ws))
+    return out[0] if squeeze else out
+
+
 def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
     """featA (C,nA), featB (C,nB) -> (index1, index2) int64 device tensors (ascending index1).
     Synchronises once to read the match count (the reference's nonzero() does the same)."""

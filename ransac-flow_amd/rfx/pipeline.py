@@ -54,25 +54,6 @@ def cell_coords(n_rows, n_cols, device):
     return (W - 0.5) * 2, (Hh - 0.5) * 2
 
 
-def _remove_small_cc_scipy(match, match_th, cc_th):
-    """evaluation/evalKITTI/evaluation.py:85-100 on the host, as in the reference (skimage.measure.label there; scipy's
-    labelling with a full 3x3 structure = the same 8-connected components): zero every component of (match > match_th)
-    whose area fraction is <= cc_th."""
-    from scipy import ndimage
-    if cc_th == 0:
-        return match
-    lab, n = ndimage.label(match > match_th, structure=np.ones((3, 3), dtype=np.int32))
-    if n == 0:
-        return match
-    area = np.bincount(lab.ravel(), minlength=n + 1) / float(lab.size)
-    small = np.flatnonzero(area <= cc_th)
-    small = small[small != 0]
-    if small.size:
-        match = match.copy()
-        match[np.isin(lab, small)] = 0
-    return match
-
-
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
                  device="cuda", kernelSize=7):
@@ -488,11 +469,11 @@ class AlignPipeline:
         (ORIGINAL resolution) warped to the half resolution (:284) -> PredFlowMask there (:290) -> its /8 flow composed
         with the full-resolution homography grid (:294-297) -> source warped by it (:299) -> PredFlowMask whose outputs live
         at the ORIGINAL target resolution (:302) -> small-component filter on the host, like the reference's skimage call
-        (:321; ``remove_small_cc(match ndarray, 0.99, cc_th)``, default scipy 8-connectivity labelling) -> accept iff
+        (:321; on the device, ops.remove_small_cc; ``remove_small_cc(match ndarray, 0.99, cc_th)`` injects a host filter) -> accept iff
         ((match > 0.9999) outside the mask).mean() > maskRegionTh or first homography (:322) -> mask update (:333).
         The loop is the reference's ``while True``: it ends on the accept test or when fewer than 4 matches survive.
         LANCZOS resizes (outil.resizeImg) run on the device, byte-exact vs Pillow.  Host syncs per homography: match count,
-        RANSAC status + accept statistic (+ one D2H/H2D of the h_org x w_org matchability map when cc_th > 0).
+        RANSAC status + accept statistic.
         Returns dict(H=[...], flowD2=[...], flowDown8=[...], matchDown8=[...], mask)."""
         dev = self.dev
         if prep is None:
@@ -513,8 +494,6 @@ class AlignPipeline:
         Mask = torch.zeros((h_org, w_org), dtype=torch.float32, device=dev)
         out = dict(H=[], flowD2=[], flowDown8=[], matchDown8=[])
         draw = sample_fn or (lambda n, it: torch.randint(n, (it, 4)))
-        if cc_th > 0 and remove_small_cc is None:
-            remove_small_cc = _remove_small_cc_scipy
         nb = 0
         while True:
             fg = ((Mask + (1 - bg)) > 0.5).float()
@@ -535,8 +514,9 @@ class AlignPipeline:
             IsSample = ops.grid_sample(tensor_s, flowCoarse)
             pm = self.pred_flow_mask_kitti(IsSample, tensor_resize, flowCoarse, out_hw=(h_org, w_org))
             match = pm["match"][0, 0]
-            if cc_th > 0:
-                match = torch.from_numpy(remove_small_cc(match.cpu().numpy(), 0.99, cc_th)).to(dev)   # host, like :321
+            if cc_th > 0:                                                     # :321 -- on the device unless a host filter is injected
+                match = (ops.remove_small_cc(match, cc_th, 0.99) if remove_small_cc is None else
+                         torch.from_numpy(remove_small_cc(match.cpu().numpy(), 0.99, cc_th)).to(dev))
             stat = torch.stack((((match > 0.9999).float() * (1 - fg)).mean(), res[0].float()))
             gain, status = stat.cpu().tolist()                                # sync: acceptance statistic + status
             if status != 0:
@@ -558,7 +538,7 @@ class AlignPipeline:
         """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
         computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
         the match filtering, RANSAC (rfx_ransac_h4_batched), the two warps and both PredFlowMask passes over the active
-        pairs, ONE device->host->device round trip of their matchability maps for the host cc-filter, and two host syncs per
+        pairs, the small-component filter on the device, and two host syncs per
         round (match counts; acceptance statistics) instead of two per pair and homography.  Per pair the arithmetic and the
         accept / stop rule are multi_h_kitti()'s (evaluation/evalKITTI/evaluation.py:257-336); batch-1 fine passes become
         batch-a ones, which is where the time goes (the 3x3 kernels run at 0.59 of the matrix peak at batch 1, 0.8 at batch 8).
@@ -583,8 +563,6 @@ class AlignPipeline:
         outs = [dict(H=[], flowD2=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
         nb = [0] * B
         draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
-        if cc_th > 0 and remove_small_cc is None:
-            remove_small_cc = _remove_small_cc_scipy
         eye = torch.eye(3, device=dev)
         active = list(range(B))
         while active:
@@ -610,9 +588,12 @@ class AlignPipeline:
             IsSample = ops.grid_sample(tensor_s[A], flowCoarse)
             pm = self.pred_flow_mask_kitti(IsSample, tensor_resize[A], flowCoarse, out_hw=(h_org, w_org))
             match = pm["match"][:, 0]
-            if cc_th > 0:                                                               # host, like :321 -- one round trip per round
-                mh = match.cpu().numpy()
-                match = torch.from_numpy(np.stack([remove_small_cc(mh[k], 0.99, cc_th) for k in range(len(active))])).to(dev)
+            if cc_th > 0:                                                               # :321 -- on the device (rfx_remove_small_cc_f32)
+                if remove_small_cc is None:
+                    match = ops.remove_small_cc(match, cc_th, 0.99)
+                else:                                                                   # an injected host filter: one round trip
+                    mh = match.cpu().numpy()
+                    match = torch.from_numpy(np.stack([remove_small_cc(mh[k], 0.99, cc_th) for k in range(len(active))])).to(dev)
             gainv = ((match > 0.9999).float() * (1 - fg)).mean(dim=(1, 2))
             stat = torch.stack((gainv, res[:, 0].float()), dim=1).cpu().tolist()        # sync: acceptance statistics
             nxt = []

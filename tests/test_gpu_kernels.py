@@ -27,6 +27,46 @@ def relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+# ------------------------------------------------------------------ small-component filter
+def test_remove_small_cc_equals_host_labelling(dev):
+    """rfx_remove_small_cc_f32 (lock-free union-find on the device) == the reference's host filter
+    (evaluation/evalKITTI/evaluation.py:85-100, restated in oracle/restate.py and pinned on the reference's own function):
+    bit for bit on blob maps, diagonal-only (8-connected) chains, all-foreground / all-background maps, one-pixel images,
+    components exactly at the area threshold, and a batch of maps in one launch."""
+    g = torch.Generator().manual_seed(5)
+    maps = []
+    for (H, W, sigma) in ((61, 97, 3.0), (120, 333, 6.0), (47, 50, 1.0)):
+        n = torch.randn(1, 1, H, W, generator=g)
+        k = int(4 * sigma) | 1
+        ax = torch.arange(k) - k // 2
+        ker = torch.exp(-ax.float() ** 2 / (2 * sigma ** 2))
+        ker = (ker[:, None] * ker[None, :]) / ker.sum() ** 2
+        sm = F.conv2d(n, ker[None, None], padding=k // 2)[0, 0]
+        maps.append((torch.sigmoid(40 * sm / sm.std()) * 0.999999).contiguous())
+    diag = torch.zeros(40, 40)
+    for i in range(30):
+        diag[i, i] = 1.0                      # a chain that only 8-connectivity joins
+        diag[39 - i, i] = 0.995 if i < 12 else 0.0
+    maps += [diag, torch.ones(9, 13), torch.zeros(9, 13), torch.ones(1, 1), torch.full((3, 5), 0.99)]
+    for m in maps:
+        for cc_th in (0.01, 0.05, 0.3, 1.0):
+            ref = restate.remove_small_cc_eval(m.numpy().copy(), 0.99, cc_th)
+            out = ops.remove_small_cc(m.to(dev), cc_th, 0.99).cpu().numpy()
+            assert np.array_equal(out, ref), (tuple(m.shape), cc_th)
+    # a component of exactly the threshold area: 12 of 1200 pixels = 0.01 -> removed at cc_th 0.01, kept just below
+    t = torch.zeros(30, 40)
+    t[3, 5:17] = 1.0
+    t[10:20, 10:30] = 1.0
+    assert ops.cc_max_area(1200, 0.01) == 12
+    assert np.array_equal(ops.remove_small_cc(t.to(dev), 0.01).cpu().numpy(), restate.remove_small_cc_eval(t.numpy().copy(), 0.99, 0.01))
+    assert ops.remove_small_cc(t.to(dev), 0.01)[3, 5] == 0 and ops.remove_small_cc(t.to(dev), 0.0099)[3, 5] == 1
+    # batch: the maps of one launch do not see each other
+    b = torch.stack([maps[0][:40, :40], diag, maps[2][:40, :40]]).contiguous()
+    outb = ops.remove_small_cc(b.to(dev), 0.05).cpu().numpy()
+    for j in range(3):
+        assert np.array_equal(outb[j], restate.remove_small_cc_eval(b[j].numpy().copy(), 0.99, 0.05))
+
+
 # ------------------------------------------------------------------ conv family
 
 CONV_CASES = [
