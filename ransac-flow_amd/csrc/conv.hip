@@ -393,7 +393,7 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
-    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && variant != 2 && (long long)N * Hout * Wout >= 4)
+    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4)
         return 1024 | 4 | variant | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0);   // conv1x1.hip
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env > 0);  // off by default: since the branch-free epilogue the single-role kernel is as fast

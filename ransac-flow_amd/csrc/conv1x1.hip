@@ -35,6 +35,12 @@ struct C1Args {
     int tilesM, tilesP;
 };
 
+// Persistent form: gridDim.x (= 2 workgroups per CU, a multiple of 8) workgroups walk the output tiles v = blockIdx.x,
+// blockIdx.x + gridDim.x, ... and the staging pipeline runs ACROSS tiles: during the last two K steps of a tile the registers
+// already receive the first two K steps of the workgroup's next tile, so the global-memory round trip that used to open every
+// workgroup (load step 0, wait, store, load step 1, barrier: ~2 us of a 25 us lifetime when K = 256) overlaps the MFMAs and
+// the epilogue of the tile before.  A tile's folded-BN vectors live in a double-buffered LDS pair (a fast wavefront may be
+// one tile ahead of a slow one's epilogue).
 template <int TM, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32;
@@ -43,46 +49,41 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
     constexpr int NA = BK / A_RS;                // float4 per thread and step: 4 / 2
     constexpr int NBV = 4;                       // VEC: float4 per thread and step (32 float4 per row, 8 rows a round)
     constexpr int NBS = 16;                      // scalar: floats per thread and step (128 pixels per row, 2 rows a round)
+    constexpr int NB = VEC ? NBV : NBS;
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
-    __shared__ float s_scale[BM], s_shift[BM];
+    __shared__ float s_scale[2][BM], s_shift[2][BM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
-
-    const int nwg = a.tilesM * a.tilesP;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap, m-tile fastest: the workgroups that share one pixel tile sit on one L2
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int m0 = (bid % a.tilesM) * BM;
-    const long long n0 = (long long)(bid / a.tilesM) * BN;
-    if (t < BM) {
-        const int m = m0 + t;
-        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
-        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
-    }
     const size_t HW = (size_t)a.HW;
+    const int nwg = a.tilesM * a.tilesP;
+    const int nk = a.Cin / BK;                   // >= 2 (launch precondition)
 
-    // ---- staging roles ----
+    // tile v -> (m0, n0): XCD-aware bijective remap, m-tile fastest (the workgroups that share one pixel tile sit on one L2;
+    // gridDim.x is a multiple of 8, so v % 8 is the XCD of this workgroup for every tile it walks)
+    auto tile_origin = [&](int v, int& m0, long long& n0) {
+        const int q = nwg / 8, r = nwg % 8, xcd = v % 8, j = v / 8;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        m0 = (bid % a.tilesM) * BM;
+        n0 = (long long)(bid / a.tilesM) * BN;
+    };
+    // staging roles (fixed) and per-tile source pointers
     const int ar = t / A_C4, ac = t % A_C4;                                  // A: rows ar + A_RS*j, float4 column ac
-    const float* wsrc = a.wT + (size_t)ar * a.Mpad + m0 + ac * 4;            // + (k0 + A_RS*j) * Mpad
-    const float* bsrc;                                                        // + (k0 + row) * HW
-    int brow, bcol;                                                           // B: rows brow + 8*j (VEC) / brow + 2*i (scalar)
-    {
-        long long p;
-        if (VEC) { brow = t >> 5; bcol = (t & 31) * 4; p = n0 + bcol; if (p >= a.P) p = a.P - 4; }
-        else     { brow = t >> 7; bcol = t & 127;      p = n0 + bcol; if (p >= a.P) p = a.P - 1; }
+    const int brow = VEC ? t >> 5 : t >> 7, bcol = VEC ? (t & 31) * 4 : t & 127;   // B: rows brow + 8*j (VEC) / brow + 2*i
+    auto tile_sources = [&](int m0, long long n0, const float*& wsrc, const float*& bsrc) {
+        wsrc = a.wT + (size_t)ar * a.Mpad + m0 + ac * 4;                     // + (k0 + A_RS*j) * Mpad
+        long long p = n0 + bcol;
+        if (p >= a.P) p = a.P - (VEC ? 4 : 1);                               // columns past the end: any valid address
         const long long n = p / a.HW;
-        bsrc = a.in + (size_t)n * a.Cin * HW + (size_t)(p - n * a.HW) + (size_t)brow * HW;
-    }
+        bsrc = a.in + (size_t)n * a.Cin * HW + (size_t)(p - n * a.HW) + (size_t)brow * HW;   // + (k0 + row) * HW
+    };
     f32x4 ra[NA];
     f32x4 rv[VEC ? NBV : 1];
     float rb[VEC ? 1 : NBS];
-    auto load_a = [&](int k0, int j) { ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(k0 + A_RS * j) * a.Mpad); };
-    auto load_b = [&](int k0, int j) {
+    auto load_a = [&](const float* wsrc, int k0, int j) { ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(k0 + A_RS * j) * a.Mpad); };
+    auto load_b = [&](const float* bsrc, int k0, int j) {
         if (VEC) rv[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * HW);
         else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * HW];
     };
@@ -91,73 +92,93 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
         if (VEC) *reinterpret_cast<f32x4*>(&Bs[buf][brow + 8 * j][bcol]) = rv[j];
         else     Bs[buf][brow + 2 * j][bcol] = rb[j];
     };
-    constexpr int NB = VEC ? NBV : NBS;
+    auto put_scale = [&](int slot, int m0) {
+        if (t < BM) {
+            const int m = m0 + t;
+            s_scale[slot][t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+            s_shift[slot][t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+        }
+    };
 
-    f32x16 acc[TM][2];
+    int v = blockIdx.x;
+    int m0; long long n0;
+    tile_origin(v, m0, n0);
+    const float *wsrc, *bsrc;
+    tile_sources(m0, n0, wsrc, bsrc);
+    put_scale(0, m0);
+    // prologue of the first tile only: K step 0 -> LDS buffer 0, K step 1 -> registers
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < NA; ++j) load_a(wsrc, 0, j);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nk = a.Cin / BK;
-    // prologue: tile 0 -> LDS buffer 0, tile 1 -> registers
-#pragma unroll
-    for (int j = 0; j < NA; ++j) load_a(0, j);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) load_b(0, j);
+    for (int j = 0; j < NB; ++j) load_b(bsrc, 0, j);
 #pragma unroll
     for (int j = 0; j < NA; ++j) store_a(0, j);
 #pragma unroll
     for (int j = 0; j < NB; ++j) store_b(0, j);
-    {
-        const int k1 = nk > 1 ? BK : 0;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) load_a(k1, j);
+    for (int j = 0; j < NA; ++j) load_a(wsrc, BK, j);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) load_b(k1, j);
-    }
+    for (int j = 0; j < NB; ++j) load_b(bsrc, BK, j);
     __syncthreads();
 
     // per-lane operand addresses inside a buffer: row 2*kk + lrow, column (32-wide sub-tile) + lcol
     const float* arow = &As[0][lrow][wm * TM * 32 + lcol];
     const float* brow_p = &Bs[0][lrow][wn * 64 + lcol];
-    for (int s = 0; s < nk; ++s) {
-        const int cur = s & 1;
-        const float* ap = arow + cur * (BK * BM);
-        const float* bp = brow_p + cur * (BK * BN);
-        const int k2 = (s + 2 < nk ? s + 2 : nk - 1) * BK;   // the tail re-loads the last tile: harmless
-        // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
-        float af[2][4][TM], bf[2][4][2];
-        auto read_chunk = [&](int c, int slot) {
+    int g = 0;                                    // global step counter of this workgroup: LDS buffer = g & 1
+    for (int it = 0; v < nwg; ++it, v += gridDim.x) {
+        // the workgroup's next tile (none: this tile again -- its loads are harmless and nobody consumes them)
+        const int vn = v + (int)gridDim.x < nwg ? v + (int)gridDim.x : v;
+        int m0n; long long n0n;
+        tile_origin(vn, m0n, n0n);
+        const float *wsrc_n, *bsrc_n;
+        tile_sources(m0n, n0n, wsrc_n, bsrc_n);
+
+        f32x16 acc[TM][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kk = c * 4 + e;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[slot][e][i] = ap[2 * kk * BM + i * 32];
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[slot][e][j] = bp[2 * kk * BN + j * 32];
-            }
-        };
-        read_chunk(0, 0);
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        for (int s = 0; s < nk; ++s, ++g) {
+            const int cur = g & 1;
+            const float* ap = arow + cur * (BK * BM);
+            const float* bp = brow_p + cur * (BK * BN);
+            // the registers hold K step s+1 (stored below into the other buffer) and are re-loaded with step s+2 -- of this
+            // tile, or steps 0 / 1 of the next one
+            const bool nxt = s + 2 >= nk;
+            const float* wl = nxt ? wsrc_n : wsrc;
+            const float* bl = nxt ? bsrc_n : bsrc;
+            const int k2 = (nxt ? s + 2 - nk : s + 2) * BK;
+            // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
+            float af[2][4][TM], bf[2][4][2];
+            auto read_chunk = [&](int c, int slot) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c + 1 < 4) read_chunk(c + 1, (c + 1) & 1);
-            // tile s+1: registers -> the other LDS buffer (chunks 0, 1); tile s+2: global -> registers (chunks 2, 3)
-            constexpr bool ST = RFX_C1_DBG != 1 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
-            constexpr bool LD = RFX_C1_DBG != 2 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
-            // a register is re-loaded (tile s+2) right after it was stored (tile s+1), in chunks 0 / 1: the loads get the rest
-            // of the step to land (with the loads in chunks 2 / 3 the next step's first store waits for them: -5 % in
-            // scripts/ubench/mfma_mix.hip, variants g and g/1)
-            {
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = c * 4 + e;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[slot][e][i] = ap[2 * kk * BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[slot][e][j] = bp[2 * kk * BN + j * 32];
+                }
+            };
+            read_chunk(0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c + 1 < 4) read_chunk(c + 1, (c + 1) & 1);
+                constexpr bool ST = RFX_C1_DBG != 1 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
+                constexpr bool LD = RFX_C1_DBG != 2 && RFX_C1_DBG != 3 && RFX_C1_DBG != 4;
+                // a register is re-loaded right after it was stored, in chunks 0 / 1: the loads get the rest of the step to
+                // land (with the loads in chunks 2 / 3 the next step's first store waits for them: -5 % in
+                // scripts/ubench/mfma_mix.hip, variants g and g/1)
                 if (c == 0) {
 #pragma unroll
                     for (int j = 0; j < NA; ++j) {
                         if (ST) store_a(cur ^ 1, j); else if (LD) asm volatile("" ::"v"(ra[j]));
                     }
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) if (LD) load_a(k2, j);
+                    for (int j = 0; j < NA; ++j) if (LD) load_a(wl, k2, j);
                 } else if (c == 1) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
@@ -165,46 +186,47 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
                         else if (LD) { if (VEC) asm volatile("" ::"v"(rv[VEC ? j : 0])); else asm volatile("" ::"v"(rb[VEC ? 0 : j])); }
                     }
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) if (LD) load_b(k2, j);
+                    for (int j = 0; j < NB; ++j) if (LD) load_b(bl, k2, j);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (RFX_C1_DBG != 4) __syncthreads();   // step s+1 is complete in the other buffer; everyone is done reading this one
         }
-        if (RFX_C1_DBG != 4) __syncthreads();   // tile s+1 is complete in the other buffer; everyone is done reading this one
+        put_scale((it + 1) & 1, m0n);             // the next tile's BN vectors (read after >= nk barriers)
+        if (RFX_C1_DBG == 6) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (sacc == 123.456f) a.out[t] = sacc;
+        } else {
+            // ---- epilogue (conv_epilogue.h); the loads of the next tile's K step 1 are in flight meanwhile ----
+            size_t pix_off[2];
+            bool pix_ok[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                long long pp = n0 + wn * 64 + j * 32 + lcol;
+                pix_ok[j] = pp < a.P;
+                if (!pix_ok[j]) pp = a.P - 1;
+                const long long n = pp / a.HW;
+                pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pp - n * a.HW);
+            }
+            conv_epilogue<TM, 2, false>(acc, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off,
+                                        pix_ok, m0 + BM <= a.Cout);
+        }
+        m0 = m0n; n0 = n0n; wsrc = wsrc_n; bsrc = bsrc_n;
     }
-    if (RFX_C1_DBG == 6) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 123.456f) a.out[t] = sacc;
-        return;
-    }
-
-    // ---- epilogue (conv_epilogue.h) ----
-    size_t pix_off[2];
-    bool pix_ok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        long long pp = n0 + wn * 64 + j * 32 + lcol;
-        pix_ok[j] = pp < a.P;
-        if (!pix_ok[j]) pp = a.P - 1;
-        const long long n = pp / a.HW;
-        pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pp - n * a.HW);
-    }
-    conv_epilogue<TM, 2, false>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok,
-                                m0 + BM <= a.Cout);
 }
 
 template <int TM, bool VEC>
@@ -213,7 +235,15 @@ int launch_1x1(C1Args& a, hipStream_t st) {
     a.tilesP = (int)((a.P + 127) / 128);
     const long long nwg = (long long)a.tilesM * a.tilesP;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    // persistent grid: 2 workgroups per CU (what the kernel's registers and LDS allow), a multiple of 8 (XCDs)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = (2 * cus + 7) / 8 * 8;
+    }
+    const unsigned grid = (unsigned)(nwg < slots ? (nwg + 7) / 8 * 8 : slots);
+    hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3(grid), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -221,7 +251,7 @@ int launch_1x1(C1Args& a, hipStream_t st) {
 }  // namespace
 
 // Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 1x1, stride 1, pad 0,
-// Cin % 32 == 0, N*HW >= 4; tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; vec: HW % 4 == 0 and `in` 16-byte
+// Cin % 32 == 0, Cin >= 64, N*HW >= 4; tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; vec: HW % 4 == 0 and `in` 16-byte
 // aligned (16-byte pixel loads).
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
