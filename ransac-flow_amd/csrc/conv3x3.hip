@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 
 // Patch shape for a batch of N H x W maps stacked as above: the fewest padded pixels (ties: the widest, whose row segments
 // coalesce best).  The fused Bottleneck tail writes Cexp channels per pixel from a narrow patch in short row segments:
-// measured on equal work its 16x8 patch is ~5 % and its 32x4 patch ~40 % slower than 8x16, while the plain 3x3 kernel is
+// measured on equal work its 16x8 patch is ~9 % and its 32x4 patch ~40 % slower than 8x16, while the plain 3x3 kernel is
 // indifferent (scripts/ubench/conv_bench.py on the 25x33 ... 112x148 maps of the pyramid) -- hence the weights.
 int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     int best = 16;
@@ -359,7 +359,7 @@ int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     for (int pc = 16; pc >= 4; pc >>= 1) {
         const int pr = 128 / pc;
         const long long area = (((long long)N * (H + 1) + pr - 1) / pr) * ((W + pc - 1) / pc);
-        const long long cost = area * (!fused || pc == 16 ? 100 : (pc == 8 ? 105 : 140));
+        const long long cost = area * (!fused || pc == 16 ? 100 : (pc == 8 ? 109 : 140));
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pc; }
     }
     return best;

@@ -392,3 +392,35 @@ def test_conv_dispatch_table_is_stable():
     # tiny problems fall back to the 64x64 tile
     assert kid(1, 128, 49, 1, 1, 0, 12, 16) & 3 == 2
     assert lib.rfx_conv2d_tile_variant(64, 256, 120, 160) == 0 and lib.rfx_conv2d_tile_variant(1, 64, 12, 16) == 2
+
+
+def test_fused_tail_patch_choice_and_packed_weight_layout():
+    """Host logic added with the packed direct-3x3 kernel (no GPU needed): the fused Bottleneck tail avoids narrow patches
+    (rfx_conv3x3_conv1x1_kernel_id), the plain kernel takes the shape with the least padded area over the STACKED batch, and
+    ConvPlan packs wP exactly as include/rfx_api.h documents: wP[mt][s][h][m][kk] = w[mt*128 + m, k = s*72 + 2*kk + h]."""
+    lib = _lib.load()
+    fid = lib.rfx_conv3x3_conv1x1_kernel_id
+    assert fid(64, 120, 160, 64) == 512 | 1                     # 8x16 patch, 64-channel mid tile
+    assert fid(64, 60, 80, 128) == 512                           # 128-channel mid tile
+    assert fid(64, 100, 132, 64) == 512 | 1                      # W = 132: 8x16 (144) beats 16x8 (136 * 1.09) and 32x4 (132 * 1.4)
+    assert fid(64, 112, 148, 64) == 512 | 1                      # W = 148: 8x16 (160) beats 16x8 (152 * 1.09)
+    assert fid(64, 50, 66, 128) == 512 | 64                      # W = 66: 16x8 (72 * 1.09) beats 8x16 (80)
+    kid = lambda N, Cin, Cout, H, W: lib.rfx_conv2d_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W)
+    assert kid(64, 256, 256, 26, 35) & 192 == 128                # plain kernel: least area wins (32x4 -> 36 columns)
+    assert kid(64, 256, 256, 28, 37) & 192 == 64                 # 40 columns either way: the wider 16x8
+    assert kid(1, 256, 256, 25, 33) & 192 == 128                 # one image: 26 stacked rows -> one 32x4 patch row
+    from rfx import ops
+    import torch as _t
+    g = _t.Generator().manual_seed(1)
+    w = _t.randn(200, 16, 3, 3, generator=g)
+    plan = ops.ConvPlan(w, None, 1, 1, ops.ACT_NONE, device="cpu")
+    assert plan.wP.shape == (2, 2, 2, 128, 36)
+    w2 = w.reshape(200, 144)
+    for (mt, s_, h, m, kk) in ((0, 0, 0, 0, 0), (0, 1, 1, 5, 35), (1, 0, 1, 71, 7), (1, 1, 0, 3, 20)):
+        assert plan.wP[mt, s_, h, m, kk] == w2[mt * 128 + m, s_ * 72 + 2 * kk + h]
+    assert float(plan.wP[1, :, :, 72:, :].abs().max()) == 0.0   # channels past Cout are zero rows
+    # area threshold of the small-component filter: the largest a with a / size <= cc_th in float64
+    for size, th in ((1200, 0.01), (466992, 0.01), (997, 0.05), (12, 1.0), (7, 0.0001), (1000, 0.3)):
+        a = ops.cc_max_area(size, th)
+        assert a / float(size) <= th and (a + 1) / float(size) > th
+
