@@ -207,6 +207,13 @@ int rfx_grid_sample_f32(const float* in, const float* grid, float* out, int N, i
 int rfx_compose_flow_f32(const float* flowDown, const float* coarseGrid, float* flow12, float* inb,
                          float* flowUp, int N, int hd, int wd, int Hc, int Wc, int H, int W, int clamp, void* stream);
 
+/* The tail of model.predFlowCoarse / predFlowCoarseNoGrad (model/model.py:333-340, 344-350): flowCoarse (B,2,H,W) is the
+ * NetFlowCoarse output; flow (B,H,W,2) = clamp(flowCoarse.permute(0,2,3,1) + grid, -1, 1) with grid (grid_batch,H,W,2),
+ * grid_batch = 1 (broadcast) or B; flowGrad (B,1,H-1,W-1) = L2 norm over the two channels of
+ * flowCoarse[:, :, 1:, 1:] - flowCoarse[:, :, :-1, :-1], or NULL (the NoGrad variant). */
+int rfx_flow_grad_clamp_f32(const float* flowCoarse, const float* grid, float* flowGrad, float* flow, int B, int H, int W,
+                            int grid_batch, void* stream);
+
 /* Multi-homography merge of the offline flow assembly (evaluation/evalHpatch/getResults.py:48-61,
  * evaluation/evalCorr/getResults.py:121-134, evaluation/evalKITTI/getResults.py:126-138).
  * flow (n,HW,2) composed flows; match12 = up-sampled matchability of homography i at match12 + i*match12_stride;

@@ -204,6 +204,28 @@ __global__ __launch_bounds__(256) void match_score_kernel(const float* __restric
 
 }  // namespace
 
+// predFlowCoarse's tail (model/model.py:333-340): flowGrad = || f[:, :, 1:, 1:] - f[:, :, :-1, :-1] ||_2 over the two flow
+// channels, (B,1,H-1,W-1); flow = clamp(f.permute(0,2,3,1) + grid, -1, 1), (B,H,W,2).  One thread per pixel does both.
+__global__ __launch_bounds__(256) void flow_grad_clamp_kernel(const float* __restrict__ f, const float* __restrict__ grid,
+                                                             float* __restrict__ flowGrad, float* __restrict__ flow, int B,
+                                                             int H, int W, int grid_batch) {
+    const long long HW = (long long)H * W, total = (long long)B * HW;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const long long b = q / HW, p = q - b * HW;
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        const float fx = f[(b * 2) * HW + p], fy = f[(b * 2 + 1) * HW + p];
+        const float2 g = reinterpret_cast<const float2*>(grid)[(grid_batch > 1 ? b : 0) * HW + p];
+        float2 o;
+        o.x = fminf(fmaxf(fx + g.x, -1.0f), 1.0f);
+        o.y = fminf(fmaxf(fy + g.y, -1.0f), 1.0f);
+        reinterpret_cast<float2*>(flow)[q] = o;
+        if (flowGrad && y + 1 < H && x + 1 < W) {
+            const float dx = f[(b * 2) * HW + p + W + 1] - fx, dy = f[(b * 2 + 1) * HW + p + W + 1] - fy;
+            flowGrad[b * (long long)(H - 1) * (W - 1) + (long long)y * (W - 1) + x] = sqrtf(dx * dx + dy * dy);
+        }
+    }
+}
+
 extern "C" int rfx_warp_grid_f32(const float* Hm, float* grid, int B, int h, int w, void* stream) {
     if (!Hm || !grid || B <= 0 || h <= 0 || w <= 0) return RFX_E_ARG;
     const long long total = (long long)B * h * w;
@@ -251,6 +273,18 @@ extern "C" int rfx_match_score_f32(const float* match12, long long match12_strid
     const long long total = (long long)n * HW;
     hipLaunchKernelGGL(match_score_kernel, dim3(grid_for(total, 256)), dim3(256), 0, rfx_stream(stream), match12,
                        match12_stride, cyc, inb, HW, total, score);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_flow_grad_clamp_f32(const float* flowCoarse, const float* grid, float* flowGrad, float* flow, int B, int H,
+                                       int W, int grid_batch, void* stream) {
+    if (!flowCoarse || !grid || !flow || B <= 0 || H <= 0 || W <= 0 || (grid_batch != 1 && grid_batch != B)) return RFX_E_ARG;
+    if (flowGrad && (H < 2 || W < 2)) return RFX_E_ARG;
+    const long long total = (long long)B * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(flow_grad_clamp_kernel, dim3(blocks), dim3(256), 0, rfx_stream(stream), flowCoarse, grid, flowGrad, flow, B,
+                       H, W, grid_batch);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

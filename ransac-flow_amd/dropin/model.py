@@ -193,16 +193,13 @@ def SSIM(*a, **k):
 def predFlowCoarse(corrKernel21, NetFlowCoarse, grid, up8X=True):
     """model/model.py:331-340 -> (flowGrad (B,1,H-1,W-1), clamp(flow.permute(0,2,3,1) + grid, -1, 1))."""
     flowCoarse = NetFlowCoarse(corrKernel21, up8X)
-    b, _, w, h = flowCoarse.size()
-    d = flowCoarse[:, :, 1:, 1:] - flowCoarse[:, :, :-1, :-1]
-    flowGrad = torch.norm(d, dim=1, keepdim=True)
-    return flowGrad, torch.clamp(flowCoarse.permute(0, 2, 3, 1) + grid, min=-1, max=1)
+    return ops.flow_grad_clamp(flowCoarse.contiguous(), grid.contiguous(), want_grad=True)      # rfx_flow_grad_clamp_f32
 
 
 def predFlowCoarseNoGrad(corrKernel21, NetFlowCoarse, grid, up8X=True):
     """model/model.py:342-350."""
     flowCoarse = NetFlowCoarse(corrKernel21, up8X)
-    return torch.clamp(flowCoarse.permute(0, 2, 3, 1) + grid, min=-1, max=1)
+    return ops.flow_grad_clamp(flowCoarse.contiguous(), grid.contiguous(), want_grad=False)[1]
 
 
 def predMatchability(corrKernel21, NetMatchability, up8X=True):

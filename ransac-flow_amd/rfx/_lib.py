@@ -36,6 +36,7 @@ SIGNATURES = {
     "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "rfx_grid_sample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "rfx_compose_flow_f32": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "rfx_flow_grad_clamp_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "rfx_merge_multi_h_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_float, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "rfx_match_score_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p]),

@@ -429,6 +429,19 @@ def compose_flow(flowDown, coarseGrid, clamp=False, want_inb=False, want_flow_up
     return flow12, inb, fup
 
 
+def flow_grad_clamp(flowCoarse, grid, want_grad=True):
+    """model.predFlowCoarse's tail (model/model.py:333-340): -> (flowGrad (B,1,H-1,W-1) or None, clamp(flow^T + grid, -1, 1))."""
+    f = _dev(flowCoarse, "flowCoarse")
+    g = _dev(grid, "grid")
+    B, C, H, W = f.shape
+    if C != 2 or g.dim() != 4 or tuple(g.shape[1:]) != (H, W, 2) or g.shape[0] not in (1, B):
+        raise ValueError("flowCoarse (B,2,H,W) / grid (1|B,H,W,2) expected, got %s / %s" % (tuple(f.shape), tuple(g.shape)))
+    flow = torch.empty((B, H, W, 2), dtype=torch.float32, device=f.device)
+    fg = torch.empty((B, 1, H - 1, W - 1), dtype=torch.float32, device=f.device) if want_grad else None
+    _call("rfx_flow_grad_clamp_f32", _one_device(f, g), _p(f), _p(g), _p(fg), _p(flow), B, H, W, int(g.shape[0]))
+    return fg, flow
+
+
 def _match_plane(match12, n, H, W):
     if not isinstance(match12, torch.Tensor) or not match12.is_cuda or match12.dtype != torch.float32:
         raise RuntimeError("match12 must be a float32 tensor on a HIP device (no CPU fallback)")

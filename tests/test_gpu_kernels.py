@@ -27,6 +27,22 @@ def relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def test_flow_grad_clamp_matches_torch(dev):
+    """rfx_flow_grad_clamp_f32 == model.predFlowCoarse's tail in ATen (model/model.py:333-340): clamp(flow^T + grid) bit for bit,
+    flowGrad within one rounding of torch.norm; broadcast and per-sample grids, the NoGrad variant, odd sizes."""
+    g = torch.Generator().manual_seed(2)
+    for (B, H, W, gb) in ((1, 37, 53, 1), (3, 16, 24, 3), (2, 2, 2, 1), (4, 60, 80, 1)):
+        f = torch.randn(B, 2, H, W, generator=g) * 0.7
+        grid = torch.rand(gb, H, W, 2, generator=g) * 2.4 - 1.2
+        fg, flow = ops.flow_grad_clamp(f.to(dev), grid.to(dev))
+        ref_flow = torch.clamp(f.permute(0, 2, 3, 1) + grid, min=-1, max=1)
+        ref_fg = torch.norm(f[:, :, 1:, 1:] - f[:, :, :-1, :-1], dim=1, keepdim=True)
+        assert torch.equal(flow.cpu(), ref_flow)
+        assert fg.shape == ref_fg.shape and (fg.cpu() - ref_fg).abs().max() <= 2.4e-7 * float(ref_fg.abs().max())
+        fg2, flow2 = ops.flow_grad_clamp(f.to(dev), grid.to(dev), want_grad=False)
+        assert fg2 is None and torch.equal(flow2, flow)
+
+
 # ------------------------------------------------------------------ small-component filter
 def test_remove_small_cc_equals_host_labelling(dev):
     """rfx_remove_small_cc_f32 (lock-free union-find on the device) == the reference's host filter
