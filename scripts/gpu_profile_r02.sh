@@ -12,7 +12,7 @@ for c in ${CONFIGS:-qs 2 3 4 5}; do
   grep "^{" $R/gpurun_out/prof_$c.log | head -c 600; echo
 done
 if [ "$PMC" = "1" ]; then
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-config3-leg"
+ARGS="--config ${PMC_CONFIG:-qs} --steps 1 --warmup 1 --no-cpu-baseline --no-config3-leg"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/pmc_sq -o p -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o p -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o p -- python $R/bench.py $ARGS > $R/gpurun_out/pmc_write.log 2>&1
@@ -37,7 +37,7 @@ for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
             for k in tot:
                 out[k]["pmc_run_total_ns"] = tot[k]; out[k]["pmc_run_launches"] = n[k]
         os.remove(f)
-json.dump(out, open("gpurun_out/pmc_summary.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/pmc_summary%s.json" % ("" if os.environ.get("PMC_CONFIG", "qs") == "qs" else "_config" + os.environ["PMC_CONFIG"]), "w"), indent=1)
 print("pmc kernels:", len(out))
 PY
 fi

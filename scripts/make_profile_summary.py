@@ -42,35 +42,36 @@ for c in ("qs", "2", "3", "4", "5"):
             name, rest = line.rsplit(",", 7)[0], line.rsplit(",", 7)[1:]
             f.write(name.replace(",", " ") + "," + ",".join(rest[:6]) + "\n")
 
-pm = os.path.join(src, "pmc_summary.json")
-if os.path.exists(pm):
-    raw = json.load(open(pm))
-    kern = {}
-    for name, e in raw.items():
-        n = e.get("pmc_run_launches")
-        if not n:
-            continue
-        o = {"launches_in_pmc_run": n, "avg_ns_in_pmc_run": e["pmc_run_total_ns"] / n}
-        if "FETCH_SIZE" in e:
-            o["FETCH_SIZE_bytes_per_launch_raw"] = e["FETCH_SIZE"] * 1024.0 / e["launches_FETCH_SIZE"]
-        if "WRITE_SIZE" in e:
-            o["WRITE_SIZE_bytes_per_launch_raw"] = e["WRITE_SIZE"] * 1024.0 / e["launches_WRITE_SIZE"]
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
-            # summed over the 256 CUs x 4 SIMDs; normalised by the kernel's wall time at the nominal 2.4 GHz
-            o["mfma_busy_frac_at_2.4GHz"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["pmc_run_total_ns"] * 2.4 * 1024)
-        for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT"):
-            if c in e:
-                o[c] = e[c]
-        kern[name] = o
-    note = ("rocprofv3 --pmc passes (separate runs, kernel-trace only) over `python bench.py --steps 1 --warmup 1 --no-cpu-baseline "
-            "--no-config3-leg` on MI355X, round %s. FETCH_SIZE/WRITE_SIZE in bytes (counter x 1024) per launch, RAW: on gfx950 FETCH_SIZE "
-            "under-counts wide (16 B/lane) coalesced reads by exactly 2x (MI355X_MICROARCH.md) -- double it for the LDS-DMA correlation "
-            "kernel and the 16-byte conv loads; dword (4 B/lane) reads are uncalibrated." % RND[1:])
-    json.dump({"note": note, "kernels": kern}, open(os.path.join(dst, RND + "_pmc_summary_qs.json"), "w"), indent=1)
-    for k, o in sorted(kern.items(), key=lambda kv: -kv[1]["avg_ns_in_pmc_run"] * kv[1]["launches_in_pmc_run"])[:8]:
-        print("%-70s launches %4d avg %8.1f us  mfma %.2f  fetch %.1f MB write %.1f MB" % (
-            k[:70], o["launches_in_pmc_run"], o["avg_ns_in_pmc_run"] / 1e3, o.get("mfma_busy_frac_at_2.4GHz", 0),
-            o.get("FETCH_SIZE_bytes_per_launch_raw", 0) / 1e6, o.get("WRITE_SIZE_bytes_per_launch_raw", 0) / 1e6))
+for pm_name, pm_cfg in (("pmc_summary.json", "qs"), ("pmc_summary_config5.json", "config5")):
+  pm = os.path.join(src, pm_name)
+  if os.path.exists(pm):
+      raw = json.load(open(pm))
+      kern = {}
+      for name, e in raw.items():
+          n = e.get("pmc_run_launches")
+          if not n:
+              continue
+          o = {"launches_in_pmc_run": n, "avg_ns_in_pmc_run": e["pmc_run_total_ns"] / n}
+          if "FETCH_SIZE" in e:
+              o["FETCH_SIZE_bytes_per_launch_raw"] = e["FETCH_SIZE"] * 1024.0 / e["launches_FETCH_SIZE"]
+          if "WRITE_SIZE" in e:
+              o["WRITE_SIZE_bytes_per_launch_raw"] = e["WRITE_SIZE"] * 1024.0 / e["launches_WRITE_SIZE"]
+          if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+              # summed over the 256 CUs x 4 SIMDs; normalised by the kernel's wall time at the nominal 2.4 GHz
+              o["mfma_busy_frac_at_2.4GHz"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["pmc_run_total_ns"] * 2.4 * 1024)
+          for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT"):
+              if c in e:
+                  o[c] = e[c]
+          kern[name] = o
+      note = ("rocprofv3 --pmc passes (separate runs, kernel-trace only) over `python bench.py --steps 1 --warmup 1 --no-cpu-baseline "
+              "--no-config3-leg` (config " + pm_cfg + ") on MI355X, round %s. FETCH_SIZE/WRITE_SIZE in bytes (counter x 1024) per launch, RAW: on gfx950 FETCH_SIZE "
+              "under-counts wide (16 B/lane) coalesced reads by exactly 2x (MI355X_MICROARCH.md) -- double it for the LDS-DMA correlation "
+              "kernel and the 16-byte conv loads; dword (4 B/lane) reads are uncalibrated." % RND[1:])
+      json.dump({"note": note, "kernels": kern}, open(os.path.join(dst, RND + "_pmc_summary_" + pm_cfg + ".json"), "w"), indent=1)
+      for k, o in sorted(kern.items(), key=lambda kv: -kv[1]["avg_ns_in_pmc_run"] * kv[1]["launches_in_pmc_run"])[:8]:
+          print("%-70s launches %4d avg %8.1f us  mfma %.2f  fetch %.1f MB write %.1f MB" % (
+              k[:70], o["launches_in_pmc_run"], o["avg_ns_in_pmc_run"] / 1e3, o.get("mfma_busy_frac_at_2.4GHz", 0),
+              o.get("FETCH_SIZE_bytes_per_launch_raw", 0) / 1e6, o.get("WRITE_SIZE_bytes_per_launch_raw", 0) / 1e6))
 
 for cfg, n in (("ev", 64), ("qs", 64)):
     p = os.path.join(src, "parity_sweep_%s_%d.json" % (cfg, n))
