@@ -5,30 +5,38 @@ A "step" = one pass of the whole hot path over one batch of synthetic pairs alre
 the bit-exact LANCZOS pyramid + ToTensor/Normalize run on the device inside the step).  float32 end to end.
 
 Workloads (``--config``; BASELINE.json ``configs``):
-  qs (default)  batch of 64 480x640 pairs, quick_start semantics (quick_start/align2images.py:53-97): ResNet-50 conv4
+  3 (default)   BASELINE config 3 AS WORDED -- the headline: batch of 64 480x640 pairs, each target warped by a seeded random
+                homography, evaluation semantics (variant B: minSize 480, 7 scales x2, nA = 13 065, coarseIter 10 000),
+                multi-homography loop (maxCoarse 10, maskRegionTh 0.01) with a PredFlowMask per homography
+                (evaluation/evalHpatch/evaluation.py:193-243); RANSAC index draw on the device (utils/outil.py:120 on a GPU run).
+  qs            batch of 64 480x640 pairs, quick_start semantics (quick_start/align2images.py:53-97): ResNet-50 conv4
                 features of the 7-level x1.2 pyramid + target -> mutual NN -> RANSAC (nbIter 1000) -> warp ->
-                FeatureExtractor x2 -> 7x7 correlation -> NetFlowCoarse -> flow composition -> final warp.  The headline.
+                FeatureExtractor x2 -> 7x7 correlation -> NetFlowCoarse -> flow composition -> final warp (one homography
+                per pair; rounds 1-2's headline, now ``extra.quick_start`` of the default run).
   2             ONE 480x640 pair, coarse RANSAC only (nbIter 1000, no fine net): value = 1 / latency.
-  3             config 3 AS WORDED: batch of 64 480x640 pairs, each target warped by a seeded random homography, evaluation
-                semantics (variant B: minSize 480, 7 scales x2, nA = 13 065, coarseIter 10 000), multi-homography loop
-                (maxCoarse 10, maskRegionTh 0.01) with a PredFlowMask per homography (evaluation/evalHpatch/evaluation.py:193-243).
   4             evalHpatch-shaped stream: 960x720 pairs, minSize 720, 5 scales x2, coarseIter 50 000, multi-H on.
   5             evalKITTI-shaped stream: 1242x376 pairs, coarseSize 800, 3 scales x1.2, coarseIter 50 000, fineSize 650,
                 two-resolution fine pass, cycle-checked matchability, cc-filter on the device (evaluation/evalKITTI/evaluation.py).
-The default run also times a short config-3 leg (``extra.config3_multi_h``) and, on rank 0 at N = 1, the CPU legs below.
+The default run also times a quick_start leg (``extra.quick_start``: 10 steps, own rooflines and parity block) and, on rank
+0 at N = 1, the CPU legs below.
 
 N > 1: ``python bench.py --gpus N`` re-launches itself under ``torch.distributed.run`` (one rank per GPU, RCCL); when the
 driver launches it that way itself, RANK / LOCAL_RANK / WORLD_SIZE come from the environment.  Every rank aligns its own
 shard of the pair stream (pair i -> rank i mod N: weak scaling, no data-path collective) and the per-pair result records
-are collected with ONE all_gather per step.
+-- nbH | status | rank | H[11] | flowDown8[11] | matchDown8[11], 0.85 MB per 480x640 pair, what
+evaluation/evalHpatch/evaluation.py:254-260 saves -- are collected with ONE all_gather per step.
 
 Prints one JSON line on rank 0 (the driver's contract): value = pairs/s over all ranks, plus
   roofline      -- the conv-class kernel instance with the most GPU time (fp32 MFMA bound): algorithmic FLOP per launch /
                    average launch duration, HIP events on the launch stream inside the timed region (ops.Profiler);
   roofline_corr -- the same for the HBM-bound 7x7 correlation kernel, SURVEY 8d algorithmic bytes;
-  cpu_baseline  -- the CPU oracle (oracle/restate.py, a port of the reference path) on this host's cores: bounded sample;
-  parity        -- oracle/parity_sweep.py over ALL pairs of the timed batch: the oracle end to end on its own homography
-                   (both run in child processes; the oracle is the checker, never the thing timed).
+  cpu_baseline  -- the CPU oracle (oracle/restate.py, a port of the reference path; profiles/r03_cpu_reference_vs_port.json
+                   holds the reference/port ratio measured where the reference exists) on this host's cores: bounded sample
+                   of the SAME workload as ``value``;
+  parity        -- oracle/parity_sweep.py over pairs of the timed batch, bounded by a wall-clock budget (pairs not reached
+                   are reported): config 3 = every round of the multi-homography loop replayed on the oracle from the
+                   device's state + the oracle's own loop end to end ("ev_loop"); extra.quick_start.parity = the oracle end to
+                   end on its own homography ("qs").  Child processes: the oracle is the checker, never the thing timed.
 """
 import argparse
 import json
@@ -72,8 +80,8 @@ def cpu_threads():
 
 def cpu_baseline_subprocess(args):
     """The CPU leg in a child process with a hard wall-clock limit so that it can never stall the bench."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--height", str(args.height), "--width",
-           str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs", str(args.cpu_pairs)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config, "--height", str(args.height),
+           "--width", str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs", str(args.cpu_pairs)]
     fail = {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "port"}
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
@@ -87,30 +95,48 @@ def cpu_baseline_subprocess(args):
 
 def cpu_baseline(args):
     """Bounded CPU sample: the oracle restatement (kind = "port": /root/reference does not exist on the GPU box) on
-    `cpu_pairs` pairs of the quick_start workload."""
+    `cpu_pairs` pairs of the workload ``--config`` names (3: the multi-homography loop of evaluation semantics; qs: the
+    quick_start path)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
     import restate
     from rfx import synth, weights
-    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2))
     torch.set_num_threads(cpu_threads())
     H, W = args.height, args.width
-    ca = restate.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
-    nets = dict(feat=sds["feat"], flow=sds["flow"])
+    if args.config == "3":
+        sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+                   match=weights.net_matchability_sd(3, last_std=MULTIH_MATCH_STD))
+        ca = restate.CoarseAlignOracle(sds["trunk"], 7, 10000, 0.05, min(H, W), 2.0, variant="B")
+        nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
+        nh = []
 
-    def one(seed):
-        I1, I2 = synth.make_pair(H, W, seed=seed)
-        ca.setSource(I1)
-        ca.setTarget(I2)
-        r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
-        with torch.no_grad():
-            fc = restate.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
-            restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
+        def one(seed):
+            I1, I2 = synth.make_pair(H, W, seed=seed, homography=True)
+            ca.setPair(I1, I2)
+            nh.append(len(restate.multi_h_loop(ca, nets, max_coarse=10, mask_region_th=0.01)["H"]))
+        what = "BASELINE config 3 as worded (variant B, 7 scales x2, coarseIter 10 000, multi-homography loop, PredFlowMask per homography)"
+    else:
+        sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2))
+        ca = restate.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
+        nets = dict(feat=sds["feat"], flow=sds["flow"])
+        nh = None
+
+        def one(seed):
+            I1, I2 = synth.make_pair(H, W, seed=seed)
+            ca.setSource(I1)
+            ca.setTarget(I2)
+            r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
+            with torch.no_grad():
+                fc = restate.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
+                restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
+        what = "full coarse+fine quick_start path"
 
     t0 = time.perf_counter()
     one(1000)  # warm-up
     warm = time.perf_counter() - t0
+    if nh:
+        nh.clear()
     t0 = time.perf_counter()
     n = 0
     while n < args.cpu_pairs:
@@ -120,14 +146,17 @@ def cpu_baseline(args):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d synthetic %dx%d pairs, full coarse+fine quick_start path (oracle/restate.py: a CPU port of the "
-                      "reference path, not the reference itself), %.1f s" % (n, H, W, dt)}
+            "sample": "%d synthetic %dx%d pairs, %s (oracle/restate.py: a CPU port of the reference path, not the reference "
+                      "itself; reference/port time ratio measured in the authoring container: profiles/r03_cpu_reference_vs_port.json)"
+                      "%s, %.1f s" % (n, H, W, what, (", %.1f homographies per pair" % (sum(nh) / len(nh))) if nh else "", dt)}
 
 
 def parity_subprocess(cfg, dump_dir, seeds, H, W, budget):
     """oracle/parity_sweep.py over the dumped GPU results (child process; bounded)."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "parity_sweep.py"), "--config", cfg, "--dump", dump_dir, "--height",
            str(H), "--width", str(W), "--budget", str(budget), "--seeds"] + [str(s) for s in seeds]
+    if os.environ.get("RFX_PARITY_RECORDS"):        # per-pair records for profiles/ (evidence scripts)
+        cmd += ["--records", os.environ["RFX_PARITY_RECORDS"] + "_" + cfg + ".json"]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget + 120)
         for ln in reversed(out.stdout.splitlines()):
@@ -146,7 +175,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="qs", choices=["qs", "2", "3", "4", "5"])
+    ap.add_argument("--config", default="3", choices=["qs", "2", "3", "4", "5"])
     ap.add_argument("--batch", type=int, default=None, help="pairs per step per GPU (default: 64 for qs / 3, 1 for 2, 16 for 4, 8 for 5)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -154,11 +183,15 @@ def parse_args():
     ap.add_argument("--nb-iter", type=int, default=1000)
     ap.add_argument("--multi-h", action="store_true", help="alias of --config 3")
     ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--host-draw", action="store_true", help="RANSAC index draw with torch.randint on the CPU generator (what a "
+                    "CPU run of the reference draws) instead of on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline + parity sweep)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=None, help="pairs of the batch covered by the parity sweep (default: all)")
-    ap.add_argument("--parity-budget", type=float, default=200.0, help="wall-clock bound of the parity sweep, seconds")
-    ap.add_argument("--no-config3-leg", action="store_true", help="default run: skip the short config-3 (multi-H) leg")
+    ap.add_argument("--parity-budget", type=float, default=110.0, help="wall-clock bound of the headline's parity sweep, seconds")
+    ap.add_argument("--qs-parity-budget", type=float, default=60.0, help="wall-clock bound of the quick_start leg's parity sweep")
+    ap.add_argument("--no-qs-leg", "--no-config3-leg", dest="no_qs_leg", action="store_true",
+                    help="default run: skip the quick_start leg (extra.quick_start)")
     ap.add_argument("--host-prep", action="store_true",
                     help="build the LANCZOS pyramid with PIL on the host before the timed region (default: raw uint8 images "
                          "resident in HBM, pyramid + ToTensor + Normalize on the device inside the timed step)")
@@ -192,18 +225,22 @@ def self_spawn(args):
 
 
 def build_workload(args, dev, rank, world):
-    """Returns (step() -> (B, width) float32 record tensor on ``dev``, meta dict, extras for the parity leg)."""
+    """Returns (step() -> (B, width) float32 record tensor on ``dev``, meta dict, extras for the parity leg).  Record columns:
+    meta["col"] = dict(status=..., nbh=... or None, rank=...)."""
     import torch
-    from rfx import weights, synth
+    from rfx import weights, synth, ops
     from rfx.pipeline import AlignPipeline
     from rfx import dist as rdist
     H, W, B, cfg = args.height, args.width, args.batch, args.config
+    draw = "host" if args.host_draw else "device"
+    draw_txt = ("RANSAC index draw: Philox on the device from the device-side match counts" if draw == "device" else
+                "RANSAC index draw: torch.randint on the CPU generator per pair and homography")
     sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
                match=weights.net_matchability_sd(3))
     seeds = [rank + world * i for i in range(B)]        # this rank's shard of the synthetic stream: pair i -> rank i mod world
     if cfg in ("qs", "2"):
         pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
-                             variant="A", device=dev)
+                             variant="A", device=dev, draw=draw, seed=1000 + rank)
         pairs = [synth.make_pair(H, W, seed=s) for s in seeds]
         raw = pipe.upload_raw(pairs)
         prep0 = pipe.prepare(pairs) if args.host_prep else None
@@ -212,67 +249,68 @@ def build_workload(args, dev, rank, world):
         def step():
             p = prep0 if prep0 is not None else pipe.prepare_device(*raw)
             res = pipe.align_prepared(p, fine=fine)
-            return rdist.pack_records(res) if fine else _coarse_records(res, dev)
+            return rdist.pack_records(res, rank=rank) if fine else _coarse_records(res, dev, rank)
         if fine:
             wl = ("batch of %d %dx%d pairs per GPU per step, full pipeline: ResNet-50 conv4 feat x%d scales + mutual NN + RANSAC("
                   "nbIter=%d, 4-pt DLT) + FeatureExtractor + 7x7 corr + NetFlowCoarse + grid_sample (quick_start semantics, one "
-                  "homography per pair; BASELINE configs 2+3 at the metric's 480x640)" % (B, H, W, args.nb_scale, args.nb_iter))
+                  "homography per pair: quick_start/align2images.py at the metric's 480x640); %s" % (B, H, W, args.nb_scale, args.nb_iter, draw_txt))
         else:
             wl = ("BASELINE config 2: ONE %dx%d pair per step, coarse RANSAC only (ResNet-50 conv4 feat x%d scales + mutual NN + "
-                  "RANSAC nbIter=%d, no fine net): value = 1 / latency" % (H, W, args.nb_scale, args.nb_iter))
-        return step, dict(workload=wl, nbIter=args.nb_iter, nbScale=args.nb_scale), dict(pipe=pipe, seeds=seeds)
+                  "RANSAC nbIter=%d, no fine net): value = 1 / latency; %s" % (H, W, args.nb_scale, args.nb_iter, draw_txt))
+        col = dict(status=9, nbh=None, rank=-1 if fine else 10)
+        return step, dict(workload=wl, nbIter=args.nb_iter, nbScale=args.nb_scale, col=col), dict(pipe=pipe, seeds=seeds)
     sds["match"] = weights.net_matchability_sd(3, last_std=MULTIH_MATCH_STD)
+    col = dict(status=1, nbh=0, rank=2)
     if cfg in ("3", "4"):
         nbScale, nbIter = (7, 10000) if cfg == "3" else (5, 50000)
-        pipe = AlignPipeline(sds, nbScale=nbScale, nbIter=nbIter, tolerance=0.05, minSize=min(H, W), scaleR=2.0, variant="B", device=dev)
+        pipe = AlignPipeline(sds, nbScale=nbScale, nbIter=nbIter, tolerance=0.05, minSize=min(H, W), scaleR=2.0, variant="B", device=dev,
+                             draw=draw, seed=1000 + rank)
         raw = pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True) for s in seeds])
 
         def step():
-            return _multi_h_records(pipe.multi_h_batched(pipe.prepare_device(*raw), maxCoarse=10, maskRegionTh=0.01), dev)
+            prep = pipe.prepare_device(*raw)
+            R = ops.MultiHRecords(B, prep["ItTensor"].shape[2] // 8, prep["ItTensor"].shape[3] // 8, dev, max_h=11)
+            R.rec[:, 2] = float(rank)
+            pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False)
+            return R.rec
         wl = ("BASELINE config %s as worded: batch of %d %dx%d pairs per GPU per step, each target warped by a seeded random "
               "homography; evaluation semantics (variant B, minSize %d, %d scales x2, coarseIter %d) + multi-homography loop "
-              "(maxCoarse 10, maskRegionTh 0.01, lock-step over the batch) with FeatureExtractor + 7x7 corr (both directions) + "
-              "NetFlowCoarse + NetMatchability x2 + flow composition per homography"
-              % (cfg, B, H, W, min(H, W), nbScale, nbIter))
-        return step, dict(workload=wl, nbIter=nbIter, nbScale=nbScale, matchability_init_std=MULTIH_MATCH_STD), dict(pipe=pipe, seeds=seeds)
-    # config 5: KITTI-shaped stream, per-pair two-resolution driver
-    pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", device=dev)
+              "(maxCoarse 10, maskRegionTh 0.01, lock-step over the batch, device-resident rounds) with FeatureExtractor + 7x7 corr "
+              "(both directions from one pass) + NetFlowCoarse + NetMatchability x2 + flow composition per homography; %s; per-pair "
+              "result record = nbH | H[11] | flowDown8[11] | matchDown8[11] (evaluation/evalHpatch/evaluation.py:254-260)"
+              % (cfg, B, H, W, min(H, W), nbScale, nbIter, draw_txt))
+        return step, dict(workload=wl, nbIter=nbIter, nbScale=nbScale, matchability_init_std=MULTIH_MATCH_STD, col=col), dict(pipe=pipe, seeds=seeds)
+    # config 5: KITTI-shaped stream, two-resolution driver
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", device=dev, draw=draw,
+                         seed=1000 + rank)
     raws = [pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True, amp=0.02)]) for s in seeds]
 
     raw_all = (torch.cat([r[0] for r in raws]), torch.cat([r[1] for r in raws]))
-    lock_step = os.environ.get("RFX_KITTI_LOCKSTEP", "1") != "0"     # 0: the per-pair driver, pair after pair
+    w_r, h_r = pipe.resize_img_dims(W, H, 8, 650)
+    w_d2, h_d2 = pipe.resize_img_dims(W, H, 8, 325)
 
     def step():
-        if lock_step:
-            return _multi_h_records(pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01), dev)
-        return _multi_h_records([pipe.multi_h_kitti(r[0], r[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01) for r in raws], dev)
+        R = ops.MultiHRecords(B, h_r // 8, w_r // 8, dev, max_h=11, hd2=h_d2 // 8, wd2=w_d2 // 8)
+        R.rec[:, 2] = float(rank)
+        pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01, records=R, want_lists=False)
+        return R.rec
     wl = ("BASELINE config 5: %d evalKITTI-shaped %dx%d pairs per GPU per step (coarseSize 800 -> 2640x800 target, 3 scales "
           "x1.2, nA = 25 747, coarseIter 50 000; fineSize 650: two-resolution fine pass, cycle-checked matchability, "
-          "cc-filter 0.01 (device union-find labelling), maskRegionTh 0.005), %s" % (B, W, H, "lock-step driver over the batch" if lock_step else "per-pair driver"))
-    return step, dict(workload=wl, nbIter=50000, nbScale=3, matchability_init_std=MULTIH_MATCH_STD), dict(pipe=pipe, seeds=seeds)
+          "cc-filter 0.01 (device union-find labelling), maskRegionTh 0.005), lock-step driver over the batch, device-resident rounds; %s; "
+          "per-pair result record = nbH | H[11] | flowDown8[11] | matchDown8[11] | flowD2[11]" % (B, W, H, draw_txt))
+    return step, dict(workload=wl, nbIter=50000, nbScale=3, matchability_init_std=MULTIH_MATCH_STD, col=col), dict(pipe=pipe, seeds=seeds)
 
 
-def _coarse_records(res, dev):
+def _coarse_records(res, dev, rank=0):
+    """[H (9) | status | rank] per pair (BASELINE config 2: coarse stage only)."""
     import torch
-    rec = torch.zeros((len(res), 10), dtype=torch.float32, device=dev)
+    rec = torch.zeros((len(res), 11), dtype=torch.float32, device=dev)
+    rec[:, 10] = float(rank)
     for b, r in enumerate(res):
         if r["H"] is not None:
             rec[b, :9] = r["H"].reshape(9)
         else:
             rec[b, 9] = 1.0
-    return rec
-
-
-def _multi_h_records(outs, dev):
-    """[9 unused | status | nbH | up to 11 homographies] per pair."""
-    import torch
-    rec = torch.zeros((len(outs), 11 + 11 * 9), dtype=torch.float32, device=dev)
-    for b, o in enumerate(outs):
-        rec[b, 9] = 0.0 if o["H"] else 1.0
-        rec[b, 10] = float(len(o["H"]))
-        if o["H"]:
-            hs = torch.stack(o["H"][:11]).reshape(-1)
-            rec[b, 11:11 + hs.numel()] = hs
     return rec
 
 
@@ -365,11 +403,29 @@ def rooflines(prof, elapsed, rank):
                 "frac": round(cb / cd / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": cb, "launches": len(prof.corr),
                 "avg_launch_us": round(cd * 1e6, 2),
                 "traffic_note": "PMC per-launch traffic of this kernel: profiles/ (static, separate --pmc passes)"}
+    if getattr(prof, "corr_bidir", None):
+        # both directions of a pair in ONE launch (evaluation semantics): `achieved` is priced on the bytes that launch must
+        # move at minimum -- (2C + 2*49)*4 per pixel: x and y read once, two volumes written -- NOT on twice SURVEY 8d's
+        # per-direction figure, which is what the two one-direction launches it replaces would have moved (given below)
+        nb = len(prof.corr_bidir)
+        mb = sum(x[0] for x in prof.corr_bidir) / nb
+        pb = sum(x[1] for x in prof.corr_bidir) / nb
+        cd = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1 in prof.corr_bidir) / nb
+        bid = {"kernel": "corr7_dma_kernel, BIDIR epilogue (corr12 and corr21 of a pair from one pass over the features)", "bound": "hbm",
+               "achieved": round(mb / cd / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mb / cd / 1e9 / PEAK_HBM_GBS, 4),
+               "traffic": None, "bytes_per_launch": mb, "launches": nb, "avg_launch_us": round(cd * 1e6, 2),
+               "per_direction_accounting": {"bytes_per_launch": pb, "achieved": round(pb / cd / 1e9, 1), "frac": round(pb / cd / 1e9 / PEAK_HBM_GBS, 4),
+                                            "note": "SURVEY 8d's (2C+49)*4 B per pair-direction x the 2 directions one launch produces"},
+               "traffic_note": "PMC per-launch traffic of this kernel: profiles/ (static, separate --pmc passes)"}
+        if corr is None:
+            corr = bid
+        else:
+            corr["bidir"] = bid
     return roof, corr
 
 
 class _NoProf:
-    conv, corr = [], []
+    conv, corr, corr_bidir = [], [], []
 
     def __enter__(self):
         return self
@@ -439,22 +495,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B = args.batch
-    ok_pairs = int((out[:, 9] == 0).sum().item())
+    col = meta.get("col", dict(status=9, nbh=None, rank=0))
+    ok_pairs = int((out[:, col["status"]] == 0).sum().item())
+    names = {"3": "BASELINE config 3 (configs[2]) as worded", "qs": "quick_start semantics at the metric's size (BASELINE configs 2+3 shape, one homography)",
+             "2": "BASELINE config 2 (configs[1])", "4": "BASELINE config 4 (configs[3])", "5": "BASELINE config 5 (configs[4])"}
     line = {"metric": METRIC, "value": round(B * args.steps * world / elapsed, 3), "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": dict(meta, config=args.config, pairs_per_step_per_gpu=B, weights="random-init",
+            "config": dict({k: v for k, v in meta.items() if k != "col"}, config=args.config, baseline_config=names.get(args.config, "dry run"),
+                           pairs_per_step_per_gpu=B, weights="random-init",
                            parallelism="pairs sharded over %d rank(s) (pair i -> rank i mod N), one all_gather of result records per step" % world,
-                           gathered_records=int(out.shape[0]), aligned_ok_last_step=ok_pairs,
+                           gathered_records=int(out.shape[0]), record_bytes_per_pair=int(out.shape[1]) * 4, aligned_ok_last_step=ok_pairs,
+                           ranks_seen_in_gather=sorted(set(int(x) for x in out[:, col["rank"]].tolist())),
                            collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
                            preprocessing="host PIL, outside the timed region" if args.host_prep else
                            "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step")}
-    if args.dry_run:
-        line["config"]["ranks_seen_in_gather"] = sorted(set(int(x) for x in out[:, 0].tolist()))
-    else:
-        if args.config in ("3", "4", "5"):
-            nbh = out[:, 10]
+    if not args.dry_run:
+        if col["nbh"] is not None:
+            nbh = out[:, col["nbh"]]
             line["config"]["homographies_per_pair_last_step"] = {"mean": round(float(nbh.mean()), 2), "min": int(nbh.min()), "max": int(nbh.max())}
+            line["config"]["homographies_per_s"] = round(float(nbh.sum()) * args.steps / elapsed, 1)
         roof, corr = rooflines(prof, profiled_elapsed, rank)
         if unprofiled is not None:
             roof["note"] = ("value / ms_per_step: HIP-graph trunk, no profiler (%.2f ms per pair); this roofline: a second pass of %d steps "
@@ -465,36 +525,47 @@ def main():
             line["roofline_corr"] = corr
 
     extras = {}
-    if rank == 0 and not args.dry_run and args.config == "qs" and world == 1:
-        # ---- config 3 as worded, driver-timed next to the headline (short leg) ----
-        if not args.no_config3_leg:
-            a3 = argparse.Namespace(**vars(args))
-            a3.config, a3.steps, a3.warmup = "3", 2, 1
-            step3, meta3, _ = build_workload(a3, dev, rank, world)
-            e3, out3, prof3 = timed_loop(step3, a3, None, sync, ops.Profiler)
-            r3, c3 = rooflines(prof3, e3, rank)
-            nbh = out3[:, 10]
-            extras["config3_multi_h"] = {"value": round(B * a3.steps / e3, 3), "unit": "pairs/s", "ms_per_step": round(e3 / a3.steps * 1e3, 2),
-                                         "steps": a3.steps, "workload": meta3["workload"],
-                                         "homographies_per_pair": {"mean": round(float(nbh.mean()), 2), "min": int(nbh.min()), "max": int(nbh.max())},
-                                         "homographies_per_s": round(float(nbh.sum()) * a3.steps / e3, 1),
-                                         "roofline": {k: r3[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops")},
-                                         "roofline_corr": c3 and {k: c3[k] for k in ("achieved", "frac", "avg_launch_us", "bytes_per_launch", "launches")}}
-            log("config-3 leg done: %.1f pairs/s" % extras["config3_multi_h"]["value"])
-            del step3
-            torch.cuda.empty_cache()
-        # ---- CPU legs: bounded oracle baseline, then the end-to-end parity sweep over the timed batch ----
+    if rank == 0 and not args.dry_run and args.config == "3" and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        # ---- quick_start semantics, driver-timed next to the headline: rounds 1-2's headline workload ----
+        if not args.no_qs_leg:
+            aq = argparse.Namespace(**vars(args))
+            aq.config, aq.steps, aq.warmup, aq.nb_iter, aq.nb_scale = "qs", 10, 2, 1000, 7
+            stepq, metaq, extraq = build_workload(aq, dev, rank, world)
+            torch.manual_seed(123)
+            eq, outq, profq = timed_loop(stepq, aq, None, sync, ops.Profiler)
+            rq, cq = rooflines(profq, eq, rank)
+            extras["quick_start"] = {"value": round(B * aq.steps / eq, 3), "unit": "pairs/s", "ms_per_step": round(eq / aq.steps * 1e3, 2),
+                                     "steps": aq.steps, "warmup": aq.warmup, "workload": metaq["workload"],
+                                     "aligned_ok_last_step": int((outq[:, 9] == 0).sum().item()),
+                                     "roofline": {k: rq[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops", "conv_time_share")},
+                                     "roofline_corr": cq}
+            log("quick_start leg done: %.1f pairs/s" % extras["quick_start"]["value"])
+        # ---- CPU legs: bounded oracle baseline, then the parity sweeps over pairs of the timed batches ----
         if not args.no_cpu_baseline:
             log("GPU legs done; timing the CPU oracle (bounded sample, child process)")
             line["cpu_baseline"] = cpu_baseline_subprocess(args)
             if not args.no_parity:
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                import parity_sweep   # the CHECKER: dumps the device results, the oracle runs in a child process
+                import parity_sweep   # the CHECKER: dumps the device results, the oracle runs in child processes
                 seeds = extra["seeds"][:args.parity_pairs] if args.parity_pairs else extra["seeds"]
-                d = tempfile.mkdtemp(prefix="rfx_parity_")
-                parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d, pipe=extra["pipe"])
-                log("parity sweep: oracle end to end on %d pairs (budget %.0f s)" % (len(seeds), args.parity_budget))
-                line["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.parity_budget)
+                d = tempfile.mkdtemp(prefix="rfx_parity_loop_")
+                parity_sweep.dump_gpu_loop("ev_loop", seeds, dev, d, batch=16)
+                log("parity sweep (config 3: every round of the multi-H loop on the oracle), %d pairs dumped, budget %.0f s" % (len(seeds), args.parity_budget))
+                line["parity"] = parity_subprocess("ev_loop", d, seeds, args.height, args.width, args.parity_budget)
+                if not args.no_qs_leg:
+                    d = tempfile.mkdtemp(prefix="rfx_parity_qs_")
+                    parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
+                    log("parity sweep (quick_start: oracle end to end), budget %.0f s" % args.qs_parity_budget)
+                    extras["quick_start"]["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.qs_parity_budget)
+    elif rank == 0 and not args.dry_run and args.config == "qs" and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        line["cpu_baseline"] = cpu_baseline_subprocess(args)
+        if not args.no_parity:
+            import parity_sweep
+            seeds = extra["seeds"][:args.parity_pairs] if args.parity_pairs else extra["seeds"]
+            d = tempfile.mkdtemp(prefix="rfx_parity_")
+            parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
+            line["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.parity_budget)
     if extras:
         line["extra"] = extras
     if rank == 0:

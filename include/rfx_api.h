@@ -38,6 +38,12 @@ extern "C" {
 /* library / build identification; returns a static string "rfx <version> gfx950". */
 const char* rfx_version(void);
 
+/* ABI revision of this header: bumped whenever an entry point changes its signature or its operand layout (round 2:
+ * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights).  A binding
+ * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
+#define RFX_ABI_VERSION 3
+int rfx_abi_version(void);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution family (ResNet-50 conv1..layer3 trunk: model/resnet50.py:68-104,112-169 as used by
  * quick_start/coarseAlignFeatMatch.py:34-52,106,124; FeatureExtractor model/model.py:59-125;
@@ -180,10 +186,23 @@ int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C,
  * automatic choice of rfx_corr_neigh_f32): 1..3 = 64/32/16-row x 16-column tiles, 4 = 16 rows x 80 columns (whole
  * 480x640-pair feature-map width) plain, 5 = the tuned 16x80 kernel (3 tap groups, hand-pipelined LDS reads, balanced wave
  * map, masked DMA, equal row tiles), 6 = 5 with 2 tap groups, 7 / 8 = the tuned kernel with 48- / 64-column tiles, 9 = 32x32.  Variants 1..9 give
- * bit-identical results (channel-ordered fmaf sums).  21 .. 24 = variant 5 with the compute / the DMA / the LDS reads / the FMAs
- * removed: WRONG results, timing experiments only.  Unknown variant -> RFX_E_ARG. */
+ * bit-identical results (channel-ordered fmaf sums).  Unknown variant -> RFX_E_ARG.  (The roofline-decomposition variants 21..24
+ * -- compute / DMA / LDS reads / FMAs removed, WRONG results -- exist only in experiment builds, -DRFX_CORR_EXPERIMENTS:
+ * `make exp NAME=correxp SRC=corr DEFS=-DRFX_CORR_EXPERIMENTS`; the product library rejects them.) */
 int rfx_corr_neigh_variant_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
                                int variant, void* stream);
+
+/* Both directions of a pair in ONE pass over the features -- what PredFlowMask computes with two CorrNeigh calls
+ * (evaluation/evalHpatch/evaluation.py:29,34: corr12 = netCorr(featt, featsSample), corr21 = netCorr(featsSample, featt)):
+ *     out_xy = CorrNeigh(x, y),   out_yx = CorrNeigh(y, x),   each (N, K*K, H, W).
+ * The reverse volume is the forward one at mirrored taps and shifted pixels,
+ *     out_yx[n, (K-1-i)*K + (K-1-j), r+i-K/2, c+j-K/2] = out_xy[n, i*K+j, r, c]
+ * (the same channel-ordered products, so the values are bit-identical to a second rfx_corr_neigh_f32 call), and zero where
+ * the source pixel lies outside the image: the kernel stores every accumulator twice instead of reading 2*C*H*W floats a
+ * second time -- (2C + 2K^2)*4 bytes per pixel instead of 2*(2C + K^2)*4.  Requires W % 4 == 0, C % 2 == 0 and 16-byte aligned
+ * pointers (the host mirror pads other widths with rfx_copy_cols_f32); K must be 7. */
+int rfx_corr_neigh_bidir_f32(const float* x, const float* y, float* out_xy, float* out_yx, int N, int C, int H, int W, int K,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Warping (kornia HomographyWarper.warp_grid: quick_start/align2images.py:61,65;
@@ -311,6 +330,51 @@ int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_
 int rfx_gather_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32_t* n, int cap, const float* xa,
                            const float* ya, const float* xb, const float* yb, float* match1, float* match2, int batch,
                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The rounds of the multi-homography drivers without host glue (evaluation/evalHpatch/evaluation.py:211-243,
+ * evaluation/evalKITTI/evaluation.py:270-336).  All per-pair state (explained-region mask, homography count, cached match
+ * list, result record) stays on the device; `active` (int32, n_active entries, NULL = identity) names the pairs of the batch
+ * that still iterate, and every per-round array is indexed by the position k in that list.
+ * ------------------------------------------------------------------------------------------ */
+/* The RANSAC index draw on the device (utils/outil.py:120 draws torch.randint(0, nbMatch, (nbIter, nbPoint),
+ * device=match1.device): on a GPU run the reference draws on the GPU).  samples (batch,N,4) int64;
+ * samples[b,h,p] = word p of Philox4x32-10(counter = (h, b, stream_id lo, stream_id hi), key = (seed lo, seed hi))
+ * modulo n[b] (torch's mapping of 32 random bits to a range below 2^32); n (batch) int32 ON THE DEVICE, n[b] <= 0 -> zeros.
+ * No host value of nbMatch is needed: the draw is enqueued behind the kernel that produces the counts. */
+int rfx_draw_samples_i64(const int32_t* n, int64_t* samples, int N, int batch, uint64_t seed, uint64_t stream_id,
+                         void* stream);
+
+/* CoarseAlign.getCoarse of the evaluation variant up to the match lists (evaluation/evalHpatch/coarseAlignFeatMatch.py:
+ * 156-170) for the active pairs of a batch: fg = ((mask + (1 - bg)) > 0.5), MtExtend = 1 - fg bilinear-resized
+ * (align_corners=False) to the (rt, ct) target feature map and thresholded at 0.5 -- evaluated only at the cells the cached
+ * matches point to -- and the surviving matches compacted IN ORDER into match1/match2 (n_active,cap,3) as
+ * rfx_gather_matches_f32 lays them out (rows >= n_out[k] zero); n_out (n_active) int32; kept (n_active,cap) int32 or NULL =
+ * slot in the cached list of every surviving match (-1 padding).  idx1/idx2 (batch,cap) int64 + count (batch) int32 = the
+ * cached mutual matches (rfx_mutual_nn_batched_f32); mask (batch,h,w) 0/1 floats; bg (batch,h,w) or NULL (= all ones). */
+int rfx_filter_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32_t* count, int cap, const int32_t* active,
+                           int n_active, const float* mask, const float* bg, int h, int w, int rt, int ct, const float* xa,
+                           const float* ya, const float* xb, const float* yb, float* match1, float* match2, int32_t* n_out,
+                           int32_t* kept, void* stream);
+
+/* The accept rule, mask update and result-record store of one round.  match (n_active,h,w) = PredFlowMask's matchability
+ * (after the small-component filter for KITTI); mask (batch,h,w) in/out; ransac_result (n_active,4) from
+ * rfx_ransac_h4_batched; n_match (n_active); nbH (batch) int32 in/out = homographies accepted so far.
+ *   mode 0 (evalHpatch/evaluation.py:225,238-239): gain = mean(match * (1 - fg)); mask <- (mask + match * (1 - fg)) >= 1
+ *   mode 1 (evalKITTI/evaluation.py:322,332-333):  gain = mean((match > 0.9999) * (1 - fg)); mask <- (... ) > 0.9999
+ * accept[k] = n_match >= 4 && status == 0 && (gain > th || nbH == 0); gain is the float64 sum of the float32 terms divided by
+ * h*w and rounded to float32 (numpy's float32 mean up to summation order).  For an accepted pair the record row
+ * rec + b*rec_stride (floats; NULL = no records) receives, at slot s = nbH[b] < max_h: H -> [off_H + 9 s], flowDown8 (2,h8,w8)
+ * -> [off_flow + 2 h8 w8 s], match12Down8 | match21Down8 -> [off_match + 2 h8 w8 s], flowD2 (2,hd2,wd2; NULL outside KITTI) ->
+ * [off_d2 + 2 hd2 wd2 s], and element 0 = the new homography count; then nbH[b] += 1.  The host reads back `accept`
+ * (n_active int32) -- the ONE device-to-host copy of a round.  ws: rfx_multih_accept_ws_bytes(n_active). */
+size_t rfx_multih_accept_ws_bytes(int n_active);
+int rfx_multih_accept_f32(const float* match, float* mask, const float* bg, const int32_t* active, int n_active, int h, int w,
+                          const int32_t* ransac_result, const int32_t* n_match, int32_t* nbH, double th, int mode,
+                          int32_t* accept, float* gain, void* ws, const float* bestH, const float* flowDown8,
+                          const float* match12Down8, const float* match21Down8, int h8, int w8, const float* flowD2, int hd2,
+                          int wd2, float* rec, long long rec_stride, int max_h, int off_H, int off_flow, int off_match,
+                          int off_d2, void* stream);
 
 #ifdef __cplusplus
 }

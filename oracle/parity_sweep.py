@@ -21,6 +21,19 @@ draws on a CPU run for a given generator state -- and ``compare`` reports
 Variants: "qs" = quick_start semantics (variant A, ResizeMaxSize, 7 scales x1.2, nA = 8 531 at 480x640, fine =
 align2images.py:87-95); "ev" = evaluation semantics (variant B, ResizeMinSize, 7 scales x2, nA = 13 065, first
 homography + PredFlowMask of evaluation/evalHpatch/evaluation.py:23-55).
+
+Round 3:
+  * every pair whose match list differs is ALSO checked downstream of the arg-max: the oracle's RANSAC + fine stage on the
+    DEVICE's match list with the same draw (inlier indices bit-exact, |dH|, flow) -> ``downstream_exact_given_matches``;
+  * ``max_flow_delta_e2e`` is the maximum over ALL compared pairs (the identical-list subset keeps its ``_identical`` key);
+  * ``--stability``: the oracle against ITSELF under a different thread count / oneDNN on-off -- how many of the pairs
+    flip a match oracle-vs-oracle (is the reference CPU path stable at these margins?);
+  * loop sweeps "ev_loop" (BASELINE config 3 as worded: the full multi-homography loop at 480x640, maxCoarse 10),
+    "c4" (config 4: 960x720, 5 scales x2, nA = 21 675, coarseIter 50 000) and "c5" (config 5: the KITTI two-resolution loop,
+    1242x376, nA = 25 747): the device driver leaves a per-round trace (``dump_gpu_loop``), the oracle replays EVERY ROUND
+    from the device's own state (teacher-forced: same surviving-match count, RANSAC on the device's matches with the same
+    draw, its own PredFlowMask on its own H, accept decision, next mask with a threshold-pixel proof) and also runs its
+    own loop end to end (``free_run``).
 """
 import argparse
 import json
@@ -39,10 +52,20 @@ for p in (HERE, os.path.join(ROOT, "ransac-flow_amd")):
 DRAW_SEED = 10_000
 TIE_EPS = 2e-5          # feature round-off is <= 2e-5 per element: a flip whose evidence exceeds this is NOT explained by it -> failure
 
+MULTIH_MATCH_STD = 3.0   # saturating matchability head of the multi-H workloads (bench.py, tests/golden/make_golden.py)
+SAT_EPS = 1e-5           # a mask pixel that differs must have its matchability within this of the saturation threshold
+
 CONFIGS = {
     # name: (variant, nbScale, scaleR, minSize rule, nbIter, match head init)
     "qs": dict(variant="A", nbScale=7, scaleR=1.2, size="max", nbIter=1000),
     "ev": dict(variant="B", nbScale=7, scaleR=2.0, size="min", nbIter=10000),
+    # loop sweeps: BASELINE configs 3 / 4 / 5 at their own sizes (bench.py --config 3 / 4 / 5 times exactly these)
+    "ev_loop": dict(variant="B", nbScale=7, scaleR=2.0, size="min", nbIter=10000, loop="hpatch", H=480, W=640, maxCoarse=10,
+                    th=0.01, amp=0.05),
+    "c4": dict(variant="B", nbScale=5, scaleR=2.0, size="min", nbIter=50000, loop="hpatch", H=720, W=960, maxCoarse=10, th=0.01,
+               amp=0.05),
+    "c5": dict(variant="B", nbScale=3, scaleR=1.2, size=800, nbIter=50000, loop="kitti", H=376, W=1242, fineSize=650, th=0.005,
+               cc_th=0.01, amp=0.02),
 }
 
 
@@ -52,10 +75,29 @@ def draw(seed, n, nb_iter):
     return torch.randint(int(n), (int(nb_iter), 4), generator=g)
 
 
-def state_dicts():
+def draw_round(seed, k, n, nb_iter):
+    """Index draw of round k (the k-th RANSAC call) of pair ``seed`` in the loop sweeps."""
+    import torch
+    g = torch.Generator().manual_seed(DRAW_SEED + 1000 * int(seed) + int(k))
+    return torch.randint(int(n), (int(nb_iter), 4), generator=g)
+
+
+def state_dicts(match_std=None):
     from rfx import weights
     return dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
-                match=weights.net_matchability_sd(3))
+                match=weights.net_matchability_sd(3) if match_std is None else weights.net_matchability_sd(3, last_std=match_std))
+
+
+def make_pair(cfg_name, seed, H, W):
+    from rfx import synth
+    c = CONFIGS[cfg_name]
+    if "loop" in c:
+        return synth.make_pair(H, W, seed=seed, homography=True, amp=c["amp"])
+    return synth.make_pair(H, W, seed=seed)
+
+
+def _min_size(c, H, W):
+    return c["size"] if isinstance(c["size"], int) else (max(H, W) if c["size"] == "max" else min(H, W))
 
 
 # ------------------------------------------------------------------------------------------------ GPU side (called by tests / bench)
@@ -64,10 +106,9 @@ def state_dicts():
 def gpu_pipeline(cfg_name, H, W, dev, sds=None):
     from rfx.pipeline import AlignPipeline
     c = CONFIGS[cfg_name]
-    sds = sds or state_dicts()
-    min_size = max(H, W) if c["size"] == "max" else min(H, W)
-    return AlignPipeline(sds, nbScale=c["nbScale"], nbIter=c["nbIter"], tolerance=0.05, minSize=min_size, scaleR=c["scaleR"],
-                         variant=c["variant"], device=dev)
+    sds = sds or state_dicts(MULTIH_MATCH_STD if "loop" in c else None)
+    return AlignPipeline(sds, nbScale=c["nbScale"], nbIter=c["nbIter"], tolerance=0.05, minSize=_min_size(c, H, W), scaleR=c["scaleR"],
+                         variant=c["variant"], device=dev, draw="host")
 
 
 def dump_gpu_pairs(cfg_name, seeds, H, W, dev, out_dir, pipe=None, batch=16):
@@ -102,15 +143,65 @@ def dump_gpu_pairs(cfg_name, seeds, H, W, dev, out_dir, pipe=None, batch=16):
     return out_dir
 
 
+def dump_gpu_loop(cfg_name, seeds, dev, out_dir, pipe=None, batch=4, sub=4):
+    """Runs the lock-step multi-homography driver of BASELINE config 3 / 4 / 5 (``cfg_name`` = ev_loop / c4 / c5) on
+    make_pair(seed) for every seed with the explicit per-round draw ``draw_round`` and writes out_dir/pair_<seed>.npz: the
+    cached match list and, per round, the mask before the round, the surviving-match count, RANSAC status and H, the /8
+    outputs, the composed flow at every ``sub``-th pixel, the accept flag / gain and the mask after the round."""
+    import torch
+    from rfx import ops
+    c = CONFIGS[cfg_name]
+    H, W = c["H"], c["W"]
+    pipe = pipe or gpu_pipeline(cfg_name, H, W, dev)
+    os.makedirs(out_dir, exist_ok=True)
+    seeds = list(seeds)
+    for k0 in range(0, len(seeds), batch):
+        sb = seeds[k0:k0 + batch]
+        raw = pipe.upload_raw([make_pair(cfg_name, s, H, W) for s in sb])
+        calls = [0] * len(sb)
+
+        def fn(b, n, it):
+            calls[b] += 1
+            return draw_round(sb[b], calls[b] - 1, n, it)
+        trace = []
+        if c["loop"] == "hpatch":
+            outs = pipe.multi_h_batched(pipe.prepare_device(*raw), maxCoarse=c["maxCoarse"], maskRegionTh=c["th"], sample_fn=fn,
+                                        trace=trace)
+        else:
+            outs = pipe.multi_h_kitti_batched(raw[0], raw[1], fineSize=c["fineSize"], maskRegionTh=c["th"], cc_th=c["cc_th"],
+                                              sample_fn=fn, trace=trace)
+        for b, s in enumerate(sb):
+            i1, i2, cnt = outs[b]["matches"]
+            n = int(cnt.item())
+            rows = [(t, t["active"].index(b)) for t in trace if b in t["active"]]
+            pack = lambda m: np.packbits(m.cpu().numpy() > 0.5, axis=-1)
+            d = dict(seed=s, index1=i1[:n].cpu().numpy(), index2=i2[:n].cpu().numpy(), nbH=outs[b]["nbH"], sub=sub,
+                     mask_before=np.stack([pack(t["mask_before"][k]) for t, k in rows]),
+                     mask_after=np.stack([pack(t["mask_after"][k]) for t, k in rows]),
+                     n=np.asarray([int(t["n"][k]) for t, k in rows]), status=np.asarray([int(t["res"][k, 0]) for t, k in rows]),
+                     H=np.stack([t["H"][k].cpu().numpy() for t, k in rows]),
+                     flowDown8=np.stack([t["pm"]["flowDown8"][k].cpu().numpy() for t, k in rows]),
+                     matchDown8=np.stack([torch.cat((t["pm"]["match12Down8"][k], t["pm"]["match21Down8"][k])).cpu().numpy() for t, k in rows]),
+                     flow12_sub=np.stack([t["pm"]["flow12"][k, ::sub, ::sub].cpu().numpy() for t, k in rows]),
+                     accept=np.asarray([int(t["accept"][k]) for t, k in rows]), gain=np.asarray([float(t["gain"][k]) for t, k in rows]),
+                     final_mask=pack(outs[b]["mask"]))
+            if c["loop"] == "kitti":
+                d["flowD2"] = np.stack([t["flowD2"][k].cpu().numpy() for t, k in rows])
+            np.savez_compressed(os.path.join(out_dir, "pair_%d.npz" % s), **d)
+        del trace, outs
+        torch.cuda.empty_cache()
+    return out_dir
+
+
 # ------------------------------------------------------------------------------------------------ oracle side
 
 _W = {}
 
 
-def _worker_init(threads):
+def _worker_init(threads, match_std=None):
     import torch
     torch.set_num_threads(threads)
-    _W["sds"] = state_dicts()
+    _W["sds"] = state_dicts(match_std)
 
 
 def oracle_pair(cfg_name, seed, H, W, sds=None):
@@ -120,8 +211,7 @@ def oracle_pair(cfg_name, seed, H, W, sds=None):
     from rfx import synth
     c = CONFIGS[cfg_name]
     sds = sds or _W.get("sds") or state_dicts()
-    min_size = max(H, W) if c["size"] == "max" else min(H, W)
-    ca = restate.CoarseAlignOracle(sds["trunk"], c["nbScale"], c["nbIter"], 0.05, min_size, c["scaleR"], variant=c["variant"],
+    ca = restate.CoarseAlignOracle(sds["trunk"], c["nbScale"], c["nbIter"], 0.05, _min_size(c, H, W), c["scaleR"], variant=c["variant"],
                                    sample_fn=lambda n, it: draw(seed, n, it))
     I1, I2 = synth.make_pair(H, W, seed=seed)
     h = w = None
@@ -204,16 +294,248 @@ def compare(cfg_name, seed, H, W, gpu_npz):
             rec["max_abs_flow_delta_given_gpu_H"] = float(np.abs(fine_given_h(cfg_name, ca, g["H"]) - g["flow12"]).max())
         if cfg_name == "ev":
             rec["max_abs_match_delta"] = float(np.abs(r["match"] - g["match"]).max())
+    if not same and bool(g["ok"]):
+        rec.update(downstream_given_matches(cfg_name, seed, ca, g))
     return rec
+
+
+def matches_from_indices(ca, i1, i2):
+    """match1 / match2 (n,3) of the oracle for a given index list (quick_start/coarseAlignFeatMatch.py:150-155)."""
+    import torch
+    i1, i2 = torch.as_tensor(np.asarray(i1), dtype=torch.long), torch.as_tensor(np.asarray(i2), dtype=torch.long)
+    ones = torch.ones(len(i1))
+    return (torch.stack((ca.HMultiScale[i1], ca.WMultiScale[i1], ones), dim=1),
+            torch.stack((ca.Ht[i2], ca.Wt[i2], ones), dim=1))
+
+
+def downstream_given_matches(cfg_name, seed, ca, g):
+    """Everything downstream of the arg-max on the DEVICE's match list: the oracle's RANSAC with the same draw (the draw the
+    device made: ``draw(seed, nMatch_device, nbIter)``) and the oracle's fine stage on the oracle's own H from it.  Shows that
+    a pair whose match list differs by a near-tie is exact from there on."""
+    import restate
+    c = CONFIGS[cfg_name]
+    m1, m2 = matches_from_indices(ca, g["index1"], g["index2"])
+    Hb, cnt, inl, _ = restate.ransac(m1, m2, 0.05, draw(seed, len(m1), c["nbIter"]))
+    if Hb is None:
+        return dict(downstream_ok=False, downstream_note="oracle RANSAC aborted on the device's match list")
+    out = dict(downstream_ok=True, downstream_inlier_bit_exact=bool(np.array_equal(inl, g["inlier"])),
+               downstream_H_delta=float(np.abs(Hb - g["H"]).max()),
+               downstream_flow_delta=float(np.abs(fine_given_h(cfg_name, ca, Hb) - g["flow12"]).max()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ loop sweeps (configs 3 / 4 / 5)
+
+
+def _unpack(bits, w):
+    return np.unpackbits(bits, axis=-1)[..., :w].astype(np.float32)
+
+
+def compare_loop(cfg_name, seed, gpu_npz):
+    """Oracle vs device for ONE pair of a loop sweep.  (1) match list with tie evidence; (2) every device round replayed on
+    the oracle from the device's own state (teacher-forced); (3) the oracle's own loop end to end (free run)."""
+    import torch
+    import torch.nn.functional as F
+    import restate
+    c = CONFIGS[cfg_name]
+    H, W = c["H"], c["W"]
+    g = np.load(gpu_npz)
+    sds = _W.get("sds") or state_dicts(MULTIH_MATCH_STD)
+    nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
+    state = {"k": 0}
+
+    def sample_fn(n, it):
+        state["k"] += 1
+        return draw_round(seed, state["k"] - 1, n, it)
+    ca = restate.CoarseAlignOracle(sds["trunk"], c["nbScale"], c["nbIter"], 0.05, _min_size(c, H, W), c["scaleR"], variant="B",
+                                   sample_fn=sample_fn)
+    Is, It = make_pair(cfg_name, seed, H, W)
+    ca.setPair(Is, It)
+    kitti = c["loop"] == "kitti"
+    if kitti:
+        T = restate.kitti_setup(Is, It, c["fineSize"])
+        h, w = T["org"]
+    else:
+        h, w = ca.It.size[1], ca.It.size[0]
+        with torch.no_grad():
+            featt = F.normalize(restate.feature_extractor(nets["feat"], ca.ItTensor))
+        grid = restate.identity_grid(h, w)
+    # ---- (1) the cached match list
+    ref = set(zip(ca.index1.tolist(), ca.index2.tolist()))
+    got = set(zip(g["index1"].tolist(), g["index2"].tolist()))
+    same = bool(np.array_equal(ca.index1.numpy(), g["index1"]) and np.array_equal(ca.index2.numpy(), g["index2"]))
+    rec = dict(seed=int(seed), nA=int(ca.featsMultiScale.shape[1]), nB=int(ca.featt.shape[2] * ca.featt.shape[3]),
+               n_matches_oracle=len(ref), n_matches_gpu=len(got), identical_list=same, n_differing=len(ref ^ got),
+               rounds=int(len(g["n"])), nbH_gpu=int(g["nbH"]))
+    if not same:
+        rec["flips"] = tie_evidence(ca, sorted(ref - got), sorted(got - ref))
+        rec["max_tie_evidence"] = max(f["evidence"] for f in rec["flips"])
+    # ---- (2) every device round from the device's own state
+    WI, HI = restate.get_wh_int(ca.featt.shape[2], ca.featt.shape[3])
+    i1d, i2d = torch.from_numpy(g["index1"]), torch.from_numpy(g["index2"])
+    m1_all, m2_all = matches_from_indices(ca, i1d, i2d)
+    sub = int(g["sub"])
+    rr = []
+    nb = 0
+    for k in range(len(g["n"])):
+        fg = _unpack(g["mask_before"][k], w)                       # It_bg = 1: the mask IS fgMask
+        keep = ca._mask_to_feat(fg)[0, 0]
+        valid = keep[WI[i2d], HI[i2d]]
+        n_or = int(valid.sum())
+        r = dict(k=k, n_gpu=int(g["n"][k]), n_oracle=n_or, count_equal=n_or == int(g["n"][k]), status_gpu=int(g["status"][k]))
+        if n_or != int(g["n"][k]) or n_or < 4:
+            rr.append(r)
+            if n_or < 4 and int(g["n"][k]) < 4:
+                r["both_below_4"] = True
+            continue
+        Hb, cnt, inl, _ = restate.ransac(m1_all[valid], m2_all[valid], 0.05, draw_round(seed, k, n_or, c["nbIter"]))
+        r["status_equal"] = (Hb is None) == (int(g["status"][k]) != 0)
+        if Hb is None or int(g["status"][k]) != 0:
+            rr.append(r)
+            continue
+        r["H_delta"] = float(np.abs(Hb - g["H"][k]).max())
+        Hm = torch.from_numpy(np.asarray(Hb, dtype=np.float32))[None]
+        if kitti:
+            match, flow_d2, fd8, md8, flow12 = restate.kitti_fine_round(nets, T, Hm, c["cc_th"])
+            fd8, md8 = fd8.numpy(), md8.numpy()
+            r["flowD2_delta"] = float(np.abs(flow_d2.numpy()[0] - g["flowD2"][k]).max())
+            stat = (match > 0.9999) * (1 - fg)
+        else:
+            with torch.no_grad():
+                flow12, match, fd8, md8 = restate.pred_flow_mask(nets, ca.IsTensor, featt, restate.warp_grid(Hm, h, w), grid)
+            stat = match * (1 - fg)
+        r["flow12_delta"] = float(np.abs(flow12[0, ::sub, ::sub].numpy() - g["flow12_sub"][k]).max())
+        r["flowDown8_delta"] = float(np.abs(fd8[0] - g["flowDown8"][k]).max())
+        r["matchDown8_frac_over_1e-3"] = float(np.mean(np.abs(md8[0] - g["matchDown8"][k]) > 1e-3))
+        gain = float(stat.mean())
+        acc = bool(gain > c["th"] or nb == 0)
+        r.update(gain_oracle=gain, gain_gpu=float(g["gain"][k]), accept_oracle=acc, accept_gpu=bool(g["accept"][k]),
+                 accept_equal=acc == bool(g["accept"][k]))
+        if bool(g["accept"][k]):
+            nb += 1
+        if acc and bool(g["accept"][k]):
+            upd = fg + match * (1 - fg)
+            new = ((upd > 0.9999) if kitti else (upd >= 1.0)).astype(np.float32)
+            diff = new != _unpack(g["mask_after"][k], w)
+            r["mask_diff_frac"] = float(diff.mean())
+            if diff.any() and not kitti:
+                # a differing pixel must sit at the saturation threshold of the sigmoid on the oracle's side too
+                r["mask_diff_min_match"] = float(match[diff].min())
+                r["mask_diff_at_threshold"] = bool(match[diff].min() > 1 - SAT_EPS)
+        rr.append(r)
+    rec["round_records"] = rr
+    # ---- (3) the oracle's own loop, end to end.  When the lists are identical and every round above reproduced the device's
+    # count, status, accept decision and NEXT MASK exactly, the oracle's own loop visits the same states by induction (same
+    # state + same draw -> the computations of (2)): it is not run a second time.
+    if same and rr and all(q["count_equal"] and q.get("status_equal", True) and q.get("accept_equal", True)
+                           and q.get("mask_diff_frac", 0.0) == 0.0 for q in rr):
+        rec["free_run"] = dict(implied_by_exact_rounds=True, nbH_oracle=int(g["nbH"]), nbH_gpu=int(g["nbH"]), same_nbH=True,
+                               max_H_delta=max([q["H_delta"] for q in rr if "H_delta" in q and q.get("accept_gpu")], default=0.0),
+                               final_mask_diff_frac=0.0)
+        return rec
+    state["k"] = 0
+    if kitti:
+        o = restate.multi_h_loop_kitti(ca, nets, Is, It, c["fineSize"], mask_region_th=c["th"], cc_th=c["cc_th"])
+    else:
+        o = restate.multi_h_loop(ca, nets, max_coarse=c["maxCoarse"], mask_region_th=c["th"])
+    Hg = g["H"][g["accept"] > 0]
+    rec["free_run"] = dict(nbH_oracle=len(o["H"]), nbH_gpu=int(g["nbH"]), same_nbH=len(o["H"]) == int(g["nbH"]))
+    if len(o["H"]) == int(g["nbH"]) and len(o["H"]):
+        rec["free_run"]["max_H_delta"] = float(np.abs(np.stack(o["H"]) - Hg).max())
+        rec["free_run"]["final_mask_diff_frac"] = float((o["masks"][-1] != _unpack(g["final_mask"], w)).mean())
+    return rec
+
+
+def summarise_loop(cfg_name, records, n_requested, elapsed):
+    c = CONFIGS[cfg_name]
+    done = [r for r in records if "error" not in r]
+    rounds = [q for r in done for q in r["round_records"]]
+    full = [q for q in rounds if "H_delta" in q]
+    flips = [f for r in done for f in r.get("flips", [])]
+    fr = [r["free_run"] for r in done]
+    mx = lambda key, rows=full: max([q[key] for q in rows if key in q], default=None)
+    thr = [q for q in full if "mask_diff_at_threshold" in q]
+    s = dict(config=cfg_name, size="%dx%d" % (c["H"], c["W"]), pairs=len(done), pairs_requested=n_requested,
+             errors=[r for r in records if "error" in r],
+             nA=done[0]["nA"] if done else None, nB=done[0]["nB"] if done else None,
+             identical_lists=sum(1 for r in done if r["identical_list"]), total_matches=sum(r["n_matches_oracle"] for r in done),
+             total_flipped_matches=sum(r["n_differing"] for r in done if not r["identical_list"]),
+             max_tie_evidence=max([f["evidence"] for f in flips], default=None),
+             flips_all_near_ties=(all(f["evidence"] < TIE_EPS for f in flips) if flips else True), tie_eps=TIE_EPS,
+             rounds=len(rounds), rounds_count_equal=sum(1 for q in rounds if q["count_equal"]),
+             rounds_compared=len(full), rounds_status_equal=all(q.get("status_equal", True) for q in rounds),
+             homographies_per_pair_gpu=round(float(np.mean([r["nbH_gpu"] for r in done])), 2) if done else None,
+             max_H_delta=mx("H_delta"), max_flow12_delta=mx("flow12_delta"), max_flowDown8_delta=mx("flowDown8_delta"),
+             max_flowD2_delta=mx("flowD2_delta"), max_matchDown8_frac_over_1e3=mx("matchDown8_frac_over_1e-3"),
+             accept_equal="%d/%d" % (sum(1 for q in full if q["accept_equal"]), len(full)),
+             max_gain_delta=max([abs(q["gain_oracle"] - q["gain_gpu"]) for q in full], default=None),
+             max_mask_diff_frac=mx("mask_diff_frac"),
+             mask_diffs_all_at_threshold=(all(q["mask_diff_at_threshold"] for q in thr) if thr else None),
+             free_run_same_nbH="%d/%d" % (sum(1 for f in fr if f["same_nbH"]), len(fr)),
+             free_run_max_H_delta=max([f["max_H_delta"] for f in fr if "max_H_delta" in f], default=None),
+             free_run_max_final_mask_diff=max([f["final_mask_diff_frac"] for f in fr if "final_mask_diff_frac" in f], default=None),
+             oracle_wall_s=round(elapsed, 1))
+    s["rounds_exact_given_state"] = "%d/%d" % (sum(1 for q in full if q["H_delta"] <= 2e-6 and q["flow12_delta"] < 1e-3
+                                                   and q["accept_equal"]), len(full))
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ oracle vs oracle
+
+
+def oracle_stability(cfg_name, seed, H, W, threads_a, threads_b):
+    """The oracle's match list and end-to-end flow under two CPU execution settings: (threads_a, oneDNN on) vs
+    (threads_b, oneDNN off).  Is the reference CPU path itself stable at the arg-max margins where the device flips?"""
+    import torch
+    runs = []
+    for threads, mkldnn in ((threads_a, True), (threads_b, False)):
+        torch.set_num_threads(threads)
+        with torch.backends.mkldnn.flags(enabled=mkldnn):
+            r, ca = oracle_pair(cfg_name, seed, H, W)
+        runs.append((r, ca))
+    (ra, ca), (rb, _) = runs
+    A = set(zip(ra["index1"].tolist(), ra["index2"].tolist()))
+    B = set(zip(rb["index1"].tolist(), rb["index2"].tolist()))
+    rec = dict(seed=int(seed), identical_list=A == B, n_differing=len(A ^ B), n_matches=len(A))
+    if A != B:
+        rec["flips"] = tie_evidence(ca, sorted(A - B), sorted(B - A))
+    if ra.get("ok") and rb.get("ok"):
+        rec["flow_delta"] = float(np.abs(ra["flow12"] - rb["flow12"]).max())
+        rec["H_delta"] = float(np.abs(ra["H"] - rb["H"]).max())
+    return rec
+
+
+def _stab_job(args):
+    t0 = time.perf_counter()
+    try:
+        rec = oracle_stability(*args)
+    except Exception as e:  # noqa: BLE001
+        rec = dict(seed=int(args[1]), error="%s: %s" % (type(e).__name__, e))
+    rec["oracle_s"] = round(time.perf_counter() - t0, 2)
+    return rec
+
+
+def summarise_stability(cfg_name, records, H, W, ta, tb):
+    done = [r for r in records if "error" not in r]
+    flips = [f for r in done for f in r.get("flips", [])]
+    return dict(kind="oracle_vs_oracle", config=cfg_name, size="%dx%d" % (H, W),
+                settings=["%d threads, oneDNN on" % ta, "%d thread(s), oneDNN off" % tb], pairs=len(done),
+                errors=[r for r in records if "error" in r],
+                pairs_with_flips=sum(1 for r in done if not r["identical_list"]),
+                total_flipped_matches=sum(r["n_differing"] for r in done), total_matches=sum(r["n_matches"] for r in done),
+                max_tie_evidence=max([f["evidence"] for f in flips], default=None),
+                max_flow_delta_identical=max([r["flow_delta"] for r in done if r["identical_list"] and "flow_delta" in r], default=None),
+                max_flow_delta_with_flips=max([r["flow_delta"] for r in done if not r["identical_list"] and "flow_delta" in r], default=None))
 
 
 def _job(args):
     cfg_name, seed, H, W, path = args
     t0 = time.perf_counter()
     try:
-        rec = compare(cfg_name, seed, H, W, path)
+        rec = compare_loop(cfg_name, seed, path) if "loop" in CONFIGS[cfg_name] else compare(cfg_name, seed, H, W, path)
     except Exception as e:  # noqa: BLE001 -- a checker crash must surface in the summary, not kill the sweep
-        rec = dict(seed=int(seed), error="%s: %s" % (type(e).__name__, e))
+        import traceback
+        rec = dict(seed=int(seed), error="%s: %s" % (type(e).__name__, e), trace=traceback.format_exc()[-800:])
     rec["oracle_s"] = round(time.perf_counter() - t0, 2)
     return rec
 
@@ -232,7 +554,8 @@ def summarise(cfg_name, records, n_requested, elapsed, H, W):
              inlier_indices_bit_exact=(all(r.get("inlier_indices_bit_exact", True) for r in ident) if ident else None),
              max_abs_H_delta_identical=max([r["max_abs_H_delta"] for r in ident if "max_abs_H_delta" in r], default=None),
              max_flow_delta_e2e_identical=max([r["max_abs_flow_delta_e2e"] for r in ident if "max_abs_flow_delta_e2e" in r], default=None),
-             max_flow_delta_e2e=max([r["max_abs_flow_delta_e2e"] for r in ident if "max_abs_flow_delta_e2e" in r], default=None),   # = _identical (the bound 1e-3 applies where both sides ran the same RANSAC)
+             # maximum over ALL compared pairs -- incl. the pairs where a near-tie flip made the two sides run different RANSACs
+             max_flow_delta_e2e=max([r["max_abs_flow_delta_e2e"] for r in both_ok], default=None),
              pairs_with_flips=len(diff), total_flipped_matches=sum(r["n_differing"] for r in diff),
              total_matches=sum(r["n_matches_oracle"] for r in done),
              max_tie_evidence=max([f["evidence"] for f in flips], default=None),
@@ -241,6 +564,17 @@ def summarise(cfg_name, records, n_requested, elapsed, H, W):
              max_flow_delta_fine_stage_with_flips=max([r["max_abs_flow_delta_given_gpu_H"] for r in diff if "max_abs_flow_delta_given_gpu_H" in r], default=None),
              sentinel_agreement=all(r["oracle_ok"] == r["gpu_ok"] for r in ident),
              oracle_wall_s=round(elapsed, 1))
+    # downstream of the arg-max: identical-list pairs are exact end to end; flipped pairs are checked on the device's list
+    dn = [r for r in diff if r.get("downstream_ok")]
+    exact = lambda r: r["downstream_inlier_bit_exact"] and r["downstream_H_delta"] <= 2e-6 and r["downstream_flow_delta"] < 1e-3
+    ident_exact = [r for r in ident if r.get("inlier_indices_bit_exact") and r.get("max_abs_H_delta", 1) <= 2e-6
+                   and r.get("max_abs_flow_delta_e2e", 1) < 1e-3]
+    ident_sentinel = [r for r in ident if "max_abs_flow_delta_e2e" not in r and r["oracle_ok"] == r["gpu_ok"]]
+    s["downstream_exact_given_matches"] = "%d/%d" % (len(ident_exact) + len(ident_sentinel) + sum(1 for r in dn if exact(r)), len(done))
+    s["downstream_checked_flipped_pairs"] = len(dn)
+    s["downstream_max_H_delta_flipped"] = max([r["downstream_H_delta"] for r in dn], default=None)
+    s["downstream_max_flow_delta_flipped"] = max([r["downstream_flow_delta"] for r in dn], default=None)
+    s["downstream_inlier_bit_exact_flipped"] = all(r["downstream_inlier_bit_exact"] for r in dn) if dn else None
     if cfg_name == "ev" and both_ok:
         s["max_match_delta_identical"] = max([r["max_abs_match_delta"] for r in ident if "max_abs_match_delta" in r], default=None)
     return s
@@ -254,17 +588,19 @@ def sweep(cfg_name, dump_dir, seeds, H, W, workers=None, threads=8, budget_s=Non
     threads = max(1, min(threads, cores))
     workers = workers or max(1, cores // threads)
     jobs = [(cfg_name, s, H, W, os.path.join(dump_dir, "pair_%d.npz" % s)) for s in seeds]
+    loop = "loop" in CONFIGS[cfg_name]
+    mstd = MULTIH_MATCH_STD if loop else None
     t0 = time.perf_counter()
     records = []
     if workers == 1:
-        _worker_init(threads)
+        _worker_init(threads, mstd)
         for j in jobs:
             if budget_s and time.perf_counter() - t0 > budget_s:
                 break
             records.append(_job(j))
     else:
         ctx = mp.get_context("spawn")
-        with ctx.Pool(workers, initializer=_worker_init, initargs=(threads,)) as pool:
+        with ctx.Pool(workers, initializer=_worker_init, initargs=(threads, mstd)) as pool:
             it = pool.imap_unordered(_job, jobs)
             for _ in jobs:
                 left = None if not budget_s else max(1.0, budget_s - (time.perf_counter() - t0))
@@ -274,22 +610,44 @@ def sweep(cfg_name, dump_dir, seeds, H, W, workers=None, threads=8, budget_s=Non
                     break
             pool.terminate()
     records.sort(key=lambda r: r["seed"])
+    if loop:
+        return summarise_loop(cfg_name, records, len(jobs), time.perf_counter() - t0), records
     return summarise(cfg_name, records, len(jobs), time.perf_counter() - t0, H, W), records
+
+
+def stability_sweep(cfg_name, seeds, H, W, threads_a, threads_b, budget_s=None):
+    t0 = time.perf_counter()
+    _W["sds"] = state_dicts()
+    records = []
+    for s in seeds:
+        if budget_s and time.perf_counter() - t0 > budget_s:
+            break
+        records.append(_stab_job((cfg_name, s, H, W, threads_a, threads_b)))
+    return summarise_stability(cfg_name, records, H, W, threads_a, threads_b), records
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="qs", choices=sorted(CONFIGS))
-    ap.add_argument("--dump", required=True)
+    ap.add_argument("--dump", default=None)
+    ap.add_argument("--stability", action="store_true", help="oracle vs oracle (thread count / oneDNN), no GPU dump needed")
+    ap.add_argument("--threads-b", type=int, default=1)
     ap.add_argument("--seeds", type=int, nargs="+", default=list(range(64)))
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--workers", type=int, default=None)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--budget", type=float, default=None)
     ap.add_argument("--records", type=str, default=None, help="write the per-pair records to this JSON file")
     a = ap.parse_args()
-    summary, records = sweep(a.config, a.dump, a.seeds, a.height, a.width, a.workers, a.threads, a.budget)
+    a.height = a.height or CONFIGS[a.config].get("H", 480)
+    a.width = a.width or CONFIGS[a.config].get("W", 640)
+    if a.stability:
+        summary, records = stability_sweep(a.config, a.seeds, a.height, a.width, a.threads, a.threads_b, a.budget)
+    else:
+        if not a.dump:
+            ap.error("--dump is required unless --stability")
+        summary, records = sweep(a.config, a.dump, a.seeds, a.height, a.width, a.workers, a.threads, a.budget)
     if a.records:
         json.dump(dict(summary=summary, records=records), open(a.records, "w"), indent=1)
     print(json.dumps(summary))

@@ -44,6 +44,7 @@ struct Cfg {
     static constexpr bool ZM = OPT_ & 2;    // halo / padding slots zeroed ONCE, DMA lanes that would fetch zeros masked off
     static constexpr bool XPAD = OPT_ & 4;  // x rows padded to the y row stride (conflict-free ds_read_b128 of x)
     static constexpr bool PRIO = OPT_ & 8;  // s_setprio 1 for the waves of the largest tap group
+    static constexpr bool BIDIR = OPT_ & 16; // also write corr(y, x): the same products at mirrored taps / shifted pixels
     static constexpr int NW = TR / 16 * NCB * NG;              // waves per workgroup: strips x column blocks x tap-row groups
     static constexpr int YR = TR + 6;                          // halo rows
     static constexpr int YQ = 4 * NCB + 2;                     // float4 per halo row (cols c0-4 .. c0+16*NCB+3)
@@ -171,7 +172,8 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <class G, int I0, int I1>
 __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave, int amask,
                                             int strip, int cb, int lane, int nchunks, size_t HW,
-                                            float* __restrict__ out, int n, int row0, int c0, int H, int W, int trv) {
+                                            float* __restrict__ out, float* __restrict__ out21, int n, int row0, int c0, int H,
+                                            int W, int trv) {
     constexpr int NI = I1 - I0, NS = G::NS, CK = G::CK, PF = G::PF, DBG = G::DBG, TR = G::TR;
     auto issue = [&](int chunk, int buf) {
         const size_t cbase = (size_t)chunk * CK * HW;
@@ -253,13 +255,40 @@ __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const 
             f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
             *reinterpret_cast<f32x4*>(o + (size_t)(I0 * 7 + q) * HW) = v;
         }
+        if constexpr (G::BIDIR) {
+            // corr(y, x)[(6-i)*7 + (6-j), r+i-3, c+j-3] = corr(x, y)[i*7 + j, r, c]: the SAME channel-ordered sum (products
+            // commute bit for bit), so the reverse direction of a pair is this lane's accumulators stored once more at the
+            // mirrored tap and the shifted pixel.  A destination whose source pixel lies outside the image is a zero of
+            // the reverse volume (its window tap falls into the padding, model/model.py:135,143): the lane that OWNS that
+            // destination pixel writes the zero, so every element of out21 is written exactly once.
+            float* o21 = out21 + (size_t)n * 49 * HW;
+#pragma unroll
+            for (int q = 0; q < NI * 7; ++q) {
+                const int i = I0 + q / 7, j = q % 7;
+                float* pl = o21 + (size_t)((6 - i) * 7 + (6 - j)) * HW;
+                const int dr = gr + i - 3;
+                if ((unsigned)dr < (unsigned)H) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int dc = gc + d + j - 3;
+                        if ((unsigned)dc < (unsigned)W) pl[(size_t)dr * W + dc] = acc[d][q];
+                    }
+                }
+                const int sr = gr - (i - 3);                    // source row of this lane's own pixels in plane (6-i, 6-j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int sc = gc + d - (j - 3);
+                    if ((unsigned)sr >= (unsigned)H || (unsigned)sc >= (unsigned)W) pl[(size_t)gr * W + gc + d] = 0.f;
+                }
+            }
+        }
     }
 }
 
 template <class G>
 __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_kernel(
-    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int N, int C, int H, int W,
-    int tilesR, int tilesC, int trv) {
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, float* __restrict__ out21, int N, int C,
+    int H, int W, int tilesR, int tilesC, int trv) {
     constexpr int TR = G::TR, NCB = G::NCB, NG = G::NG;
     __shared__ __attribute__((aligned(16))) f32x4 smem[G::NS * G::BUF_SLOTS];
 
@@ -328,7 +357,7 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
     }
     const int strip = sc / NCB, cb = sc - strip * NCB;
     const int nch = C / G::CK;
-#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, amask, strip, cb, lane, nch, HW, out, n, row0, c0, H, W, trv)
+#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, amask, strip, cb, lane, nch, HW, out, out21, n, row0, c0, H, W, trv)
     if (G::PRIO && grp == 0) __builtin_amdgcn_s_setprio(1);   // the 4-/3-row group has the most FMAs per chunk: let it win VALU arbitration
     if (grp == 0) RFX_STRIP(0);
     else if (grp == 1) RFX_STRIP(1);
@@ -338,11 +367,12 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
 }
 
 template <class G>
-static void launch_corr(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st, bool even = false) {
+static void launch_corr(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st, bool even = false,
+                        float* out21 = nullptr) {
     const int tilesR = (H + G::TR - 1) / G::TR, tilesC = (W + TC * G::NCB - 1) / (TC * G::NCB);
     const int trv = even ? (H + tilesR - 1) / tilesR : G::TR;      // equal row tiles (60 = 4 x 15) or full 16-row strips
-    hipLaunchKernelGGL((corr7_dma_kernel<G>), dim3((unsigned)(N * tilesR * tilesC)), dim3(G::NW * 64), 0, st, x, y, out, N,
-                       C, H, W, tilesR, tilesC, trv);
+    hipLaunchKernelGGL((corr7_dma_kernel<G>), dim3((unsigned)(N * tilesR * tilesC)), dim3(G::NW * 64), 0, st, x, y, out,
+                       out21, N, C, H, W, tilesR, tilesC, trv);
 }
 
 // Plain fallback for widths that are not a multiple of 4 (never hit by the reference's /8 feature maps of
@@ -380,7 +410,24 @@ __global__ __launch_bounds__(256) void corr7_plain_kernel(const float* __restric
 using CfgTuned = Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15>;
 using CfgTuned4 = Cfg<16, 4, 2, 4, 3, 1, 0, 0, 14>;   // 64-column tiles: 12 waves, one of each tap group per SIMD by construction
 using CfgTuned3 = Cfg<16, 3, 2, 4, 3, 1, 0, 0, 14>;   // 48-column tiles: 9 waves
-static int launch_variant(int v, const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st) {
+// BIDIR forms (OPT bit 16) of the tile shapes the automatic choice can return: same main loop, second store in the epilogue
+using CfgTunedB = Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 16>;
+using CfgTuned4B = Cfg<16, 4, 2, 4, 3, 1, 0, 0, 14 | 16>;
+using CfgTuned3B = Cfg<16, 3, 2, 4, 3, 1, 0, 0, 14 | 16>;
+static int launch_variant(int v, const float* x, const float* y, float* out, float* out21, int N, int C, int H, int W,
+                          hipStream_t st) {
+    if (out21) {
+        switch (v) {
+            case 1: launch_corr<Cfg<64, 1, 2, 3, 2, 0, 0, 0, 16>>(x, y, out, N, C, H, W, st, false, out21); break;
+            case 2: launch_corr<Cfg<32, 1, 2, 3, 2, 0, 0, 0, 16>>(x, y, out, N, C, H, W, st, false, out21); break;
+            case 3: launch_corr<Cfg<16, 1, 2, 3, 2, 0, 0, 0, 16>>(x, y, out, N, C, H, W, st, false, out21); break;
+            case 5: launch_corr<CfgTunedB>(x, y, out, N, C, H, W, st, true, out21); break;
+            case 7: launch_corr<CfgTuned3B>(x, y, out, N, C, H, W, st, true, out21); break;
+            case 8: launch_corr<CfgTuned4B>(x, y, out, N, C, H, W, st, true, out21); break;
+            default: return RFX_E_ARG;
+        }
+        return RFX_OK;
+    }
     switch (v) {
         case 1: launch_corr<Cfg<64, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
         case 2: launch_corr<Cfg<32, 1, 2, 3>>(x, y, out, N, C, H, W, st); break;
@@ -391,13 +438,40 @@ static int launch_variant(int v, const float* x, const float* y, float* out, int
         case 7: launch_corr<CfgTuned3>(x, y, out, N, C, H, W, st, true); break;
         case 8: launch_corr<CfgTuned4>(x, y, out, N, C, H, W, st, true); break;
         case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
+#ifdef RFX_CORR_EXPERIMENTS   // `make exp NAME=correxp SRC=corr DEFS=-DRFX_CORR_EXPERIMENTS`: never in the product library
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 23: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 5, 0, 15>>(x, y, out, N, C, H, W, st, true); break;   // DMA + FMAs, no LDS reads
         case 24: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 6, 0, 15>>(x, y, out, N, C, H, W, st, true); break;   // DMA + LDS reads, no FMAs
+#endif
         default: return RFX_E_ARG;
     }
     return RFX_OK;
+}
+
+// Tile shape by traffic first, parallelism second.  A tile spanning the image width has no column halo and its row-halo
+// re-reads hit the XCD's L2 (measured: 1.00x the algorithmic bytes leave L2 at 60x80, against 1.37x for 16x16 tiles); it is
+// taken when the launch still gives most CUs a workgroup.  Otherwise 16-column tiles, as tall as the workgroup count allows
+// (>= 1024 workgroups).
+static int auto_variant(int N, int H, int W) {
+    const long long tc = (W + TC - 1) / TC;
+    const long long r16 = (H + 15) / 16;
+    if (W > 32 && (long long)N * r16 * ((W + 79) / 80) >= 128) {
+        // tuned kernel: the tile width (80 / 64 / 48 columns) that pads the map width least; ties -> the widest
+        int best = 5, best_w = 1 << 30;
+        for (int ncb = 5; ncb >= 3; --ncb) {
+            const int padded = (W + 16 * ncb - 1) / (16 * ncb) * (16 * ncb);
+            if (padded < best_w) { best_w = padded; best = ncb; }
+        }
+        return best == 5 ? 5 : (best == 4 ? 8 : 7);
+    }
+    const long long b64 = (long long)N * ((H + 63) / 64) * tc, b32 = (long long)N * ((H + 31) / 32) * tc;
+    return b64 >= 1024 ? 1 : (b32 >= 1024 ? 2 : 3);
+}
+
+static bool dma_ok(const void* a, const void* b, const void* c, const void* d, int C, int W) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return W % 4 == 0 && C % 2 == 0 && al(a) && al(b) && al(c) && al(d);
 }
 
 }  // namespace
@@ -408,31 +482,9 @@ extern "C" int rfx_corr_neigh_variant_f32(const float* x, const float* y, float*
     if (K != 7) return RFX_E_ARG;
     if ((long long)C * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
     hipStream_t st = rfx_stream(stream);
-    if (W % 4 == 0 && C % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        const long long tc = (W + TC - 1) / TC;
-        if ((long long)N * ((H + 15) / 16) * tc > 0x7fffffffLL) return RFX_E_LIMIT;
-        int v = variant;
-        if (v == 0) {
-            // Tile shape by traffic first, parallelism second.  A tile spanning the image width has no column halo and
-            // its row-halo re-reads hit the XCD's L2 (measured: 1.00x the algorithmic bytes leave L2 at 60x80, against
-            // 1.37x for 16x16 tiles); it is taken when the launch still gives most CUs a workgroup.  Otherwise 16-column
-            // tiles, as tall as the workgroup count allows (>= 1024 workgroups).
-            const long long r16 = (H + 15) / 16;
-            if (W > 32 && (long long)N * r16 * ((W + 79) / 80) >= 128) {
-                // tuned kernel: the tile width (80 / 64 / 48 columns) that pads the map width least; ties -> the widest
-                int best = 5, best_w = 1 << 30;
-                for (int ncb = 5; ncb >= 3; --ncb) {
-                    const int padded = (W + 16 * ncb - 1) / (16 * ncb) * (16 * ncb);
-                    if (padded < best_w) { best_w = padded; best = ncb; }
-                }
-                v = best == 5 ? 5 : (best == 4 ? 8 : 7);
-            } else {
-                const long long b64 = (long long)N * ((H + 63) / 64) * tc, b32 = (long long)N * ((H + 31) / 32) * tc;
-                v = b64 >= 1024 ? 1 : (b32 >= 1024 ? 2 : 3);
-            }
-        }
-        const int rc = launch_variant(v, x, y, out, N, C, H, W, st);
+    if (dma_ok(x, y, out, nullptr, C, W)) {
+        if ((long long)N * ((H + 15) / 16) * ((W + TC - 1) / TC) > 0x7fffffffLL) return RFX_E_LIMIT;
+        const int rc = launch_variant(variant == 0 ? auto_variant(N, H, W) : variant, x, y, out, nullptr, N, C, H, W, st);
         if (rc != RFX_OK) return rc;
     } else {
         const long long NP = (long long)N * H * W;
@@ -447,4 +499,17 @@ extern "C" int rfx_corr_neigh_variant_f32(const float* x, const float* y, float*
 extern "C" int rfx_corr_neigh_f32(const float* x, const float* y, float* out, int N, int C, int H, int W, int K,
                                   void* stream) {
     return rfx_corr_neigh_variant_f32(x, y, out, N, C, H, W, K, 0, stream);
+}
+
+extern "C" int rfx_corr_neigh_bidir_f32(const float* x, const float* y, float* out_xy, float* out_yx, int N, int C, int H, int W,
+                                        int K, void* stream) {
+    if (!x || !y || !out_xy || !out_yx || N <= 0 || C <= 0 || H <= 0 || W <= 0) return RFX_E_ARG;
+    if (K != 7) return RFX_E_ARG;
+    if ((long long)C * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
+    if (!dma_ok(x, y, out_xy, out_yx, C, W)) return RFX_E_ARG;       // the host mirrors pad the width to a multiple of 4
+    if ((long long)N * ((H + 15) / 16) * ((W + TC - 1) / TC) > 0x7fffffffLL) return RFX_E_LIMIT;
+    const int rc = launch_variant(auto_variant(N, H, W), x, y, out_xy, out_yx, N, C, H, W, rfx_stream(stream));
+    if (rc != RFX_OK) return rc;
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
 }

@@ -6,7 +6,7 @@ loudly (RuntimeError), and every op refuses tensors that are not on a HIP device
 """
 import ctypes
 import os
-from ctypes import c_int, c_int32, c_int64, c_float, c_void_p, c_size_t, c_longlong, c_char_p
+from ctypes import c_int, c_int32, c_int64, c_uint64, c_float, c_double, c_void_p, c_size_t, c_longlong, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RFX_LIB") or os.path.normpath(os.path.join(_HERE, "..", "librfx.so"))  # RFX_LIB: experiments
@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RFX_LIB") or os.path.normpath(os.path.join(_HERE, "..
 # name -> (restype, argtypes); mirrors include/rfx_api.h one to one
 SIGNATURES = {
     "rfx_version": (c_char_p, []),
+    "rfx_abi_version": (c_int, []),
     "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
     "rfx_conv2d_tile_variant": (c_int, [c_int] * 4),
     "rfx_conv2d_kernel_id": (c_int, [c_int] * 9),
@@ -33,6 +34,7 @@ SIGNATURES = {
     "rfx_copy_cols_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "rfx_corr_neigh_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "rfx_corr_neigh_variant_f32": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
+    "rfx_corr_neigh_bidir_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "rfx_grid_sample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "rfx_compose_flow_f32": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
@@ -55,7 +57,15 @@ SIGNATURES = {
     "rfx_ransac_h4_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4
                               + [c_int, c_void_p]),
     "rfx_gather_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_void_p]),
+    "rfx_draw_samples_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_void_p]),
+    "rfx_filter_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4
+                               + [c_void_p] * 9),
+    "rfx_multih_accept_ws_bytes": (c_size_t, [c_int]),
+    "rfx_multih_accept_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 7
+                              + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),
 }
+
+ABI_VERSION = 3     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
 
 _lib = None
 
@@ -80,6 +90,9 @@ def load():
             raise RuntimeError("librfx.so is missing symbol %s (stale build?)" % name) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.rfx_abi_version() != ABI_VERSION:
+        raise RuntimeError("librfx.so has ABI revision %d, this binding was written against %d (stale build?): rebuild with "
+                           "`make -C ransac-flow_amd/csrc`" % (lib.rfx_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

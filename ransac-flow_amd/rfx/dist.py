@@ -4,8 +4,10 @@ The reference has no distributed code on this path; its only "data parallelism" 
 several processes over index slices (evaluation/evalKITTI/evaluation.py:163-164,220).  Pairs are
 independent units, so rank r aligns pairs r, r+world, ... with replicated weights and no data-path
 collective; the only exchange is ONE all_gather (RCCL over xGMI, backend "nccl") of fixed-size per-pair
-result records -- what the evaluation scripts save per pair: the coarse homography and the /8 fine flow
-(evaluation/evalHpatch/evaluation.py:254-260).  Latency-bound (38 KB / pair at 480x640).
+result records -- what the evaluation scripts save per pair (evaluation/evalHpatch/evaluation.py:254-260): quick_start
+semantics = the coarse homography + the /8 fine flow (38 KB / pair at 480x640, latency-bound); the multi-homography
+drivers = nbH, H[11], flowDown8[11], matchDown8[11] padded to 11 homographies (0.85 MB / pair at 480x640:
+rfx.ops.MultiHRecords, filled on the device by rfx_multih_accept_f32).
 """
 import torch
 
@@ -15,19 +17,24 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def record_width(h8, w8):
-    return 9 + 1 + 2 * h8 * w8
+def record_width(h8, w8, tagged=False):
+    return 9 + 1 + 2 * h8 * w8 + (1 if tagged else 0)
 
 
-def pack_records(results):
-    """List of per-pair result dicts (rfx.pipeline) -> (B, 9 + 1 + 2*h8*w8) float32 tensor:
-    [H row-major (zeros if failed) | status (0 ok, 1 failed) | flowDown8 (2,h8,w8) flattened]."""
+def pack_records(results, rank=None):
+    """List of per-pair result dicts (rfx.pipeline, one homography per pair) -> (B, 9 + 1 + 2*h8*w8 [+ 1]) float32 tensor:
+    [H row-major (zeros if failed) | status (0 ok, 1 failed) | flowDown8 (2,h8,w8) flattened [| rank of the producer]].
+    The multi-homography drivers fill rfx.ops.MultiHRecords rows on the device instead (nbH | status | rank | H[11] |
+    flowDown8[11] | matchDown8[11]: what evaluation/evalHpatch/evaluation.py:254-260 saves per pair)."""
     dev = results[0]["flowDown"].device
     zero9 = torch.zeros(9, dtype=torch.float32, device=dev)
     Hm = torch.stack([r["H"].reshape(9) if r["H"] is not None else zero9 for r in results])          # one kernel
     status = torch.tensor([[0.0 if r["H"] is not None else 1.0] for r in results], dtype=torch.float32).to(dev, non_blocking=True)
     fd = torch.cat([r["flowDown"].reshape(1, -1) for r in results], dim=0)                              # one kernel
-    return torch.cat((Hm, status, fd), dim=1)
+    parts = (Hm, status, fd)
+    if rank is not None:
+        parts = parts + (torch.full((len(results), 1), float(rank), dtype=torch.float32, device=dev),)
+    return torch.cat(parts, dim=1)
 
 
 def gather_records(rec, dist=None, force=False):

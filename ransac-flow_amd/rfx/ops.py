@@ -51,12 +51,13 @@ class Profiler:
     launch stream; nothing is recorded -- and no event is created -- outside such a block.
 
         prof.conv: list of (kernel_id, flops, ev0, ev1, shape, algorithmic_bytes)
-        prof.corr: list of (algorithmic_bytes, ev0, ev1)
+        prof.corr: list of (algorithmic_bytes, ev0, ev1)                       one-direction launches
+        prof.corr_bidir: list of (minimal_bytes, per_direction_bytes, ev0, ev1)   both directions of a pair in one launch
     """
     _tls = threading.local()
 
     def __init__(self):
-        self.conv, self.corr = [], []
+        self.conv, self.corr, self.corr_bidir = [], [], []
 
     def __enter__(self):
         self._prev = getattr(Profiler._tls, "active", None)
@@ -72,17 +73,21 @@ class Profiler:
         return getattr(Profiler._tls, "active", None)
 
     @staticmethod
-    def begin():
+    def begin(dev=None):
+        """Start event on the current stream OF THE DEVICE THE LAUNCH GOES TO (``dev``: a tensor of the op or its device;
+        default: the current device) -- the stream _call() launches on."""
         if getattr(Profiler._tls, "active", None) is None:
             return None
+        dev = dev.device if isinstance(dev, torch.Tensor) else dev
         e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(torch.cuda.current_stream(dev))
+        e0._rfx_dev = dev
         return e0
 
     @staticmethod
     def end(e0):
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1.record(torch.cuda.current_stream(getattr(e0, "_rfx_dev", None)))
         return e1
 
 
@@ -162,7 +167,7 @@ class ConvPlan:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
         lib = _lib.load()
         direct = self.wP is not None and (lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, 3, 3, 1, 1, Ho, Wo) & 32) != 0
-        e0 = Profiler.begin()
+        e0 = Profiler.begin(x)
         if direct:
             _call("rfx_conv3x3_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
                   _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
@@ -199,7 +204,7 @@ def bottleneck_tail(x, plan2, plan3, residual=None):
     out = torch.empty((N, plan3.Cout, H, W), dtype=torch.float32, device=x.device)
     if res is not None and res.shape != out.shape:
         raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
-    e0 = Profiler.begin()
+    e0 = Profiler.begin(x)
     _call("rfx_conv3x3_conv1x1_f32", _one_device(x, res, plan2.wP, plan3.scale), _p(x), _p(plan2.wP), _p(plan2.scale),
           _p(plan2.shift), plan2.act, _p(plan3.quad_weights()), _p(plan3.scale), _p(plan3.shift), _p(res), plan3.act,
           _p(out), N, C, H, W, plan2.Cout, plan3.Cout)
@@ -251,7 +256,7 @@ def stem_conv_maxblur(x, plan):
         raise ValueError("stem_conv_maxblur: not a 3x3/s1/p1 ReLU convolution of a 3-channel image")
     Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
     out = torch.empty((N, plan.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    e0 = Profiler.begin()
+    e0 = Profiler.begin(x)
     _call("rfx_stem_conv3x3_maxblur_f32", _one_device(x, plan.wT), _p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
                                                        plan.Cout)
     if e0 is not None:
@@ -272,7 +277,7 @@ def stem_conv7_maxpool(x, plan):
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     out = torch.empty((N, plan.Cout, Hp, Wp), dtype=torch.float32, device=x.device)
-    e0 = Profiler.begin()
+    e0 = Profiler.begin(x)
     _call("rfx_stem_conv7x7_maxpool_f32", _one_device(x, plan.wT), _p(x), _p(plan.wT), _p(plan.scale), _p(plan.shift), _p(out), N, H, W,
                                                        plan.Cout)
     if e0 is not None:
@@ -386,12 +391,44 @@ def corr_neigh(x, y, K=7, variant=None):
         xp, yp = copy_cols(x.view(-1, W), Wp).view(N, C, H, Wp), copy_cols(y.view(-1, W), Wp).view(N, C, H, Wp)
         return copy_cols(corr_neigh(xp, yp, K).view(-1, Wp), W).view(N, K * K, H, W)
     out = torch.empty((N, K * K, H, W), dtype=torch.float32, device=x.device)
-    e0 = Profiler.begin()
+    e0 = Profiler.begin(x)
     v = int(os.environ.get("RFX_CORR_VARIANT", "0")) if variant is None else int(variant)
     _call("rfx_corr_neigh_variant_f32", _one_device(x, y), _p(x), _p(y), _p(out), N, C, H, W, K, v)
     if e0 is not None:
         Profiler.active().corr.append(((2 * C + K * K) * 4.0 * N * H * W, e0, Profiler.end(e0)))  # algorithmic bytes
     return out
+
+
+def corr_neigh_bidir(x, y, K=7, out=None):
+    """Both directions of a pair in ONE launch: returns (corr_neigh(x, y), corr_neigh(y, x)), each (N,49,H,W).  The reverse
+    volume is the forward one at mirrored taps and shifted pixels -- corr(y,x)[(6-i)*7+(6-j), r+i-3, c+j-3] =
+    corr(x,y)[i*7+j, r, c], the same channel-ordered sums -- so it costs a second store, not a second 2*C*H*W read
+    (evaluation/evalHpatch/evaluation.py:29-35 computes both).  ``out``: optional (2N,49,H,W) buffer; the two results are
+    its halves (what the matchability head consumes as one batch)."""
+    x, y = _dev(x, "corr x"), _dev(y, "corr y")
+    if x.shape != y.shape:
+        raise ValueError("corr_neigh_bidir: x %s and y %s differ" % (tuple(x.shape), tuple(y.shape)))
+    N, C, H, W = x.shape
+    if W % 4 != 0:
+        Wp = (W + 3) // 4 * 4
+        xp, yp = copy_cols(x.view(-1, W), Wp).view(N, C, H, Wp), copy_cols(y.view(-1, W), Wp).view(N, C, H, Wp)
+        both = torch.empty((2 * N, K * K, H, Wp), dtype=torch.float32, device=x.device)
+        corr_neigh_bidir(xp, yp, K, out=both)
+        res = copy_cols(both.view(-1, Wp), W).view(2 * N, K * K, H, W)
+        if out is not None:
+            out.copy_(res)
+            res = out
+        return res[:N], res[N:]
+    if out is None:
+        out = torch.empty((2 * N, K * K, H, W), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (2 * N, K * K, H, W) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("corr_neigh_bidir: out must be a contiguous float32 (2N,49,H,W) tensor")
+    e0 = Profiler.begin(x)
+    _call("rfx_corr_neigh_bidir_f32", _one_device(x, y, out), _p(x), _p(y), _p(out[:N]), _p(out[N:]), N, C, H, W, K)
+    if e0 is not None:
+        Profiler.active().corr_bidir.append(((2 * C + 2 * K * K) * 4.0 * N * H * W, 2 * (2 * C + K * K) * 4.0 * N * H * W, e0,
+                                             Profiler.end(e0)))
+    return out[:N], out[N:]
 
 
 def warp_grid(Hm, h, w):
@@ -606,3 +643,104 @@ def ransac_h4_batched(match1, match2, n, samples, tol):
     _call("rfx_ransac_h4_batched", _one_device(match1, match2, n, samples), _p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
                                          _p(res), _p(ws), B)
     return bestH, inl.bool(), res
+
+
+# ------------------------------------------------------------------------------------------------ multi-homography rounds (multih.hip)
+
+def draw_samples(n, nb_iter, seed, stream_id):
+    """RANSAC index draw on the device (utils/outil.py:120 on a GPU run): n (B,) int32 device match counts ->
+    samples (B, nb_iter, 4) int64, Philox4x32-10 keyed by (seed, stream_id, pair, hypothesis) modulo n[b].  No host sync."""
+    n = _dev(n, "n", torch.int32)
+    B = n.shape[0]
+    smp = torch.empty((B, int(nb_iter), 4), dtype=torch.int64, device=n.device)
+    _call("rfx_draw_samples_i64", n.device, _p(n), _p(smp), int(nb_iter), B, int(seed) & (2 ** 64 - 1), int(stream_id) & (2 ** 64 - 1))
+    return smp
+
+
+def filter_matches(idx1, idx2, count, active, mask, bg, rt, ct, xa, ya, xb, yb, want_kept=False):
+    """The cached matches of the active pairs that lie outside the explained region, compacted in order (one launch):
+    -> match1, match2 (a,cap,3) float32, n (a,) int32[, kept (a,cap) int32].  ``active``: (a,) int32 device tensor or None."""
+    idx1, idx2 = _dev(idx1, "idx1", torch.int64), _dev(idx2, "idx2", torch.int64)
+    count = _dev(count, "count", torch.int32)
+    mask = _dev(mask, "mask")
+    bg = _dev(bg, "bg") if bg is not None else None
+    act = _dev(active, "active", torch.int32) if active is not None else None
+    B, cap = idx1.shape
+    a = B if act is None else act.shape[0]
+    h, w = mask.shape[1], mask.shape[2]
+    dev = idx1.device
+    m1 = torch.empty((a, cap, 3), dtype=torch.float32, device=dev)
+    m2 = torch.empty((a, cap, 3), dtype=torch.float32, device=dev)
+    n = torch.empty(a, dtype=torch.int32, device=dev)
+    kept = torch.empty((a, cap), dtype=torch.int32, device=dev) if want_kept else None
+    _call("rfx_filter_matches_f32", _one_device(idx1, idx2, count, act, mask, bg, xa, ya, xb, yb), _p(idx1), _p(idx2), _p(count), cap,
+          _p(act), a, _p(mask), _p(bg), h, w, int(rt), int(ct), _p(_dev(xa, "xa")), _p(_dev(ya, "ya")), _p(_dev(xb, "xb")),
+          _p(_dev(yb, "yb")), _p(m1), _p(m2), _p(n), _p(kept))
+    return (m1, m2, n, kept) if want_kept else (m1, m2, n)
+
+
+class MultiHRecords:
+    """The fixed-size per-pair result records of the multi-homography drivers (what
+    evaluation/evalHpatch/evaluation.py:254-260 saves per pair), one float32 row per pair so that ONE all_gather moves them:
+    [0] nbH | [1] status (0 ok, 1 no homography) | H (max_h,9) | flowDown8 (max_h,2,h8,w8) | matchDown8 (max_h,2,h8,w8)
+    [| flowD2 (max_h,2,hd2,wd2): the half-resolution /8 flow of the KITTI driver].  Filled on the device by multih_accept."""
+
+    def __init__(self, B, h8, w8, device, max_h=11, hd2=0, wd2=0):
+        self.B, self.h8, self.w8, self.hd2, self.wd2, self.max_h = B, h8, w8, hd2, wd2, max_h
+        r4 = lambda x: (x + 3) // 4 * 4
+        self.off_H = 4
+        self.off_flow = self.off_H + r4(9 * max_h)
+        self.off_match = self.off_flow + 2 * h8 * w8 * max_h
+        self.off_d2 = self.off_match + 2 * h8 * w8 * max_h
+        self.width = r4(self.off_d2 + 2 * hd2 * wd2 * max_h)
+        self.rec = torch.zeros((B, self.width), dtype=torch.float32, device=device)
+        self.rec[:, 1] = 1.0
+
+    def views(self):
+        """(nbH (B,), status (B,), H (B,max_h,3,3), flowDown8 (B,max_h,2,h8,w8), matchDown8 (B,max_h,2,h8,w8), flowD2 or None)."""
+        r, B, m = self.rec, self.B, self.max_h
+        n8 = 2 * self.h8 * self.w8
+        d2 = r[:, self.off_d2:self.off_d2 + 2 * self.hd2 * self.wd2 * m].view(B, m, 2, self.hd2, self.wd2) if self.hd2 else None
+        return (r[:, 0], r[:, 1], r[:, self.off_H:self.off_H + 9 * m].view(B, m, 3, 3),
+                r[:, self.off_flow:self.off_flow + n8 * m].view(B, m, 2, self.h8, self.w8),
+                r[:, self.off_match:self.off_match + n8 * m].view(B, m, 2, self.h8, self.w8), d2)
+
+
+def multih_accept(match, mask, bg, active, ransac_result, n_match, nbH, th, mode, bestH=None, flowDown8=None, match12Down8=None,
+                  match21Down8=None, flowD2=None, records=None):
+    """Accept rule + mask update + record store of one round (rfx_multih_accept_f32) -> (accept (a,) int32, gain (a,) f32),
+    both on the device; ``mask`` (B,h,w) and ``nbH`` (B,) int32 are updated in place."""
+    match, mask = _dev(match, "match"), _dev(mask, "mask")
+    if not mask.is_contiguous():
+        raise ValueError("mask must be contiguous (updated in place)")
+    bg = _dev(bg, "bg") if bg is not None else None
+    act = _dev(active, "active", torch.int32) if active is not None else None
+    res, n_match, nbH = _dev(ransac_result, "ransac result", torch.int32), _dev(n_match, "n", torch.int32), _dev(nbH, "nbH", torch.int32)
+    a = match.shape[0]
+    h, w = mask.shape[1], mask.shape[2]
+    if match.numel() != a * h * w:
+        raise ValueError("match must be (a,h,w) / (a,1,h,w) at the mask's resolution")
+    dev = match.device
+    accept = torch.empty(a, dtype=torch.int32, device=dev)
+    gain = torch.empty(a, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws = torch.empty(lib.rfx_multih_accept_ws_bytes(a), dtype=torch.uint8, device=dev)
+    h8 = w8 = hd2 = wd2 = 0
+    f8 = m12 = m21 = fd2 = None
+    if flowDown8 is not None:
+        f8 = _dev(flowDown8, "flowDown8")
+        h8, w8 = f8.shape[2], f8.shape[3]
+        m12, m21 = _dev(match12Down8, "match12Down8"), _dev(match21Down8, "match21Down8")
+    if flowD2 is not None:
+        fd2 = _dev(flowD2, "flowD2")
+        hd2, wd2 = fd2.shape[2], fd2.shape[3]
+    R = records
+    if R is not None and (R.h8, R.w8, R.hd2, R.wd2) != (h8, w8, hd2, wd2):
+        raise ValueError("record layout does not match the round's tensors")
+    bh = _dev(bestH, "bestH") if bestH is not None else None
+    _call("rfx_multih_accept_f32", _one_device(match, mask, bg, act, res, n_match, nbH, bh, f8, m12, m21, fd2), _p(match), _p(mask), _p(bg),
+          _p(act), a, h, w, _p(res), _p(n_match), _p(nbH), float(th), int(mode), _p(accept), _p(gain), _p(ws), _p(bh), _p(f8), _p(m12),
+          _p(m21), h8, w8, _p(fd2), hd2, wd2, _p(R.rec) if R is not None else ctypes.c_void_p(0), R.width if R is not None else 0,
+          R.max_h if R is not None else 0, R.off_H if R is not None else 0, R.off_flow if R is not None else 0,
+          R.off_match if R is not None else 0, R.off_d2 if R is not None else 0)
+    return accept, gain

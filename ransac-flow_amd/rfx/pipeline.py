@@ -56,7 +56,15 @@ def cell_coords(n_rows, n_cols, device):
 
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
-                 device="cuda", kernelSize=7):
+                 device="cuda", kernelSize=7, draw="device", seed=0):
+        """``draw``: where the RANSAC index draw of utils/outil.py:120 happens when no explicit ``samples`` / ``sample_fn`` is
+        given.  "device" (default; the reference draws on ``match1.device``, i.e. on the GPU in a GPU run): Philox4x32-10 on
+        the device keyed by (``seed``, call counter, pair, hypothesis) -- no host sync for nbMatch, no CPU draw + upload.
+        "host": ``torch.randint`` on the CPU generator per pair in pair order = what a CPU run of the reference draws
+        (the parity mode: the oracle can replay it from ``torch.manual_seed``)."""
+        if draw not in ("device", "host"):
+            raise ValueError("draw must be 'device' or 'host'")
+        self.draw, self.seed, self._draw_calls = draw, int(seed), 0
         self.dev = torch.device(device)
         self.trunk = ResNet50Trunk(sds["trunk"], self.dev)
         self.feat = FeatureExtractorNet(sds["feat"], self.dev) if "feat" in sds else None
@@ -67,6 +75,20 @@ class AlignPipeline:
         self.scaleList = scale_list(nbScale, scaleR)
         self.mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
         self.std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+
+    def reseed(self, seed):
+        """Restart the device-side index-draw stream (same seed + same call sequence -> same draws)."""
+        self.seed, self._draw_calls = int(seed), 0
+
+    def _pair_draw(self, n, it):
+        """Index draw of the per-pair drivers: the pipeline's draw mode for one pair with n matches."""
+        if self.draw == "device":
+            return self._device_draw(torch.tensor([n], dtype=torch.int32, device=self.dev))[0]
+        return torch.randint(n, (it, 4))
+
+    def _device_draw(self, n_dev):
+        self._draw_calls += 1
+        return ops.draw_samples(n_dev, self.nbIter, self.seed, self._draw_calls)
 
     # ---------------------------------------------------------------- host pre-processing
     def _resize(self, I, size):
@@ -131,28 +153,51 @@ class AlignPipeline:
             return self._features_graphed(prep)
         return self._features_eager(prep)
 
+    MAX_GRAPHS = 4      # captured shapes kept (LRU): each pins a private memory pool + static input / output buffers
+
     def _features_graphed(self, prep):
+        """HIP-graph replay of the trunk pass.  A shape is captured at its SECOND sighting (a stream of variable-size pairs
+        never pays warm-up + capture for shapes it sees once) and at most MAX_GRAPHS captures are kept (LRU; an evicted
+        entry releases its graph, pool and static buffers).  Warm-up, capture and replay run under the pipeline's own
+        device: ``torch.cuda.graph`` captures the CURRENT device's stream, while the kernels launch on self.dev's."""
+        import collections
         key = (tuple(tuple(x.shape) for x in prep["src"]), tuple(prep["tgt"].shape))
-        cache = self.__dict__.setdefault("_graphs", {})
+        cache = self.__dict__.setdefault("_graphs", collections.OrderedDict())
+        seen = self.__dict__.setdefault("_graph_seen", collections.OrderedDict())
         ent = cache.get(key)
         if ent is None:
-            self._features_eager(prep)                      # warm-up: lazily built state (packed weights ...) must exist
-            torch.cuda.synchronize(self.dev)
-            static = dict(src=[torch.empty_like(x) for x in prep["src"]], tgt=torch.empty_like(prep["tgt"]), B=prep["B"])
+            if key not in seen:
+                seen[key] = True
+                while len(seen) > 64:
+                    seen.popitem(last=False)
+                return self._features_eager(prep)
+            with torch.cuda.device(self.dev):
+                self._features_eager(prep)                  # warm-up: lazily built state (packed weights ...) must exist
+                torch.cuda.synchronize(self.dev)
+                static = dict(src=[x.clone() for x in prep["src"]], tgt=prep["tgt"].clone(), B=prep["B"])
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._features_eager(static)
+                # an empty capture (kernels launched outside the captured stream) would replay stale features for ever:
+                # check once that a replay really rewrites the outputs
+                out["featA"].zero_()
+                g.replay()
+                torch.cuda.synchronize(self.dev)
+                if not bool(out["featA"].abs().sum() > 0):
+                    raise RuntimeError("HIP-graph capture of the trunk pass is empty (kernels did not go to the capture stream)")
+            ent = cache[key] = (g, static, out)
+            while len(cache) > self.MAX_GRAPHS:
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(key)
+        g, static, out = ent
+        with torch.cuda.device(self.dev):
             for d, x in zip(static["src"], prep["src"]):
                 d.copy_(x)
             static["tgt"].copy_(prep["tgt"])
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._features_eager(static)
-            ent = cache[key] = (g, static, out)
-        g, static, out = ent
-        for d, x in zip(static["src"], prep["src"]):
-            d.copy_(x)
-        static["tgt"].copy_(prep["tgt"])
-        g.replay()
-        res = dict(out)
-        res["featA"], res["featB"] = out["featA"].clone(), out["featB"].clone()   # the graph's own buffers are reused by the next replay
+            g.replay()
+            res = dict(out)
+            res["featA"], res["featB"] = out["featA"].clone(), out["featB"].clone()   # the graph's own buffers are reused by the next replay
         return res
 
     def _features_eager(self, prep):
@@ -178,6 +223,8 @@ class AlignPipeline:
         # overlapping launches distort the per-kernel event timing bench.py's roofline is computed from).
         env = os.environ.get("RFX_TRUNK_STREAMS")
         nstream = max(1, int(env)) if env else (len(prep["src"]) if B <= 4 else 1)
+        if ops.Profiler.active() is not None:
+            nstream = 1          # per-launch event timing: overlapping streams would charge one kernel with another's time
         main = torch.cuda.current_stream(self.dev)
         if nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
             self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstream)]
@@ -214,38 +261,39 @@ class AlignPipeline:
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
     def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None):
-        """Per pair: mutual NN -> matches -> RANSAC.  ``samples``: optional list of (nbIter,4) int64 CPU tensors
-        (explicit index draw), or ``sample_fn(b, nMatch, nbIter)`` -> such a tensor; default = torch.randint on the
-        CPU generator per pair, in pair order, which is what utils/outil.py:120 draws on a CPU run.  Returns a list
-        of per-pair dicts (device tensors)."""
+        """Per pair: mutual NN -> matches -> RANSAC.  Index draw (utils/outil.py:120): ``samples`` = list of (nbIter,4) int64
+        CPU tensors, or ``sample_fn(b, nMatch, nbIter)`` -> such a tensor; otherwise the pipeline's ``draw`` mode -- "device":
+        Philox on the device from the device-side match counts, ONE host sync per batch (the result records); "host":
+        torch.randint on the CPU generator per pair, in pair order (what a CPU run of the reference draws), which needs the
+        match counts on the host first (a second sync).  Returns a list of per-pair dicts (device tensors)."""
         feats = feats or self.features(prep)
         B = prep["B"]
         lib_out = []
-        # phase 1: ONE batched mutual-NN launch chain for all pairs, one sync for the counts (the index draw of
-        # utils/outil.py:120 needs nbMatch on the host)
+        # ONE batched mutual-NN launch chain for all pairs
         idx1, idx2, cnt = self._mutual_batched(feats, B, maskB)
-        counts = cnt.cpu().tolist()  # <- sync #1
-        # phase 2: index draw on the host (per pair, in pair order), then ONE batched launch chain for the match
-        # lists and RANSAC of every pair
-        draws = []
-        for b in range(B):
-            n = counts[b]
-            if n >= 4:
-                draws.append(samples[b] if samples is not None else
-                             (sample_fn(b, n, self.nbIter) if sample_fn is not None else torch.randint(n, (self.nbIter, 4))))
-            else:
-                draws.append(torch.zeros((self.nbIter, 4), dtype=torch.int64))
-        if len({tuple(d.shape) for d in draws}) != 1:       # explicit draws of different lengths: one launch chain per pair
-            return self._coarse_per_pair(feats, idx1, idx2, counts, draws)
-        smp = torch.stack(draws).to(self.dev, non_blocking=True)
+        if samples is None and sample_fn is None and self.draw == "device":
+            smp = self._device_draw(cnt)
+            counts, draws = None, smp
+        else:
+            counts = cnt.cpu().tolist()  # <- sync: the host-side index draw needs nbMatch
+            draws = []
+            for b in range(B):
+                n = counts[b]
+                if n >= 4:
+                    draws.append(samples[b] if samples is not None else
+                                 (sample_fn(b, n, self.nbIter) if sample_fn is not None else torch.randint(n, (self.nbIter, 4))))
+                else:
+                    draws.append(torch.zeros((self.nbIter, 4), dtype=torch.int64))
+            if len({tuple(d.shape) for d in draws}) != 1:       # explicit draws of different lengths: one launch chain per pair
+                return self._coarse_per_pair(feats, idx1, idx2, counts, draws)
+            smp = torch.stack(draws).to(self.dev, non_blocking=True)
         M1, M2 = ops.gather_matches(idx1, idx2, cnt, feats["HA"], feats["WA"], feats["Ht"], feats["Wt"])
         bestH, inl, resd = ops.ransac_h4_batched(M1, M2, cnt, smp, self.tol)
-        st = resd.cpu().tolist()  # <- sync #2
+        host = torch.cat((cnt[:, None], resd), dim=1).cpu().tolist()  # <- sync: result records (+ the match counts)
         for b in range(B):
-            n = counts[b]
+            n, status, c, widx, nuniq = host[b]
             res = dict(index1=idx1[b, :n], index2=idx2[b, :n], H=None, inlier=None, samples=None, n=n)
             if n >= 4:
-                status, c, widx, nuniq = st[b]
                 res.update(match1=M1[b, :n], match2=M2[b, :n], samples=draws[b], status=status, count=c, winner=widx,
                            nUnique=nuniq)
                 if status == 0:
@@ -303,13 +351,25 @@ class AlignPipeline:
         return dict(flowCoarse=flowCoarse, img1_coarse=img1_coarse, feat1=feat1, feat2=feat2, corr12=corr12,
                     flowDown=flowDown, flow12=flow12, img1_fine=img1_fine)
 
+    @staticmethod
+    def _corr_both(featt, feats):
+        """(2B,49,h,w) = corr(featt, feats) | corr(feats, featt) (evaluation/evalHpatch/evaluation.py:29,34).  RFX_CORR_BIDIR=0:
+        the two directions as one launch over a doubled batch (each re-reads both feature maps), bit-identical."""
+        if os.environ.get("RFX_CORR_BIDIR", "1") == "0":
+            return ops.corr_neigh(torch.cat((featt, feats), dim=0), torch.cat((feats, featt), dim=0))
+        B, _, h, w = featt.shape
+        out = torch.empty((2 * B, 49, h, w), dtype=torch.float32, device=featt.device)
+        ops.corr_neigh_bidir(featt, feats, out=out)
+        return out
+
     def pred_flow_mask(self, IsTensor, featt, flowCoarse):
         """evaluation/evalHpatch/evaluation.py:23-55 (PredFlowMask) for a batch."""
         IsSample = ops.grid_sample(IsTensor, flowCoarse)
         feats = ops.l2norm(self.feat(IsSample))
         B = IsTensor.shape[0]
-        # both correlation directions in ONE launch, both matchability passes in one batch
-        c = ops.corr_neigh(torch.cat((featt, feats), dim=0), torch.cat((feats, featt), dim=0))
+        # both correlation directions from ONE pass over the features (the reverse volume is the forward one at mirrored
+        # taps / shifted pixels: ops.corr_neigh_bidir), both matchability passes in one batch
+        c = self._corr_both(featt, feats)
         corr12 = c[:B]
         flowDown8 = self.flow(corr12, False)
         md = self.match(c, False)
@@ -329,7 +389,7 @@ class AlignPipeline:
         B = IsSample.shape[0]
         f = ops.l2norm(self.feat(torch.cat((IsSample, ItSample), dim=0)))
         feats, featt = f[:B], f[B:]
-        c = ops.corr_neigh(torch.cat((featt, feats), dim=0), torch.cat((feats, featt), dim=0))   # corr12 | corr21, one launch
+        c = self._corr_both(featt, feats)                                                        # corr12 | corr21, one launch
         corr12 = c[:B]
         flowDown8 = self.flow(corr12, False)
         md = self.match(c, False)
@@ -362,7 +422,7 @@ class AlignPipeline:
         bg = torch.ones((h, w), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
         Mask = torch.zeros((h, w), dtype=torch.float32, device=dev)
         out = dict(H=[], flowDown8=[], matchDown8=[])
-        draw = sample_fn or (lambda n, it: torch.randint(n, (it, 4)))
+        draw = sample_fn or self._pair_draw
         nb = 0
         while nb <= maxCoarse:
             fg = ((Mask + (1 - bg)) > 0.5).float()
@@ -392,65 +452,81 @@ class AlignPipeline:
         out["mask"] = Mask
         return out
 
-    def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None):
-        """multi_h() for every pair of the batch in lock-step: iteration k computes the k-th homography of all pairs
-        that are still active -- ONE batched launch chain for the match filtering, RANSAC (rfx_ransac_h4_batched), the
-        warp and PredFlowMask (FeatureExtractor / correlation / heads over all active pairs) and two host syncs per
-        iteration (match counts for the index draws; acceptance statistics), instead of two syncs and batch-1 kernels
-        per pair and homography.  Semantics per pair = evaluation/evalHpatch/evaluation.py:184-243.
-        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor (default: torch.randint, pairs in ascending order).
-        Returns a list of dicts like multi_h()."""
+    def _round_draws(self, active, n_dev, sample_fn):
+        """Index draws of one lock-step round -> (a,nbIter,4) int64 device tensor.  Device mode: Philox from the device-side
+        counts, no sync.  Host mode / explicit sample_fn: one sync for the counts, CPU draws for the active pairs in
+        ascending order, one upload."""
+        if sample_fn is None and self.draw == "device":
+            return self._device_draw(n_dev)
+        n_host = n_dev.cpu().tolist()                                                   # sync: sizes of the index draws
+        draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
+        return torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
+                            for b, n in zip(active, n_host)]).to(self.dev, non_blocking=True)
+
+    def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None, records=None,
+                        want_lists=True, trace=None):
+        """multi_h() for every pair of the batch in lock-step: round k computes the k-th homography of all pairs that are
+        still active.  A round is device work end to end -- rfx_filter_matches_f32 (mask -> keep map -> ordered compaction of
+        the cached matches), the index draw (device mode), rfx_ransac_h4_batched, the warp, PredFlowMask over the active
+        pairs, rfx_multih_accept_f32 (gain, accept rule, mask update, result-record store) -- and ONE host readback: the
+        accept flags, from which the host builds the next round's active list.  Semantics per pair =
+        evaluation/evalHpatch/evaluation.py:184-243.
+        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; costs a second sync per round).
+        ``records``: an ops.MultiHRecords to fill (the fixed-size rows one all_gather moves); ``want_lists=False`` skips the
+        per-pair Python lists (throughput drivers that only ship the records).  ``trace``: a list that receives one dict per
+        round with the round's state (mask before the round, counts, H, PredFlowMask outputs, accept flags) -- the parity
+        sweeps replay every round on the oracle from it.
+        Returns a list of dicts like multi_h() (H / flowDown8 / matchDown8 lists are views of per-round tensors)."""
         feats = feats or self.features(prep)
         dev = self.dev
         B = prep["B"]
         h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
         rt, ct = feats["rt"], feats["ct"]
         idx1, idx2, cnt = self._mutual_batched(feats, B)
-        cap = idx1.shape[1]
-        slot_ok = torch.arange(cap, device=dev)[None, :] < cnt[:, None]                  # (B,cap)
-        cell2 = torch.where(slot_ok, idx2, torch.zeros_like(idx2))                      # target cell of every match slot
         featt = ops.l2norm(self.feat(prep["ItTensor"]))
-        bg = torch.ones((B, h, w), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        bg = None if It_bg is None else It_bg.to(dev).float().contiguous()
         Mask = torch.zeros((B, h, w), dtype=torch.float32, device=dev)
+        nbH = torch.zeros(B, dtype=torch.int32, device=dev)
         outs = [dict(H=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
         nb = [0] * B
-        draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
         eye = torch.eye(3, device=dev)
         active = list(range(B))
         while active:
-            A = torch.tensor(active, device=dev)
-            fg = ((Mask[A] + (1 - bg[A])) > 0.5).float()                                # (a,h,w)
-            keep = ops.resize_bilinear((1 - fg)[:, None], (rt, ct), align_corners=False)[:, 0] > 0.5
-            valid = keep.flatten(1).gather(1, cell2[A]) & slot_ok[A]                    # matches outside the explained region
-            n_dev = valid.sum(1).to(torch.int32)
-            n_host = n_dev.cpu().tolist()                                               # sync: sizes of the index draws
-            order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)         # surviving matches first, in order
-            M1, M2 = ops.gather_matches(idx1[A].gather(1, order), idx2[A].gather(1, order), n_dev, feats["HA"], feats["WA"],
-                                        feats["Ht"], feats["Wt"])
-            smp = torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
-                               for b, n in zip(active, n_host)]).to(dev, non_blocking=True)
+            full = len(active) == B
+            A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
+            M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
+                                               feats["Wt"])
+            smp = self._round_draws(active, n_dev, sample_fn)
             bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
-            ok = (res[:, 0] == 0)
-            Hs = torch.where(ok[:, None, None], bestH, eye)                             # failed pairs: any finite warp
+            Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flowCoarse = ops.warp_grid(Hs, h, w)
-            pm = self.pred_flow_mask(prep["IsTensor"][A], featt[A], flowCoarse)
-            new = pm["match"][:, 0] * (1 - fg)
-            stat = torch.stack((new.mean(dim=(1, 2)), res[:, 0].float()), dim=1).cpu().tolist()   # sync: acceptance statistics
+            Is = prep["IsTensor"] if full else prep["IsTensor"].index_select(0, A)
+            pm = self.pred_flow_mask(Is, featt if full else featt.index_select(0, A), flowCoarse)
+            mask_before = (Mask if full else Mask.index_select(0, A)).clone() if trace is not None else None
+            accept, gain = ops.multih_accept(pm["match"], Mask, bg, A, res, n_dev, nbH, maskRegionTh, 0, bestH=bestH,
+                                             flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
+                                             match21Down8=pm["match21Down8"], records=records)
+            if trace is not None:
+                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, pm=pm, match=pm["match"][:, 0],
+                                  accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
+            md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
+            acc = accept.cpu().tolist()                                                 # the round's ONE sync
             nxt = []
             for k, b in enumerate(active):
-                gain, status = stat[k]
-                if n_host[k] < 4 or status != 0 or not (gain > maskRegionTh or nb[b] == 0):
+                if not acc[k]:
                     continue
-                outs[b]["H"].append(bestH[k])
-                outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
-                outs[b]["matchDown8"].append(torch.cat((pm["match12Down8"][k:k + 1], pm["match21Down8"][k:k + 1]), dim=1))
+                if want_lists:
+                    outs[b]["H"].append(bestH[k])
+                    outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
+                    outs[b]["matchDown8"].append(md2[k:k + 1])
                 nb[b] += 1
-                Mask[b] = ((Mask[b] + new[k]) >= 1.0).float()
                 if nb[b] <= maxCoarse:
                     nxt.append(b)
             active = nxt
         for b in range(B):
             outs[b]["mask"] = Mask[b]
+            outs[b]["nbH"] = nb[b]
+            outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
         return outs
 
     # ---------------------------------------------------------------- KITTI two-resolution driver (SURVEY 8f1, BASELINE config 5)
@@ -493,7 +569,7 @@ class AlignPipeline:
         bg = torch.ones((h_org, w_org), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
         Mask = torch.zeros((h_org, w_org), dtype=torch.float32, device=dev)
         out = dict(H=[], flowD2=[], flowDown8=[], matchDown8=[])
-        draw = sample_fn or (lambda n, it: torch.randint(n, (it, 4)))
+        draw = sample_fn or self._pair_draw
         nb = 0
         while True:
             fg = ((Mask + (1 - bg)) > 0.5).float()
@@ -533,16 +609,43 @@ class AlignPipeline:
         out["mask"] = Mask
         return out
 
+    def kitti_fine_round(self, Hs, tensor_s, tensor_d2, tensor_resize, org_hw, cc_th=0.01, remove_small_cc=None):
+        """The fine part of one round of the KITTI driver (evaluation/evalKITTI/evaluation.py:279-321) for a batch of
+        homographies Hs (a,3,3): homography grids at the half and the full fine resolution -> source warped to the half
+        resolution -> PredFlowMask there -> its /8 flow composed with the full-resolution homography grid -> source warped by
+        it -> PredFlowMask whose outputs live at the ORIGINAL target resolution ``org_hw`` -> small-component filter
+        (device: rfx_remove_small_cc_f32; or an injected host filter ``remove_small_cc(match ndarray, 0.99, cc_th)``).
+        Returns (flow_d2 (a,2,hd2,wd2), PredFlowMask dict of the full-resolution pass, match (a,h_org,w_org) after the filter)."""
+        h_d2, w_d2 = tensor_d2.shape[2], tensor_d2.shape[3]
+        h_r, w_r = tensor_resize.shape[2], tensor_resize.shape[3]
+        hom_d2 = ops.warp_grid(Hs, h_d2, w_d2)
+        hom_resize = ops.warp_grid(Hs, h_r, w_r)
+        Is_d2 = ops.grid_sample(tensor_s, hom_d2)
+        flow_d2 = self.pred_flow_mask_kitti(Is_d2, tensor_d2, hom_d2)["flowDown8"]
+        flowCoarse, _, _ = ops.compose_flow(flow_d2, hom_resize, clamp=True)
+        IsSample = ops.grid_sample(tensor_s, flowCoarse)
+        pm = self.pred_flow_mask_kitti(IsSample, tensor_resize, flowCoarse, out_hw=org_hw)
+        match = pm["match"][:, 0]
+        if cc_th > 0:                                                                   # :321
+            if remove_small_cc is None:
+                match = ops.remove_small_cc(match, cc_th, 0.99)
+            else:                                                                       # an injected host filter: one round trip
+                mh = match.cpu().numpy()
+                match = torch.from_numpy(np.stack([remove_small_cc(mh[k], 0.99, cc_th) for k in range(mh.shape[0])])).to(self.dev)
+        return flow_d2, pm, match
+
     def multi_h_kitti_batched(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, sample_fn=None,
-                              remove_small_cc=None):
+                              remove_small_cc=None, records=None, want_lists=True, trace=None):
         """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
         computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
-        the match filtering, RANSAC (rfx_ransac_h4_batched), the two warps and both PredFlowMask passes over the active
-        pairs, the small-component filter on the device, and two host syncs per
-        round (match counts; acceptance statistics) instead of two per pair and homography.  Per pair the arithmetic and the
-        accept / stop rule are multi_h_kitti()'s (evaluation/evalKITTI/evaluation.py:257-336); batch-1 fine passes become
-        batch-a ones, which is where the time goes (the 3x3 kernels run at 0.59 of the matrix peak at batch 1, 0.8 at batch 8).
-        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor (default: torch.randint, active pairs in ascending order).
+        the match filtering (rfx_filter_matches_f32), the index draw (device mode), RANSAC (rfx_ransac_h4_batched), the two
+        warps and both PredFlowMask passes over the active pairs, the small-component filter on the device and the accept
+        rule / mask update / record store (rfx_multih_accept_f32, mode 1), with ONE host readback per round (the accept
+        flags).  Per pair the arithmetic and the accept / stop rule are multi_h_kitti()'s
+        (evaluation/evalKITTI/evaluation.py:257-336); batch-1 fine passes become batch-a ones, which is where the time goes
+        (the 3x3 kernels run at 0.59 of the matrix peak at batch 1, 0.8 at batch 8).
+        ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; a second sync per round).
+        ``records``: ops.MultiHRecords built with the half-resolution /8 size (hd2, wd2); ``trace``: as in multi_h_batched.
         Returns a list of dicts like multi_h_kitti()."""
         dev = self.dev
         B, h_org, w_org = tgt_u8.shape[0], tgt_u8.shape[1], tgt_u8.shape[2]
@@ -555,62 +658,50 @@ class AlignPipeline:
         tensor_d2, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_d2, h_d2))
         rt, ct = feats["rt"], feats["ct"]
         idx1, idx2, cnt = self._mutual_batched(feats, B)
-        cap = idx1.shape[1]
-        slot_ok = torch.arange(cap, device=dev)[None, :] < cnt[:, None]
-        cell2 = torch.where(slot_ok, idx2, torch.zeros_like(idx2))
-        bg = torch.ones((B, h_org, w_org), dtype=torch.float32, device=dev) if It_bg is None else It_bg.to(dev).float()
+        bg = None if It_bg is None else It_bg.to(dev).float().contiguous()
         Mask = torch.zeros((B, h_org, w_org), dtype=torch.float32, device=dev)
+        nbH = torch.zeros(B, dtype=torch.int32, device=dev)
         outs = [dict(H=[], flowD2=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
         nb = [0] * B
-        draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
         eye = torch.eye(3, device=dev)
         active = list(range(B))
         while active:
-            A = torch.tensor(active, device=dev)
-            fg = ((Mask[A] + (1 - bg[A])) > 0.5).float()
-            keep = ops.resize_bilinear((1 - fg)[:, None], (rt, ct), align_corners=False)[:, 0] > 0.5
-            valid = keep.flatten(1).gather(1, cell2[A]) & slot_ok[A]
-            n_dev = valid.sum(1).to(torch.int32)
-            n_host = n_dev.cpu().tolist()                                               # sync: sizes of the index draws
-            order = torch.argsort((~valid).to(torch.uint8), dim=1, stable=True)
-            M1, M2 = ops.gather_matches(idx1[A].gather(1, order), idx2[A].gather(1, order), n_dev, feats["HA"], feats["WA"],
-                                        feats["Ht"], feats["Wt"])
-            smp = torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
-                               for b, n in zip(active, n_host)]).to(dev, non_blocking=True)
+            full = len(active) == B
+            A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
+            sel = (lambda t: t) if full else (lambda t: t.index_select(0, A))
+            M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
+                                               feats["Wt"])
+            smp = self._round_draws(active, n_dev, sample_fn)
             bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
-            ok = (res[:, 0] == 0)
-            Hs = torch.where(ok[:, None, None], bestH, eye)                             # failed pairs: any finite warp
-            hom_d2 = ops.warp_grid(Hs, h_d2, w_d2)
-            hom_resize = ops.warp_grid(Hs, h_r, w_r)
-            Is_d2 = ops.grid_sample(tensor_s[A], hom_d2)
-            flow_d2 = self.pred_flow_mask_kitti(Is_d2, tensor_d2[A], hom_d2)["flowDown8"]
-            flowCoarse, _, _ = ops.compose_flow(flow_d2, hom_resize, clamp=True)
-            IsSample = ops.grid_sample(tensor_s[A], flowCoarse)
-            pm = self.pred_flow_mask_kitti(IsSample, tensor_resize[A], flowCoarse, out_hw=(h_org, w_org))
-            match = pm["match"][:, 0]
-            if cc_th > 0:                                                               # :321 -- on the device (rfx_remove_small_cc_f32)
-                if remove_small_cc is None:
-                    match = ops.remove_small_cc(match, cc_th, 0.99)
-                else:                                                                   # an injected host filter: one round trip
-                    mh = match.cpu().numpy()
-                    match = torch.from_numpy(np.stack([remove_small_cc(mh[k], 0.99, cc_th) for k in range(len(active))])).to(dev)
-            gainv = ((match > 0.9999).float() * (1 - fg)).mean(dim=(1, 2))
-            stat = torch.stack((gainv, res[:, 0].float()), dim=1).cpu().tolist()        # sync: acceptance statistics
+            Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
+            flow_d2, pm, match = self.kitti_fine_round(Hs, sel(tensor_s), sel(tensor_d2), sel(tensor_resize), (h_org, w_org),
+                                                       cc_th, remove_small_cc)
+            mask_before = (Mask if full else Mask.index_select(0, A)).clone() if trace is not None else None
+            accept, gain = ops.multih_accept(match, Mask, bg, A, res, n_dev, nbH, maskRegionTh, 1, bestH=bestH,
+                                             flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
+                                             match21Down8=pm["match21Down8"], flowD2=flow_d2, records=records)
+            if trace is not None:
+                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, pm=pm, match=match,
+                                  flowD2=flow_d2, accept=accept, gain=gain,
+                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
+            md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
+            acc = accept.cpu().tolist()                                                 # the round's ONE sync
             nxt = []
             for k, b in enumerate(active):
-                gain, status = stat[k]
-                if n_host[k] < 4 or status != 0 or not (gain > maskRegionTh or nb[b] == 0):
+                if not acc[k]:
                     continue
-                outs[b]["H"].append(bestH[k])
-                outs[b]["flowD2"].append(flow_d2[k:k + 1])
-                outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
-                outs[b]["matchDown8"].append(torch.cat((pm["match12Down8"][k:k + 1], pm["match21Down8"][k:k + 1]), dim=1))
+                if want_lists:
+                    outs[b]["H"].append(bestH[k])
+                    outs[b]["flowD2"].append(flow_d2[k:k + 1])
+                    outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
+                    outs[b]["matchDown8"].append(md2[k:k + 1])
                 nb[b] += 1
-                Mask[b] = ((Mask[b] + match[k] * (1 - fg[k])) > 0.9999).float()
                 nxt.append(b)
             active = nxt
         for b in range(B):
             outs[b]["mask"] = Mask[b]
+            outs[b]["nbH"] = nb[b]
+            outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
         return outs
 
     # ---------------------------------------------------------------- whole path

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--bidir", type=int, default=0, help="1: images 0..N/2-1 = (a,b), N/2.. = (b,a) [both directions, far "
                     "apart]; 2: (a0,b0),(b0,a0),(a1,b1),.. interleaved [both directions of a pair on neighbouring workgroups]")
+    ap.add_argument("--pairs", action="store_true", help="also time both directions of N pairs: one BIDIR launch vs two launches")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     C, H, W = a.shape
@@ -80,6 +81,34 @@ def main():
                        f64_err_ref=err)
             rows.append(row)
             print(json.dumps(row), flush=True)
+        # both directions of a pair from one pass (ops.corr_neigh_bidir) against two one-direction launches over the same pairs
+        if a.pairs:
+            out2 = torch.empty((2 * N, 49, H, W), device=dev)
+            r12, r21 = ops.corr_neigh(*sets[0]), ops.corr_neigh(sets[0][1], sets[0][0])
+            b12, b21 = ops.corr_neigh_bidir(*sets[0], out=out2)
+            same = bool(torch.equal(b12, r12) and torch.equal(b21, r21))
+            for mode in ("bidir", "two_launches"):
+                evs = []
+                for k in range(a.iters + 3):
+                    x, y = sets[k % a.sets]
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    if mode == "bidir":
+                        ops.corr_neigh_bidir(x, y, out=out2)
+                    else:
+                        ops.corr_neigh(x, y)
+                        ops.corr_neigh(y, x)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs[3:])
+                avg = sum(ts) / len(ts)
+                minb, perdir = (2 * C + 98) * 4.0 * N * H * W, 2 * nbytes
+                row = dict(N=N, pairs=N, mode=mode, avg_us=round(avg, 1), min_us=round(ts[0], 1), bit_identical=same,
+                           frac_min_traffic=round(minb / avg / 1e3 / 8000.0, 4), frac_per_direction=round(perdir / avg / 1e3 / 8000.0, 4))
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+            del out2
         del sets, ref
         torch.cuda.empty_cache()
     if a.out:

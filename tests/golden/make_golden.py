@@ -344,6 +344,54 @@ def gen_coarse_b():
 MULTIH_MATCH_STD = 3.0      # saturating matchability head: the explained-region mask of the multi-H loop grows
 
 
+class _RoundRecorder:
+    """Per-round state of a reference driver loop, observed from outside (nothing in the loop is changed): the mask every
+    ``coarseModel.getCoarse(fgMask)`` call receives, the number of matches every ``outil.RANSAC`` call sees and the H it
+    returns, and the full-resolution matchability the accept test reads (the ``matchFine`` of PredFlowMask for Hpatch; the
+    output of ``remove_small_cc`` for KITTI).  Stored as <tag>_round_fg (rounds,h,w) packed bits, <tag>_round_n,
+    <tag>_round_H, <tag>_round_match: what a teacher-forced test needs to replay round k from the reference's own state."""
+
+    def __init__(self, R, ca):
+        self.fg, self.n, self.H, self.match = [], [], [], []
+        self.outil, self.ca = R["outil"], ca
+        self._ransac, self._get = self.outil.RANSAC, ca.getCoarse
+
+        def ransac(nbIter, match1, match2, *a, **k):
+            self.n.append(len(match1))
+            r = self._ransac(nbIter, match1, match2, *a, **k)
+            self.H.append(np.zeros((3, 3), np.float32) if r[0] is None else np.asarray(r[0], dtype=np.float32))
+            return r
+
+        def get(Mt):
+            self.fg.append(np.asarray(Mt, dtype=np.float32).copy())
+            k = len(self.n)
+            r = self._get(Mt)
+            if len(self.n) == k:              # fewer than 4 matches: RANSAC was not called
+                self.n.append(-1)
+                self.H.append(np.zeros((3, 3), np.float32))
+            return r
+        self.outil.RANSAC, ca.getCoarse = ransac, get
+
+    def wrap_match(self, fn, out_index):
+        """Records element ``out_index`` of fn's result (None: the result itself) as the round's matchability map."""
+        def rec(*a, **k):
+            r = fn(*a, **k)
+            m = r if out_index is None else r[out_index]
+            self.match.append(np.asarray(m, dtype=np.float32).copy())
+            return r
+        return rec
+
+    def close(self):
+        self.outil.RANSAC = self._ransac
+        self.ca.getCoarse = self._get
+
+    def save(self, out, tag, every=1):
+        out["%s_round_fg" % tag] = np.packbits(np.stack(self.fg) > 0.5, axis=-1)
+        out["%s_round_n" % tag] = np.asarray(self.n)
+        out["%s_round_H" % tag] = np.stack(self.H)
+        out["%s_round_match" % tag] = np.stack(self.match[every - 1::every])
+
+
 def gen_multi_h():
     """The reference's multi-homography driver loop itself -- the ``while nbCoarse <= args.maxCoarse`` statement of
     evaluation/evalHpatch/evaluation.py:211-243, compiled out of the script and executed on the variables its module
@@ -360,14 +408,18 @@ def gen_multi_h():
         ca = _ref_coarse_b(nbScale=3, nbIter=300, minSize=240, scaleR=1.2)
         ca.setPair(I1, I2)
         Itw, Ith = ca.It.size
+        rounds = _RoundRecorder(R, ca)
         with torch.no_grad():
             featt = F.normalize(net["netFeatCoarse"](ca.ItTensor))
             ns = dict(args=types.SimpleNamespace(maxCoarse=maxCoarse, maskRegionTh=th), coarseModel=ca, network=net,
                       featt=featt, grid=_grid(Ith, Itw), warper=R["kornia_geometry"].HomographyWarper(Ith, Itw),
                       It_bg=np.ones((Ith, Itw), dtype=np.float32), Mask=np.zeros((Ith, Itw), dtype=np.float32),
-                      Coarse_Flow_Tensor=[], Fine_Flow_Tensor=[], Fine_Mask_Tensor=[], nbCoarse=0, PredFlowMask=pfm)
+                      Coarse_Flow_Tensor=[], Fine_Flow_Tensor=[], Fine_Mask_Tensor=[], nbCoarse=0,
+                      PredFlowMask=rounds.wrap_match(pfm, 1))
             torch.manual_seed(500 + seed)
             loop(ns)
+        rounds.close()
+        rounds.save(out, tag)
         n = ns["nbCoarse"]
         out["%s_cfg" % tag] = np.asarray([seed, maxCoarse, th, 500 + seed])
         out["%s_nb" % tag] = np.asarray(n)
@@ -405,14 +457,17 @@ def gen_kitti_loop():
             w_resize, h_resize, tensor_resize, grid_resize, warper_resize = get_info(It_resize)
             w_d2, h_d2, tensor_d2, grid_d2, warper_d2 = get_info(It_d2)
             ca.setPair(Is, It)
+        rounds = _RoundRecorder(R, ca)
         ns = dict(args=types.SimpleNamespace(cc_th=cc_th, maskRegionTh=th), coarseModel=ca, network=net,
                   It_bg=np.ones((h_org, w_org), dtype=np.float32), Mask=np.zeros((h_org, w_org), dtype=np.float32),
                   warper_d2=warper_d2, warper_resize=warper_resize, tensor_s=tensor_s, tensor_d2=tensor_d2,
                   tensor_resize=tensor_resize, grid_d2=grid_d2, grid_resize=grid_resize, grid_org=grid_org,
                   Homography=[], Org_D2=[], Finetune_D2=[], Org_Mask=[], Finetune_Mask=[], Org=[], Finetune=[], nbCoarse=0,
-                  PredFlowMask=fk["PredFlowMask"], remove_small_cc=fk["remove_small_cc"])
+                  PredFlowMask=fk["PredFlowMask"], remove_small_cc=rounds.wrap_match(fk["remove_small_cc"], None))
         torch.manual_seed(700 + seed)
         loop(ns)
+        rounds.close()
+        rounds.save(out, tag)
         n = ns["nbCoarse"]
         cat = lambda lst: torch.cat(lst, dim=0).numpy().astype(np.float32)
         out["%s_cfg" % tag] = np.asarray([seed, fine, cc_th, th, 700 + seed])

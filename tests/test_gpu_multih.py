@@ -1,0 +1,209 @@
+"""The device kernels that took the host out of the multi-homography rounds (csrc/multih.hip), the two-direction
+correlation (csrc/corr.hip, BIDIR) and the HIP-graph trunk path, each against an independent formulation: the ATen glue
+they replaced (evaluation/evalHpatch/coarseAlignFeatMatch.py:156-170, evaluation/evalHpatch/evaluation.py:211-243 as the
+per-pair drivers still spell it), the numpy Philox restatement (tests/philox_ref.py, pinned on the published known-answer
+vectors by tests/test_philox_cpu.py), and two one-direction correlation launches.  ``-m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import philox_ref
+from rfx import ops, weights, synth
+from rfx.pipeline import AlignPipeline, cell_coords
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_index_draw_is_philox_modulo_the_device_counts(dev):
+    n = torch.tensor([1200, 4, 0, 7, 8531, 3], dtype=torch.int32, device=dev)
+    for seed, stream in ((0, 1), (0x1234_5678_9ABC_DEF0, 0xFFFF_FFFF_0000_0003)):
+        got = ops.draw_samples(n, 1000, seed, stream).cpu().numpy()
+        ref = philox_ref.draw_samples(n.cpu().numpy(), 1000, seed, stream)
+        assert np.array_equal(got, ref)
+    # uniform over [0, n): every residue of a small range appears, mean near (n-1)/2
+    big = ops.draw_samples(torch.tensor([1200], dtype=torch.int32, device=dev), 50000, 7, 9).cpu().numpy()
+    assert big.min() == 0 and big.max() == 1199 and abs(big.mean() - 599.5) < 5
+    # a different stream id / pair index gives different draws
+    a = ops.draw_samples(n[:1].repeat(2), 100, 1, 1).cpu()
+    assert not torch.equal(a[0], a[1])
+    assert not torch.equal(a[0], ops.draw_samples(n[:1], 100, 1, 2).cpu()[0])
+
+
+def _aten_filter(idx1, idx2, cnt, b, Mask, bg, rt, ct, HA, WA, Ht, Wt):
+    """The glue the kernel replaced, for one pair (pipeline.multi_h spells the same)."""
+    n = int(cnt[b])
+    i1, i2 = idx1[b, :n], idx2[b, :n]
+    bgb = torch.ones_like(Mask[b]) if bg is None else bg[b]
+    fg = ((Mask[b] + (1 - bgb)) > 0.5).float()
+    keep = ops.resize_bilinear((1 - fg)[None, None], (rt, ct), align_corners=False)[0, 0] > 0.5
+    valid = keep[i2 // ct, i2 % ct]
+    ones = torch.ones(int(valid.sum()), device=Mask.device)
+    m1 = torch.stack((HA[i1][valid], WA[i1][valid], ones), dim=1)
+    m2 = torch.stack((Ht[i2][valid], Wt[i2][valid], ones), dim=1)
+    return m1, m2, torch.nonzero(valid)[:, 0]
+
+
+@pytest.mark.parametrize("shape", [(240, 320, 15, 20), (96, 312, 10, 33), (376, 1242, 50, 165)])
+def test_filter_matches_equals_the_aten_glue(dev, shape):
+    h, w, rt, ct = shape
+    g = torch.Generator().manual_seed(h + w)
+    B, nA = 4, 3 * rt * ct
+    cap = rt * ct
+    Wt, Ht = cell_coords(rt, ct, dev)
+    WA, HA = torch.rand(nA, generator=g).to(dev), torch.rand(nA, generator=g).to(dev)
+    cnt = torch.tensor([cap, cap // 2, 3, 0], dtype=torch.int32, device=dev)
+    idx1 = torch.stack([torch.sort(torch.randperm(nA, generator=g)[:cap]).values for _ in range(B)]).to(dev)
+    idx2 = torch.stack([torch.randperm(cap, generator=g) for _ in range(B)]).to(dev)
+    # blobby 0/1 masks (non-integer resize ratios in two of the shapes) and a background map on half of the cases
+    blob = torch.nn.functional.avg_pool2d(torch.rand(B, 1, h + 16, w + 16, generator=g), 17, 1)[:, 0]
+    Mask = (blob > blob.median()).float().to(dev).contiguous()
+    for bg in (None, (torch.rand(B, h, w, generator=g) > 0.2).float().to(dev)):
+        for active in (None, torch.tensor([2, 0, 3, 1], dtype=torch.int32, device=dev), torch.tensor([1], dtype=torch.int32, device=dev)):
+            m1, m2, n, kept = ops.filter_matches(idx1, idx2, cnt, active, Mask, bg, rt, ct, HA, WA, Ht, Wt, want_kept=True)
+            order = list(range(B)) if active is None else active.cpu().tolist()
+            for k, b in enumerate(order):
+                r1, r2, rk = _aten_filter(idx1, idx2, cnt, b, Mask, bg, rt, ct, HA, WA, Ht, Wt)
+                nk = int(n[k])
+                assert nk == r1.shape[0]
+                assert torch.equal(m1[k, :nk], r1) and torch.equal(m2[k, :nk], r2)
+                assert torch.equal(kept[k, :nk].long(), rk)
+                assert float(m1[k, nk:].abs().max() if nk < cap else 0) == 0 and (nk == cap or int(kept[k, nk:].max()) == -1)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_multih_accept_equals_the_reference_rule(dev, mode):
+    g = torch.Generator().manual_seed(40 + mode)
+    B, h, w, h8, w8 = 5, 96, 136, 12, 17
+    act = torch.tensor([4, 0, 2, 3], dtype=torch.int32, device=dev)
+    a = act.shape[0]
+    # saturating "matchability": many exact ones, values straddling 0.9999
+    logits = torch.randn(a, h, w, generator=g) * 12
+    match = torch.sigmoid(logits).to(dev).contiguous()
+    Mask0 = (torch.rand(B, h, w, generator=g) > 0.7).float().to(dev).contiguous()
+    bg = (torch.rand(B, h, w, generator=g) > 0.1).float().to(dev)
+    res = torch.tensor([[0, 50, 3, 280], [0, 9, 1, 290], [1, 0, -1, 290], [0, 12, 8, 300]], dtype=torch.int32, device=dev)
+    n_match = torch.tensor([300, 3, 200, 40], dtype=torch.int32, device=dev)
+    nbH0 = torch.tensor([1, 0, 2, 0, 3], dtype=torch.int32, device=dev)        # pair 3: first homography -> accepted regardless of gain
+    bestH = torch.randn(a, 3, 3, generator=g).to(dev)
+    f8 = torch.randn(a, 2, h8, w8, generator=g).to(dev)
+    m12, m21 = torch.rand(a, 1, h8, w8, generator=g).to(dev), torch.rand(a, 1, h8, w8, generator=g).to(dev)
+    fd2 = torch.randn(a, 2, 6, 9, generator=g).to(dev) if mode else None
+    for use_bg in (True, False):
+        bgx = bg if use_bg else None
+        bgv = bg if use_bg else torch.ones_like(bg)
+        fg = ((Mask0[act.long()] + (1 - bgv[act.long()])) > 0.5).float()
+        stat = (match > 0.9999).float() * (1 - fg) if mode else match * (1 - fg)
+        gain_ref = stat.double().mean(dim=(1, 2)).float()
+        th = float(gain_ref.sort().values[1] + gain_ref.sort().values[2]) / 2          # some above, some below
+        ok = (n_match >= 4) & (res[:, 0] == 0) & ((gain_ref > th) | (nbH0[act.long()] == 0))
+        upd = Mask0[act.long()] + match * (1 - fg)
+        new_ref = ((upd > 0.9999) if mode else (upd >= 1.0)).float()
+        Mask, nbH = Mask0.clone(), nbH0.clone()
+        R = ops.MultiHRecords(B, h8, w8, dev, max_h=4, hd2=6 if mode else 0, wd2=9 if mode else 0)
+        acc, gain = ops.multih_accept(match, Mask, bgx, act, res, n_match, nbH, th, mode, bestH=bestH, flowDown8=f8, match12Down8=m12,
+                                      match21Down8=m21, flowD2=fd2, records=R)
+        assert torch.equal(acc.bool(), ok), (acc, ok, gain, gain_ref)
+        assert (gain - gain_ref).abs().max() < 1e-7
+        nbv, status, RH, Rf, Rm, Rd2 = R.views()
+        for k, b in enumerate(act.tolist()):
+            if ok[k]:
+                assert torch.equal(Mask[b], new_ref[k])
+                s = int(nbH0[b])
+                assert int(nbH[b]) == s + 1 and float(nbv[b]) == s + 1 and float(status[b]) == 0
+                if s < 4:
+                    assert torch.equal(RH[b, s], bestH[k]) and torch.equal(Rf[b, s], f8[k])
+                    assert torch.equal(Rm[b, s, 0], m12[k, 0]) and torch.equal(Rm[b, s, 1], m21[k, 0])
+                    if mode:
+                        assert torch.equal(Rd2[b, s], fd2[k])
+            else:
+                assert torch.equal(Mask[b], Mask0[b]) and int(nbH[b]) == int(nbH0[b]) and float(status[b]) == 1
+        assert torch.equal(Mask[1], Mask0[1])                                            # a pair outside the active list is untouched
+        assert ok.any() and not ok.all()
+
+
+@pytest.mark.parametrize("shape", [(32, 16, 60, 80), (16, 8, 120, 64), (16, 8, 120, 48), (12, 8, 90, 120), (6, 8, 81, 268),   # tuned 80/64/48-column tiles
+                                   (512, 2, 64, 32), (300, 2, 64, 32), (2, 64, 17, 24),                                        # 64- / 32- / 16-row x 16-column tiles
+                                   (3, 32, 9, 26), (2, 64, 41, 134)])                                                          # widths that are not a multiple of 4
+def test_two_direction_correlation_is_bit_identical_to_two_launches(dev, shape):
+    """corr(y, x) is corr(x, y) at mirrored taps / shifted pixels (same channel-ordered products): the BIDIR epilogue must
+    reproduce the second launch bit for bit, borders included, on every tile shape the automatic choice can take."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.nn.functional.normalize(torch.randn(N, C, H, W, generator=g), dim=1).to(dev)
+    y = torch.nn.functional.normalize(torch.randn(N, C, H, W, generator=g), dim=1).to(dev)
+    c12, c21 = ops.corr_neigh(x, y), ops.corr_neigh(y, x)
+    both = torch.full((2 * N, 49, H, W), float("nan"), device=dev)
+    b12, b21 = ops.corr_neigh_bidir(x, y, out=both)
+    assert torch.equal(b12, c12)
+    assert torch.equal(b21, c21)
+    assert torch.equal(both[:N], c12) and torch.equal(both[N:], c21)          # every element written (no NaN left)
+    # the index identity itself, on the one-direction results
+    i, j, r, c = 1, 5, H // 2, W // 2
+    assert float(c21[0, (6 - i) * 7 + (6 - j), r + i - 3, c + j - 3]) == float(c12[0, i * 7 + j, r, c])
+
+
+def test_graphed_trunk_pass_equals_the_eager_pass(dev, monkeypatch):
+    """B <= 4: the trunk pass is captured into a HIP graph at the SECOND sighting of a shape and replayed afterwards.  Two
+    different inputs of one shape must give their own, eager-identical features through the replay (a capture taken on the
+    wrong device / stream would replay stale outputs), and the capture cache is bounded."""
+    pipe = AlignPipeline(dict(trunk=weights.resnet50_trunk_sd(0)), nbScale=3, nbIter=10, tolerance=0.05, minSize=160, scaleR=1.2,
+                         device=dev)
+    preps = [pipe.prepare([synth.make_pair(128, 160, seed=s)]) for s in (1, 2, 3)]
+    monkeypatch.setenv("RFX_GRAPH", "0")
+    eager = [pipe.features(p) for p in preps]
+    monkeypatch.setenv("RFX_GRAPH", "1")
+    first = pipe.features(preps[0])                        # first sighting: eager
+    assert not getattr(pipe, "_graphs", {})
+    second = pipe.features(preps[1])                       # second sighting: capture + replay
+    assert len(pipe._graphs) == 1
+    third = pipe.features(preps[2])                        # replay
+    fourth = pipe.features(preps[0])
+    for got, ref in ((first, eager[0]), (second, eager[1]), (third, eager[2]), (fourth, eager[0])):
+        assert torch.equal(got["featA"], ref["featA"]) and torch.equal(got["featB"], ref["featB"])
+    assert not torch.equal(second["featA"], third["featA"])
+    # bounded cache: more shapes than MAX_GRAPHS, each seen twice
+    for k in range(pipe.MAX_GRAPHS + 2):
+        p = pipe.prepare([synth.make_pair(96 + 16 * k, 160, seed=k)])
+        pipe.features(p); pipe.features(p)
+    assert len(pipe._graphs) <= pipe.MAX_GRAPHS
+
+
+def test_lock_step_driver_device_draw_records_and_determinism(dev):
+    """The throughput form as bench.py runs it: device-side draw (no explicit samples), result records filled on the device.
+    Same seed + same call sequence -> the same homographies; the records hold exactly what the per-pair lists hold; the
+    RANSAC of every round is the oracle's on the device's own matches and draws (checked through the recorded H)."""
+    import restate
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=3.0))
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev, seed=5)
+    assert pipe.draw == "device"
+    pairs = [synth.make_pair(240, 320, seed=s, homography=True) for s in (7, 8, 9, 10)]
+    prep = pipe.prepare_device(*pipe.upload_raw(pairs))
+    feats = pipe.features(prep)
+    runs = []
+    for _ in range(2):
+        pipe.reseed(5)
+        R = ops.MultiHRecords(4, 30, 40, dev)
+        outs = pipe.multi_h_batched(prep, maxCoarse=3, maskRegionTh=0.01, feats=feats, records=R)
+        runs.append((outs, R))
+    (o1, R1), (o2, R2) = runs
+    assert torch.equal(R1.rec, R2.rec)
+    nbv, status, RH, Rf, Rm, _ = R1.views()
+    assert max(o["nbH"] for o in o1) >= 2
+    for b, o in enumerate(o1):
+        assert int(nbv[b]) == o["nbH"] == len(o["H"]) and float(status[b]) == (0.0 if o["H"] else 1.0)
+        for k in range(o["nbH"]):
+            assert torch.equal(RH[b, k], o["H"][k]) and torch.equal(Rf[b, k], o["flowDown8"][k][0])
+            assert torch.equal(Rm[b, k], o["matchDown8"][k][0])
+        assert float(RH[b, o["nbH"]:].abs().max()) == 0
+    # first round by hand: the device draw of call 1 is Philox(seed 5, stream 1); RANSAC on the device's matches with that draw
+    # must be the oracle's
+    idx1, idx2, cnt = pipe._mutual_batched(feats, 4)
+    Mask = torch.zeros((4, 240, 320), device=dev)
+    M1, M2, n = ops.filter_matches(idx1, idx2, cnt, None, Mask, None, feats["rt"], feats["ct"], feats["HA"], feats["WA"], feats["Ht"], feats["Wt"])
+    assert torch.equal(n, cnt)
+    smp = philox_ref.draw_samples(n.cpu().numpy(), 300, 5, 1)
+    for b in range(4):
+        nb_ = int(n[b])
+        Hb, c, inl, _ = restate.ransac(M1[b, :nb_].cpu(), M2[b, :nb_].cpu(), 0.05, torch.from_numpy(smp[b]))
+        assert np.abs(Hb - o1[b]["H"][0].cpu().numpy()).max() <= 1.2e-7
