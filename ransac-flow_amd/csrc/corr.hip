@@ -27,6 +27,7 @@
 //
 // Requires W % 4 == 0 for the 16-byte DMA path; other widths use the plain fallback kernel below.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,6 +46,7 @@ struct Cfg {
     static constexpr bool XPAD = OPT_ & 4;  // x rows padded to the y row stride (conflict-free ds_read_b128 of x)
     static constexpr bool PRIO = OPT_ & 8;  // s_setprio 1 for the waves of the largest tap group
     static constexpr bool BIDIR = OPT_ & 16; // also write corr(y, x): the same products at mirrored taps / shifted pixels
+    static constexpr bool LDW = OPT_ & 32;   // DMA issued only by the waves of the LIGHT tap groups (3 pieces each), none by the heavy one
     static constexpr int NW = TR / 16 * NCB * NG;              // waves per workgroup: strips x column blocks x tap-row groups
     static constexpr int YR = TR + 6;                          // halo rows
     static constexpr int YQ = 4 * NCB + 2;                     // float4 per halo row (cols c0-4 .. c0+16*NCB+3)
@@ -53,8 +55,12 @@ struct Cfg {
     static constexpr int Y_PIECES = (Y_SLOTS + 63) / 64;
     static constexpr int X_SLOTS = CK * TR * XQ;
     static constexpr int X_PIECES = (X_SLOTS + 63) / 64;
-    static constexpr int PPW = (Y_PIECES + X_PIECES + NW - 1) / NW;   // DMA pieces per wave per chunk (padded)
-    static constexpr int N_PIECES = PPW * NW;                  // incl. padding pieces (dump area, never read)
+    // LDW: a DMA piece costs its issuing wave 100-200 cycles inside a compute phase (MI355X_MICROARCH.md), as much as ~50 of its
+    // FMAs; the wave of the 3-row tap group already has 1.5x the FMAs of the others, so the pieces are dealt to the NL waves of
+    // the 2-row groups only (3 each instead of 2 for everyone) and every wave of a SIMD's {H,L,L,L} set is busy about equally.
+    static constexpr int NL = LDW ? NW - NW / NG : NW;         // waves that issue DMA
+    static constexpr int PPW = (Y_PIECES + X_PIECES + NL - 1) / NL;   // DMA pieces per issuing wave per chunk (padded)
+    static constexpr int N_PIECES = PPW * NL;                  // incl. padding pieces (dump area, never read)
     static constexpr int BUF_SLOTS = N_PIECES * 64;
     // window rows of group g: [row_begin(g), row_begin(g+1))  -- 2 groups: 4+3, 3 groups: 3+2+2, 4 groups: 2+2+2+1
     static constexpr int row_begin(int g) { return NG == 2 ? (g == 0 ? 0 : g == 1 ? 4 : 7)
@@ -77,6 +83,14 @@ struct Cfg {
         for (int v = 0; v < w; ++v) r += wave_group(v) == wave_group(w);
         return r;
     }
+    static constexpr int loader_rank(int w) {          // rank of w among the DMA-issuing waves; -1: this wave issues none
+        if (!LDW) return w;
+        if (wave_group(w) == 0) return -1;
+        int r = 0;
+        for (int v = 0; v < w; ++v) r += wave_group(v) != 0;
+        return r;
+    }
+    static_assert(!LDW || (BAL && TR == 16 && NCB == 5 && NG == 3), "LDW is defined for the balanced 15-wave map");
     static_assert(NG >= 2 && NG <= 4, "2..4 tap-row groups");
     static_assert(PF >= 0 && PF <= 2, "LDS read pipeline distance 0..2 steps");
     static_assert(NW * 64 <= 1024, "workgroup too large");
@@ -170,7 +184,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 // (I1-I0) accumulators per lane).  Splitting the 49 taps over NG wavefronts divides the register footprint (3 or 4
 // instead of 2 wavefronts per SIMD); all groups read the same LDS tile, so the DMA traffic is unchanged.
 template <class G, int I0, int I1>
-__device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave, int amask,
+__device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int lw, int amask,
                                             int strip, int cb, int lane, int nchunks, size_t HW,
                                             float* __restrict__ out, float* __restrict__ out21, int n, int row0, int c0, int H,
                                             int W, int trv) {
@@ -179,7 +193,7 @@ __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const 
         const size_t cbase = (size_t)chunk * CK * HW;
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
-            const int pi = wave + G::NW * i;
+            const int pi = lw + G::NL * i;             // lw < 0 (a wave that issues no DMA): amask == 0, nothing below runs
             const float* base = (pi < G::Y_PIECES ? yn : xn) + cbase;
             if constexpr (G::ZM) {
                 // slots outside the image were zeroed once: their lanes are masked off (no fetch, no LDS write) and a piece
@@ -190,6 +204,7 @@ __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const 
                     if (off[i] >= 0)
                         __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
             } else {
+                static_assert(G::ZM || !G::LDW, "LDW needs the masked issue");
                 const float* src = off[i] >= 0 ? base + off[i] : rfx_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
             }
@@ -311,11 +326,17 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
     const float* yn = y + (size_t)n * C * HW;
 
     // per-lane source offsets of the PPW DMA pieces this wave issues per chunk; -1 = 16-byte zero block
+    int lw = wave;
+    if constexpr (G::LDW) {
+        constexpr unsigned long long lmap = []() { unsigned long long m = 0; for (int w = 0; w < G::NW; ++w) m |= (unsigned long long)(G::loader_rank(w) & 15) << (4 * w); return m; }();
+        lw = (int)((lmap >> (4 * wave)) & 15);
+        if (lw == 15) lw = -1;
+    }
     int off[G::PPW];
     int amask = 0;
 #pragma unroll
     for (int i = 0; i < G::PPW; ++i) {
-        const int pi = wave + G::NW * i;
+        const int pi = lw < 0 ? G::N_PIECES : lw + G::NL * i;
         int o = -1;
         if (pi < G::Y_PIECES) {
             const int s = pi * 64 + lane;
@@ -341,10 +362,10 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
         // zero the out-of-image / padding slots of every ring buffer ONCE: the DMA never writes them again
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i)
-            if (off[i] < 0) {
+            if (off[i] < 0 && lw >= 0) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int b = 0; b < G::NS; ++b) smem[b * G::BUF_SLOTS + (wave + G::NW * i) * 64 + lane] = z;
+                for (int b = 0; b < G::NS; ++b) smem[b * G::BUF_SLOTS + (lw + G::NL * i) * 64 + lane] = z;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the raw s_barrier of the main loop does not wait for ds_write
     }
@@ -357,7 +378,7 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
     }
     const int strip = sc / NCB, cb = sc - strip * NCB;
     const int nch = C / G::CK;
-#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, amask, strip, cb, lane, nch, HW, out, out21, n, row0, c0, H, W, trv)
+#define RFX_STRIP(g) corr7_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, lw, amask, strip, cb, lane, nch, HW, out, out21, n, row0, c0, H, W, trv)
     if (G::PRIO && grp == 0) __builtin_amdgcn_s_setprio(1);   // the 4-/3-row group has the most FMAs per chunk: let it win VALU arbitration
     if (grp == 0) RFX_STRIP(0);
     else if (grp == 1) RFX_STRIP(1);
@@ -366,10 +387,25 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
 #undef RFX_STRIP
 }
 
+// Small launches (the multi-homography rounds of the evaluation drivers run the correlation on the 8-16 pairs that are still
+// active: 48-200 workgroups of 16-row tiles on 256 CUs) are bound by the lifetime of ONE workgroup, not by bandwidth.
+// Experiment knob RFX_CORR_MIN_WGS = n: equal row tiles are made shorter than 16 rows until the grid reaches n workgroups or a
+// tile would fall under 8 rows.  Measured (profiles/r03_corr_small_launches.txt, both directions of 8-24 pairs): n = 256 is a
+// wash (+-5 %: the 6 halo rows of a shorter tile cost what the extra workgroups gain), n = 512 is 35-60 % slower -> default 0.
+static int corr_min_wgs() {
+    static const int v = []() { const char* e = getenv("RFX_CORR_MIN_WGS"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <class G>
 static void launch_corr(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st, bool even = false,
                         float* out21 = nullptr) {
-    const int tilesR = (H + G::TR - 1) / G::TR, tilesC = (W + TC * G::NCB - 1) / (TC * G::NCB);
+    int tilesR = (H + G::TR - 1) / G::TR;
+    const int tilesC = (W + TC * G::NCB - 1) / (TC * G::NCB);
+    if (even) {
+        const long long want = corr_min_wgs();
+        while ((long long)N * tilesR * tilesC < want && (H + tilesR) / (tilesR + 1) >= 8) ++tilesR;
+    }
     const int trv = even ? (H + tilesR - 1) / tilesR : G::TR;      // equal row tiles (60 = 4 x 15) or full 16-row strips
     hipLaunchKernelGGL((corr7_dma_kernel<G>), dim3((unsigned)(N * tilesR * tilesC)), dim3(G::NW * 64), 0, st, x, y, out,
                        out21, N, C, H, W, tilesR, tilesC, trv);
@@ -438,6 +474,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, flo
         case 7: launch_corr<CfgTuned3>(x, y, out, N, C, H, W, st, true); break;
         case 8: launch_corr<CfgTuned4>(x, y, out, N, C, H, W, st, true); break;
         case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
+        case 10: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 32>>(x, y, out, N, C, H, W, st, true); break;   // 5 + DMA on the light waves
+        case 11: launch_corr<Cfg<16, 5, 2, 5, 3, 1, 0, 0, 15 | 32>>(x, y, out, N, C, H, W, st, true); break;   // 10 with a ring of 5
 #ifdef RFX_CORR_EXPERIMENTS   // `make exp NAME=correxp SRC=corr DEFS=-DRFX_CORR_EXPERIMENTS`: never in the product library
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;

@@ -17,6 +17,39 @@
 #define RFX_HD inline
 #endif
 
+// det(H) of the 3x3 float32 homography as torch.det evaluates it on the CPU (utils/outil.py:108,113: counts * (det > 1e-6)).
+// torch.det = sign * prod(diag(LU)) with LU from LAPACK sgetrf on the row-major storage read as column-major, i.e. of H^T
+// (det is transpose-invariant, the rounding is not).  Operation order probed against torch 2.10 + MKL 2024.2 on 3x3 inputs
+// (tests/test_oracle.py::test_det3_lu_is_torch_det: bit-equal on every sample): partial pivoting with the first
+// maximum; the first column is scaled by the RECIPROCAL of the pivot, the trailing 2x2 block updated with fused
+// multiply-adds; the second column divides by the pivot; det = ((u00 * u11) * u22) * sign.  A float32 cofactor expansion of
+// the same matrix differs from this by up to ~1.5e-8 when det is near the 1e-6 gate (terms of O(0.1) cancel): 1.4 % of
+// the hypotheses within +-10 % of the gate flipped their decision; with the LU order the gate is the oracle's bit for bit.
+// Only the fmaf calls below may fuse: the including translation unit is built with -ffp-contract=off.
+RFX_HD float rfx_det3_lu_f32(const float* h) {
+    float b00 = h[0], b01 = h[3], b02 = h[6];      // B = H^T
+    float b10 = h[1], b11 = h[4], b12 = h[7];
+    float b20 = h[2], b21 = h[5], b22 = h[8];
+    bool neg = false;
+    int p = 0;
+    float m = fabsf(b00);
+    if (fabsf(b10) > m) { p = 1; m = fabsf(b10); }
+    if (fabsf(b20) > m) p = 2;
+    if (p == 1) { float t; t = b00; b00 = b10; b10 = t; t = b01; b01 = b11; b11 = t; t = b02; b02 = b12; b12 = t; neg = !neg; }
+    if (p == 2) { float t; t = b00; b00 = b20; b20 = t; t = b01; b01 = b21; b21 = t; t = b02; b02 = b22; b22 = t; neg = !neg; }
+    if (b00 == 0.0f) return 0.0f;                   // singular: a zero on U's diagonal
+    const float r = 1.0f / b00;
+    const float l1 = b10 * r, l2 = b20 * r;
+    b11 = fmaf(-l1, b01, b11); b12 = fmaf(-l1, b02, b12);
+    b21 = fmaf(-l2, b01, b21); b22 = fmaf(-l2, b02, b22);
+    if (fabsf(b21) > fabsf(b11)) { float t; t = b11; b11 = b21; b21 = t; t = b12; b12 = b22; b22 = t; neg = !neg; }
+    if (b11 == 0.0f) return 0.0f;
+    const float l = b21 / b11;
+    const float u22 = fmaf(-l, b12, b22);
+    const float d = (b00 * b11) * u22;
+    return neg ? -d : d;
+}
+
 // dlapy2: sqrt(x^2 + y^2) without unnecessary overflow
 RFX_HD double rfx_dlapy2(double x, double y) {
     const double xa = fabs(x), ya = fabs(y);

@@ -5,7 +5,7 @@
 // 143-150).  Here the whole search is four asynchronous launches with no host round trip:
 //   pack     matches -> (x1,y1,x2,y2) float4 + z2, so scoring issues one 16-byte load per match
 //   dlt      one hypothesis per lane: duplicate test (:122-133), float64 Householder DLT (dlt.h,
-//            LAPACK-sign-exact), float32 cast, det(H) > 1e-6 gate (:108,113)
+//            LAPACK-sign-exact), float32 cast, det(H) > 1e-6 gate with torch.det's LU order (:108,113)
 //   count    one hypothesis per wavefront: lanes stride over the matches, reprojection error in the
 //            reference's float32 operation order (k-ordered fma chain for Y.H^T as sgemm does, IEEE
 //            divide, separate squares / add / sqrt), __ballot + popcount for the inlier tally (:97-100,110-113)
@@ -41,14 +41,6 @@ __global__ __launch_bounds__(256) void ransac_pack_kernel(const float* __restric
         P[i] = p;
         Z[i] = m2[i * 3 + 2];
     }
-}
-
-__device__ __forceinline__ float det3_f32(const float* h) {
-    // cofactor expansion along the first row, float32, no contraction
-    const float c0 = __fsub_rn(__fmul_rn(h[4], h[8]), __fmul_rn(h[5], h[7]));
-    const float c1 = __fsub_rn(__fmul_rn(h[3], h[8]), __fmul_rn(h[5], h[6]));
-    const float c2 = __fsub_rn(__fmul_rn(h[3], h[7]), __fmul_rn(h[4], h[6]));
-    return __fadd_rn(__fsub_rn(__fmul_rn(h[0], c0), __fmul_rn(h[1], c1)), __fmul_rn(h[2], c2));
 }
 
 // X,Y given either as gathered samples (N,4,3) [direct != 0] or through indices into the match arrays.
@@ -95,7 +87,7 @@ __global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict_
         float hf[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) { hf[j] = (float)hv[j]; Hout[(size_t)h * 9 + j] = hf[j]; }
-        fl = 1 | (det3_f32(hf) > 1e-6f ? 2 : 0);
+        fl = 1 | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);   // torch.det's own LU order (dlt.h)
     } else {
 #pragma unroll
         for (int j = 0; j < 9; ++j) Hout[(size_t)h * 9 + j] = 0.0f;

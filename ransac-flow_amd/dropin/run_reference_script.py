@@ -128,15 +128,15 @@ def patch_functional():
 
     def interpolate(input, size=None, scale_factor=None, mode="nearest", align_corners=None, **kw):
         if input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and mode == "bilinear" and not kw:
-            sf = None
-            if size is None:
+            sf, out_size = None, size                    # the caller's own arguments stay untouched for the fallback below
+            if out_size is None:
                 sf = scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor, scale_factor)
-                size = (int(input.shape[2] * sf[0]), int(input.shape[3] * sf[1]))
+                out_size = (int(input.shape[2] * sf[0]), int(input.shape[3] * sf[1]))
             # torch maps coordinates with 1/scale_factor when a scale factor is given; the kernel uses in/out sizes:
             # the two agree only when out = in * factor exactly (integer factors, the x8 of the reference)
             if sf is None or all(float(f).is_integer() for f in sf):
-                size = (size, size) if isinstance(size, int) else size
-                return ops.resize_bilinear(input, size, bool(align_corners))
+                out_size = (out_size, out_size) if isinstance(out_size, int) else out_size
+                return ops.resize_bilinear(input, out_size, bool(align_corners))
         return _ip(input, size=size, scale_factor=scale_factor, mode=mode, align_corners=align_corners, **kw)
 
     def normalize(input, p=2.0, dim=1, eps=1e-12, out=None):

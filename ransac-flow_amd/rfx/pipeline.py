@@ -45,6 +45,21 @@ def pil_to_tensor(pil):
     return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().float().div(255)
 
 
+_CELL_COORDS = {}
+
+
+def cell_coords_cached(n_rows, n_cols, device):
+    """cell_coords() memoised per (shape, device): the grids are constants of the map size (a dozen tiny ATen launches per
+    pyramid level and step otherwise)."""
+    key = (n_rows, n_cols, str(device))
+    v = _CELL_COORDS.get(key)
+    if v is None:
+        if len(_CELL_COORDS) > 256:
+            _CELL_COORDS.clear()
+        v = _CELL_COORDS[key] = cell_coords(n_rows, n_cols, device)
+    return v
+
+
 def cell_coords(n_rows, n_cols, device):
     """outil.getWHTensor (utils/outil.py:21-24): (W = row coordinate, H = column coordinate)."""
     r = (torch.arange(n_rows, dtype=torch.float32, device=device) + 0.5) / n_rows
@@ -209,7 +224,7 @@ class AlignPipeline:
         Ws, Hs, offs = [], [], []
         off = 0
         for (r, c) in dims:
-            W, Hh = cell_coords(r, c, self.dev)
+            W, Hh = cell_coords_cached(r, c, self.dev)
             Ws.append(W)
             Hs.append(Hh)
             offs.append(off)
@@ -256,7 +271,7 @@ class AlignPipeline:
             ft_raw.record_stream(main)
         ft = ops.l2norm(ft_raw if ft_raw is not None else self.trunk(tgt))
         rt, ct = ft.shape[2], ft.shape[3]
-        Wt, Ht = cell_coords(rt, ct, self.dev)
+        Wt, Ht = cell_coords_cached(rt, ct, self.dev)
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
@@ -497,7 +512,7 @@ class AlignPipeline:
             M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
                                                feats["Wt"])
             smp = self._round_draws(active, n_dev, sample_fn)
-            bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flowCoarse = ops.warp_grid(Hs, h, w)
             Is = prep["IsTensor"] if full else prep["IsTensor"].index_select(0, A)
@@ -507,7 +522,7 @@ class AlignPipeline:
                                              flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
                                              match21Down8=pm["match21Down8"], records=records)
             if trace is not None:
-                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, pm=pm, match=pm["match"][:, 0],
+                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=pm["match"][:, 0],
                                   accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
             acc = accept.cpu().tolist()                                                 # the round's ONE sync
@@ -672,7 +687,7 @@ class AlignPipeline:
             M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
                                                feats["Wt"])
             smp = self._round_draws(active, n_dev, sample_fn)
-            bestH, _, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flow_d2, pm, match = self.kitti_fine_round(Hs, sel(tensor_s), sel(tensor_d2), sel(tensor_resize), (h_org, w_org),
                                                        cc_th, remove_small_cc)
@@ -681,7 +696,7 @@ class AlignPipeline:
                                              flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
                                              match21Down8=pm["match21Down8"], flowD2=flow_d2, records=records)
             if trace is not None:
-                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, pm=pm, match=match,
+                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=match,
                                   flowD2=flow_d2, accept=accept, gain=gain,
                                   mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None

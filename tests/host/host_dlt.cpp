@@ -13,3 +13,8 @@ extern "C" void rfx_host_dlt4(const float* X, const float* Y, int N, double* h_o
         for (int j = 0; j < 9; ++j) { h_out[n * 9 + j] = h[j]; H_out[n * 9 + j] = (float)h[j]; }
     }
 }
+
+// det(H) as torch.det evaluates it (dlt.h: rfx_det3_lu_f32), for the CPU pin against torch.det.
+extern "C" void rfx_host_det3(const float* H, int N, float* out) {
+    for (int n = 0; n < N; ++n) out[n] = rfx_det3_lu_f32(H + n * 9);
+}

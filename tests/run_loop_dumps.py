@@ -24,7 +24,9 @@ def main():
     for cfg, n in jobs:
         d = os.path.join(ROOT, "gpurun_out", tag, "dumps", cfg)
         t0 = time.perf_counter()
-        parity_sweep.dump_gpu_loop(cfg, list(range(int(n))), dev, d, batch=4 if cfg != "c5" else 2)
+        # every 8th pixel of the composed flow for the 64-pair sweep (the dump must travel back: <= 64 MiB in total)
+        parity_sweep.dump_gpu_loop(cfg, list(range(int(n))), dev, d, batch=(16 if cfg == "ev_loop" else 4) if cfg != "c5" else 2,
+                                   sub=8 if cfg == "ev_loop" else 4)
         sz = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
         print("%s: %s pairs dumped to %s in %.1f s, %.1f MB" % (cfg, n, d, time.perf_counter() - t0, sz / 1e6), flush=True)
 

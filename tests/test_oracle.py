@@ -102,6 +102,62 @@ def test_householder_dlt_is_lapack_sign_exact(tmp_path_factory):
     assert np.abs(Href - Hf[:64]).max() <= 1.2e-7
 
 
+def det_gate_cases(N, seed=0, spread=0.1):
+    """N 4-point correspondences whose unit-norm DLT homography has |det| within +-``spread`` of the 1e-6 gate of
+    utils/outil.py:108,113: H0 = U diag(1, 1, d) V^T (random orthogonal U, V) maps four spread-out target points onto a
+    nearly collinear source quadruple.  Returns X (source), Y (target), each (N,4,3) float32; degenerate draws are dropped."""
+    rng = np.random.RandomState(seed)
+    base = np.array([[-0.8, -0.7], [0.75, -0.6], [0.7, 0.8], [-0.65, 0.72]])
+    Xs, Ys = [], []
+    while len(Xs) < N:
+        U, _ = np.linalg.qr(rng.randn(3, 3))
+        V, _ = np.linalg.qr(rng.randn(3, 3))
+        d = 1e-6 * (1 + spread * (2 * rng.rand() - 1)) * 2 ** 1.5          # det(H0 / |H0|_F) ~ d / (2 + d^2)^1.5
+        H0 = U @ np.diag([1, 1, d]) @ V.T
+        Yh = np.concatenate([base + 0.1 * rng.randn(4, 2), np.ones((4, 1))], 1)
+        Xh = Yh @ H0.T
+        if np.abs(Xh[:, 2]).min() < 0.2:
+            continue
+        Xs.append(np.concatenate([Xh[:, :2] / Xh[:, 2:], np.ones((4, 1))], 1))
+        Ys.append(Yh)
+    return np.stack(Xs).astype(np.float32), np.stack(Ys).astype(np.float32)
+
+
+def test_det3_lu_is_torch_det(tmp_path_factory):
+    """The kernel's determinant (dlt.h: rfx_det3_lu_f32, compiled for the host) IS torch.det's float32 value -- the LU of H^T
+    with MKL's operation order -- on random, near-singular and gate-straddling 3x3 matrices: bit for bit, so the
+    ``det(H) > 1e-6`` gate of utils/outil.py:113 decides identically.  (A float32 cofactor expansion, the round-1/2 kernel,
+    flips 1-2 % of the decisions within +-10 % of the gate: counted below.)"""
+    lib = _host_dlt_lib(tmp_path_factory)
+    rng = np.random.RandomState(3)
+    mats = []
+    for _ in range(4000):
+        U, _ = np.linalg.qr(rng.randn(3, 3))
+        V, _ = np.linalg.qr(rng.randn(3, 3))
+        M = U @ np.diag([1, 1, 10 ** rng.uniform(-8, 0)]) @ V.T
+        mats.append(M / np.linalg.norm(M) * rng.choice([-1, 1]))
+    X, Y = det_gate_cases(3000, seed=1)
+    Hg = restate.homography_svd(torch.from_numpy(X), torch.from_numpy(Y)).numpy()
+    mats = np.concatenate([np.stack(mats).astype(np.float32), Hg, rng.randn(500, 3, 3).astype(np.float32)])
+    out = np.zeros(len(mats), dtype=np.float32)
+    vp = ctypes.c_void_p
+    flat = np.ascontiguousarray(mats.reshape(-1, 9))
+    lib.rfx_host_det3(flat.ctypes.data_as(vp), len(mats), out.ctypes.data_as(vp))
+    ref = torch.det(torch.from_numpy(mats)).numpy()
+    assert np.array_equal(out, ref), "bit-equal fraction %.4f" % np.mean(out == ref)
+    # the gate-straddling family really straddles, and the cofactor expansion would have flipped some of its decisions
+    d64 = np.linalg.det(Hg.astype(np.float64))
+    band = np.abs(np.abs(d64) - 1e-6) < 1e-7
+    assert band.sum() > 1000
+    h = Hg.reshape(-1, 9)
+    f = np.float32
+    c0, c1, c2 = f(f(h[:, 4] * h[:, 8]) - f(h[:, 5] * h[:, 7])), f(f(h[:, 3] * h[:, 8]) - f(h[:, 5] * h[:, 6])), f(f(h[:, 3] * h[:, 7]) - f(h[:, 4] * h[:, 6]))
+    cof = f(f(f(h[:, 0] * c0) - f(h[:, 1] * c1)) + f(h[:, 2] * c2))
+    lo = len(mats) - 500 - len(Hg)
+    flipped = int(((cof > 1e-6) != (ref[lo:lo + len(Hg)] > 1e-6)).sum())
+    print("gate decisions a float32 cofactor expansion would flip: %d of %d within +-10 %% of the gate" % (flipped, int(band.sum())))
+
+
 def test_householder_dlt_on_degenerate_samples(tmp_path_factory):
     """Fuzz of the 4-point DLT on the samples the coarse grid makes likely: three or four points of one grid
     row or column (collinear), near-collinear points, and two sources sent to one target.  Where the 8x9
