@@ -47,6 +47,14 @@ struct Cfg {
     static constexpr bool PRIO = OPT_ & 8;  // s_setprio 1 for the waves of the largest tap group
     static constexpr bool BIDIR = OPT_ & 16; // also write corr(y, x): the same products at mirrored taps / shifted pixels
     static constexpr bool LDW = OPT_ & 32;   // DMA issued only by the waves of the LIGHT tap groups (3 pieces each), none by the heavy one
+    // ROT: register-bank rotation of the accumulators.  v_fmac_f32 acc, x, y issues in ~2.3 cycles per wave64 instruction with
+    // two of its three VGPR operands in one bank (bank = register number mod 4) and in ~4.4 with all three
+    // (scripts/ubench/valu_bank.hip, profiles/r03_valu_bank.txt).  acc[d][.] / x[d] / y[d+j+1] live in even-aligned 4-register
+    // tuples, so element index = bank offset: with the plain layout acc[d], x[d] and y[d+j+1] share a bank for one tap column
+    // in seven whenever the tuples' bases agree mod 4 (they do in the compiled kernel: v_fmac_f32 v70, v90, v98).  Storing
+    // the sum of (pixel d, tap column j) in tuple element (d+j)&3 puts acc and y one element apart -- an odd bank distance
+    // that even-aligned bases cannot cancel -- so a three-way clash is impossible whatever the allocator does.
+    static constexpr bool ROT = OPT_ & 64;
     static constexpr int NW = TR / 16 * NCB * NG;              // waves per workgroup: strips x column blocks x tap-row groups
     static constexpr int YR = TR + 6;                          // halo rows
     static constexpr int YQ = 4 * NCB + 2;                     // float4 per halo row (cols c0-4 .. c0+16*NCB+3)
@@ -162,7 +170,8 @@ __device__ __forceinline__ void corr7_steps(f32x4 (&wq)[G::CK * (I1 - I0)][3], f
         for (int j = 0; j < 7; ++j) {
             const int e = d + j + 1;
             const float yv = e < 4 ? w0[e & 3] : (e < 8 ? w1[e & 3] : w2[e & 3]);
-            acc[d][r * 7 + j] = fmaf(xv[d], yv, acc[d][r * 7 + j]);
+            float& a = acc[G::ROT ? (d + j) & 3 : d][r * 7 + j];
+            a = fmaf(xv[d], yv, a);
         }
     if constexpr (G::SB) __builtin_amdgcn_sched_barrier(0);
     if constexpr (ST + 1 < NSTEP) corr7_steps<G, I0, I1, ST + 1>(wq, xq, acc, ya, xa);
@@ -260,7 +269,25 @@ __device__ __forceinline__ void corr7_strip(f32x4* smem, const float* xn, const 
                 }
             }
         }
+        if constexpr (G::ROT) {
+            // keep every accumulator quad a REGISTER TUPLE (element index = bank offset) across the loop: an empty asm with a
+            // 128-bit operand is the only way to tell the allocator so
+#pragma unroll
+            for (int q = 0; q < NI * 7; ++q) {
+                f32x4 tq = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+                asm volatile("" : "+v"(tq));
+                acc[0][q] = tq[0]; acc[1][q] = tq[1]; acc[2][q] = tq[2]; acc[3][q] = tq[3];
+            }
+        }
         buf = buf == NS - 1 ? 0 : buf + 1;
+    }
+    if constexpr (G::ROT) {                     // undo the rotation: pixel d of tap column j sits in element (d+j)&3
+#pragma unroll
+        for (int q = 0; q < NI * 7; ++q) {
+            const int j = q % 7;
+            const float t0 = acc[(0 + j) & 3][q], t1 = acc[(1 + j) & 3][q], t2 = acc[(2 + j) & 3][q], t3 = acc[(3 + j) & 3][q];
+            acc[0][q] = t0; acc[1][q] = t1; acc[2][q] = t2; acc[3][q] = t3;
+        }
     }
     const int gr = row0 + tr, gc = c0 + cb * TC + 4 * tc;
     if (tr < trv && gr < H && gc < W) {
@@ -476,6 +503,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, flo
         case 9: launch_corr<Cfg<32, 2, 2, 3>>(x, y, out, N, C, H, W, st); break;
         case 10: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 32>>(x, y, out, N, C, H, W, st, true); break;   // 5 + DMA on the light waves
         case 11: launch_corr<Cfg<16, 5, 2, 5, 3, 1, 0, 0, 15 | 32>>(x, y, out, N, C, H, W, st, true); break;   // 10 with a ring of 5
+        case 12: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 64>>(x, y, out, N, C, H, W, st, true); break;   // 5 + accumulator bank rotation
+        case 13: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 32 | 64>>(x, y, out, N, C, H, W, st, true); break;   // 12 + DMA on the light waves
 #ifdef RFX_CORR_EXPERIMENTS   // `make exp NAME=correxp SRC=corr DEFS=-DRFX_CORR_EXPERIMENTS`: never in the product library
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
