@@ -404,6 +404,17 @@ def compare_loop(cfg_name, seed, gpu_npz):
             smp = draw_round(seed, k, n_or, c["nbIter"])[int(g["winner"][k])]
             sv = np.linalg.svd(restate.dlt_matrix(m1_all[valid][smp][None].numpy(), m2_all[valid][smp][None].numpy()), compute_uv=False)[0]
             r["dlt_sigma8_over_sigma1"] = float(sv[7] / sv[0])
+            # which hypothesis won on each side?  (the oracle's winner = first maximum of its per-hypothesis counts)
+            allsmp = draw_round(seed, k, n_or, c["nbIter"])
+            uniq = restate.filter_samples(allsmp)
+            Hs_o, cnt_o = restate.score_ransac(m1_all[valid], m2_all[valid], 0.05, uniq)
+            wo = uniq[int(torch.argmax(cnt_o))]
+            wg = allsmp[int(g["winner"][k])]
+            r["winner_same_sample"] = bool(torch.equal(wo, wg))
+            r["winner_count_oracle"] = int(cnt_o.max())
+            gi = int((uniq == wg).all(dim=1).nonzero()[0, 0]) if (uniq == wg).all(dim=1).any() else -1
+            r["oracle_count_of_gpu_winner"] = int(cnt_o[gi]) if gi >= 0 else None
+            r["degenerate_winner"] = bool(sv[7] / sv[0] < 1e-10)
         Hm = torch.from_numpy(np.asarray(Hb, dtype=np.float32))[None]
         if kitti:
             match, flow_d2, fd8, md8, flow12 = restate.kitti_fine_round(nets, T, Hm, c["cc_th"])

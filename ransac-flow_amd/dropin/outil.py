@@ -24,12 +24,9 @@ def resizeImg(I, strideNet, minSize=400, mode=Image.LANCZOS):
 def getWHTensor(feat):
     """utils/outil.py:21-24.  Returns (W, H): W = normalised *row* coordinate, H = *column* coordinate of
     every cell of ``feat`` (n,c,rows,cols), cell centres in [-1, 1]."""
-    rows, cols = feat.size(2), feat.size(3)
-    r = (torch.arange(rows, device=feat.device).float() + 0.5) / rows
-    c = (torch.arange(cols, device=feat.device).float() + 0.5) / cols
-    W = r.view(-1, 1).expand(rows, cols).reshape(-1)
-    Hh = c.view(1, -1).expand(rows, cols).reshape(-1)
-    return (W - 0.5) * 2, (Hh - 0.5) * 2
+    from rfx.pipeline import cell_coords_cached
+    # the CPU reference's values bit for bit (true division; ATen's device kernel multiplies by a rounded reciprocal)
+    return cell_coords_cached(feat.size(2), feat.size(3), feat.device)
 
 
 def getWHTensor_Int(feat):

@@ -61,12 +61,17 @@ def cell_coords_cached(n_rows, n_cols, device):
 
 
 def cell_coords(n_rows, n_cols, device):
-    """outil.getWHTensor (utils/outil.py:21-24): (W = row coordinate, H = column coordinate)."""
-    r = (torch.arange(n_rows, dtype=torch.float32, device=device) + 0.5) / n_rows
-    c = (torch.arange(n_cols, dtype=torch.float32, device=device) + 0.5) / n_cols
+    """outil.getWHTensor (utils/outil.py:21-24): (W = row coordinate, H = column coordinate).
+    Evaluated on the CPU and uploaded: ``(i + 0.5) / n`` is a true IEEE division there, while ATen's device kernel for
+    tensor / python-scalar multiplies by the rounded reciprocal -- 40 % of the cell centres come out one float32 ulp
+    (1.2e-7) away (scripts/dbg/cell_coords_check.py).  The CPU reference is the parity target: with its coordinates the
+    RANSAC inputs are the oracle's bit for bit (the 1-ulp offset used to reach H as up to 4e-7, and as 4e-6 through an
+    ill-conditioned 4-point sample)."""
+    r = (torch.arange(n_rows, dtype=torch.float32) + 0.5) / n_rows
+    c = (torch.arange(n_cols, dtype=torch.float32) + 0.5) / n_cols
     W = r.view(-1, 1).expand(n_rows, n_cols).reshape(-1)
     Hh = c.view(1, -1).expand(n_rows, n_cols).reshape(-1)
-    return (W - 0.5) * 2, (Hh - 0.5) * 2
+    return ((W - 0.5) * 2).to(device), ((Hh - 0.5) * 2).to(device)
 
 
 class AlignPipeline:

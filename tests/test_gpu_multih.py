@@ -14,6 +14,26 @@ from rfx.pipeline import AlignPipeline, cell_coords
 pytestmark = pytest.mark.gpu
 
 
+def test_cell_coordinates_are_the_cpu_reference_values_bit_for_bit(dev):
+    """outil.getWHTensor's cell centres as the CPU reference computes them (true division): the RANSAC inputs must be the
+    oracle's exactly -- ATen's device kernel for tensor / scalar multiplies by a rounded reciprocal and lands one ulp away
+    on 40 % of the cells, which a 4-point DLT amplifies by its conditioning."""
+    import restate
+    for (r, c) in [(30, 40), (60, 80), (25, 33), (50, 165), (45, 60), (7, 23)]:
+        Wd, Hd = cell_coords(r, c, dev)
+        Wo, Ho = restate.get_wh(r, c)
+        assert torch.equal(Wd.cpu(), Wo) and torch.equal(Hd.cpu(), Ho)
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ransac-flow_amd", "dropin", "outil.py")
+    spec = importlib.util.spec_from_file_location("_rfx_dropin_outil_probe", path)      # private name: no sys.modules["outil"]
+    outil = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(outil)
+    W, H = outil.getWHTensor(torch.empty((1, 4, 25, 33), device=dev))
+    Wo, Ho = restate.get_wh(25, 33)
+    assert torch.equal(W.cpu(), Wo) and torch.equal(H.cpu(), Ho)
+
+
 def test_device_index_draw_is_philox_modulo_the_device_counts(dev):
     n = torch.tensor([1200, 4, 0, 7, 8531, 3], dtype=torch.int32, device=dev)
     for seed, stream in ((0, 1), (0x1234_5678_9ABC_DEF0, 0xFFFF_FFFF_0000_0003)):
@@ -207,3 +227,50 @@ def test_lock_step_driver_device_draw_records_and_determinism(dev):
         nb_ = int(n[b])
         Hb, c, inl, _ = restate.ransac(M1[b, :nb_].cpu(), M2[b, :nb_].cpu(), 0.05, torch.from_numpy(smp[b]))
         assert np.abs(Hb - o1[b]["H"][0].cpu().numpy()).max() <= 1.2e-7
+
+
+def test_lock_step_driver_with_hopeless_pairs(dev):
+    """A batch holding an alignable pair, a pair whose target is ALL background (It_bg = 0: every cached match is masked out,
+    fewer than 4 survive -> the reference returns its None sentinel before RANSAC,
+    evaluation/evalHpatch/coarseAlignFeatMatch.py:165-166) and a noise pair: the device-resident rounds must neither crash nor
+    let one pair disturb another -- the good pair equals the same pair run alone (same draws), the record of a pair without
+    homography carries status 1 / nbH 0 / zero payload."""
+    import PIL.Image as Image
+    rng = np.random.RandomState(3)
+    good = synth.make_pair(240, 320, seed=7, homography=True)
+    blank = (good[0], Image.fromarray(np.full((240, 320, 3), 127, dtype=np.uint8)))
+    noise = (Image.fromarray((rng.rand(240, 320, 3) * 255).astype(np.uint8)), Image.fromarray((rng.rand(240, 320, 3) * 255).astype(np.uint8)))
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=3.0))
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev)
+
+    def draws_for_pair0():
+        calls = [0]
+
+        def fn(b, n, it):
+            if b != 0:
+                return torch.randint(n, (it, 4))
+            calls[0] += 1
+            return torch.randint(n, (it, 4), generator=torch.Generator().manual_seed(31 * calls[0]))
+        return fn
+    alone = pipe.multi_h_batched(pipe.prepare_device(*pipe.upload_raw([good])), maxCoarse=3, sample_fn=draws_for_pair0())
+    prep = pipe.prepare_device(*pipe.upload_raw([good, blank, noise]))
+    R = ops.MultiHRecords(3, 30, 40, dev)
+    bg = torch.ones((3, 240, 320), device=dev)
+    bg[1] = 0
+    outs = pipe.multi_h_batched(prep, maxCoarse=3, sample_fn=draws_for_pair0(), records=R, It_bg=bg)
+    assert outs[0]["nbH"] == alone[0]["nbH"] >= 1
+    for k in range(outs[0]["nbH"]):
+        assert torch.equal(outs[0]["H"][k], alone[0]["H"][k]) and torch.equal(outs[0]["flowDown8"][k], alone[0]["flowDown8"][k])
+    assert torch.equal(outs[0]["mask"], alone[0]["mask"])
+    nbv, status, RH, Rf, Rm, _ = R.views()
+    assert torch.isfinite(R.rec).all()
+    for b, o in enumerate(outs):
+        assert int(nbv[b]) == o["nbH"] and float(status[b]) == (0.0 if o["nbH"] else 1.0)
+        if o["nbH"] == 0:
+            assert float(RH[b].abs().max()) == 0 and float(Rf[b].abs().max()) == 0
+    assert outs[1]["nbH"] == 0 and float(outs[1]["mask"].sum()) == 0       # all-background target: no match survives, no homography
+    # and the device-draw default on the same batch: runs, deterministic under reseed
+    pipe.reseed(11); a = pipe.multi_h_batched(prep, maxCoarse=2, It_bg=bg)
+    pipe.reseed(11); b = pipe.multi_h_batched(prep, maxCoarse=2, It_bg=bg)
+    assert [o["nbH"] for o in a] == [o["nbH"] for o in b] and all(torch.equal(x["mask"], y["mask"]) for x, y in zip(a, b))
