@@ -157,8 +157,9 @@ def parity_subprocess(cfg, dump_dir, seeds, H, W, budget):
            str(H), "--width", str(W), "--budget", str(budget), "--seeds"] + [str(s) for s in seeds]
     if os.environ.get("RFX_PARITY_RECORDS"):        # per-pair records for profiles/ (evidence scripts)
         cmd += ["--records", os.environ["RFX_PARITY_RECORDS"] + "_" + cfg + ".json"]
+    env = dict(os.environ, OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0")     # many oracle workers side by side: no spin-waiting
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget + 120)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget + 120, env=env)
         for ln in reversed(out.stdout.splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)

@@ -632,7 +632,10 @@ def sweep(cfg_name, dump_dir, seeds, H, W, workers=None, threads=8, budget_s=Non
     import multiprocessing as mp
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(threads, cores))
-    workers = workers or max(1, cores // threads)
+    # one OpenMP thread per PHYSICAL core: on the GPU box (2 x 64 cores, SMT: 256 logical CPUs) 32 workers x 8 spinning threads
+    # ran each oracle pair 4x slower than 2 workers x 4 threads do on an 8-core host
+    phys = cores // 2 if cores >= 64 else cores
+    workers = workers or max(1, phys // threads)
     jobs = [(cfg_name, s, H, W, os.path.join(dump_dir, "pair_%d.npz" % s)) for s in seeds]
     loop = "loop" in CONFIGS[cfg_name]
     mstd = MULTIH_MATCH_STD if loop else None

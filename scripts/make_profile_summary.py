@@ -27,9 +27,11 @@ def bench_log(name, cmd, out):
             f.write("---- stderr ----\n" + "".join(l for l in open(err) if "amdgpu.ids" not in l))
 
 
-bench_log("bench", "python bench.py --steps 20 --warmup 5", RND + "_bench_default.log")
-for c in "2345":
+bench_log("bench", "python bench.py --gpus 1 --steps 20 --warmup 5", RND + "_bench_default.log")
+for c in ("2", "3", "4", "5", "qs"):
     bench_log("bench_c" + c, "python bench.py --config %s --steps 5 --warmup 2" % c, RND + "_bench_config%s.log" % c)
+bench_log("bench_c3_2ranks_1gpu_gloo", "RFX_BENCH_BACKEND=gloo RFX_BENCH_DEVICE=0 python bench.py --config 3 --gpus 2 --steps 3 --warmup 1 --batch 32 "
+          "--no-cpu-baseline  (two ranks rehearsed on ONE GPU)", RND + "_bench_config3_2ranks_on_1gpu_gloo.log")
 
 for c in ("qs", "2", "3", "4", "5"):
     p = os.path.join(src, "kernel_stats_%s.csv" % c)
@@ -42,7 +44,7 @@ for c in ("qs", "2", "3", "4", "5"):
             name, rest = line.rsplit(",", 7)[0], line.rsplit(",", 7)[1:]
             f.write(name.replace(",", " ") + "," + ",".join(rest[:6]) + "\n")
 
-for pm_name, pm_cfg in (("pmc_summary.json", "qs"), ("pmc_summary_config5.json", "config5")):
+for pm_name, pm_cfg in (("pmc_summary.json", "qs"), ("pmc_summary_config3.json", "config3"), ("pmc_summary_config5.json", "config5")):
   pm = os.path.join(src, pm_name)
   if os.path.exists(pm):
       raw = json.load(open(pm))
@@ -77,6 +79,10 @@ for cfg, n in (("ev", 64), ("qs", 64)):
     p = os.path.join(src, "parity_sweep_%s_%d.json" % (cfg, n))
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_parity_sweep_%s_%dpairs.json" % (RND, cfg, n)))
+for name, out in (("bench_parity_records_ev_loop.json", "_bench_parity_records_config3.json"), ("bench_parity_records_qs.json", "_bench_parity_records_qs.json")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, RND + out))
 for name, out in (("conv_bench_all.txt", "_conv_bench.txt"), ("mfma_mix.txt", "_mfma_mix.txt")):
     p = os.path.join(src, name)
     if os.path.exists(p):
