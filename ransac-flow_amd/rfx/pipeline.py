@@ -247,6 +247,8 @@ class AlignPipeline:
             nstream = 1          # per-launch event timing: overlapping streams would charge one kernel with another's time
         main = torch.cuda.current_stream(self.dev)
         if nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
+            # (stream priorities for the largest levels -- the critical path of a small-batch pass -- were measured: 7.7 ->
+            # 9.1-9.2 ms with one or two high-priority queues; all queues stay equal)
             self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstream)]
         ft_raw = None
         ready = torch.cuda.Event()
