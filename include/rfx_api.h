@@ -39,10 +39,27 @@ extern "C" {
 const char* rfx_version(void);
 
 /* ABI revision of this header: bumped whenever an entry point changes its signature or its operand layout (round 2:
- * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights).  A binding
+ * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
+ * round kernels, two-direction correlation, grouped launches).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 3
+#define RFX_ABI_VERSION 4
 int rfx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped launches: ONE launch per kernel instance for the same layer of several INDEPENDENT problems of different
+ * sizes.  A single pair runs the trunk on 8 images of 8 sizes (7 pyramid levels + the target,
+ * quick_start/coarseAlignFeatMatch.py:92-125): layer by layer that is 8 launches of 2-150 workgroups on 256 CUs, bound
+ * by one workgroup lifetime per layer AND level.  Between rfx_group_begin() and rfx_group_end() the convolution entry
+ * points (rfx_conv2d_f32, rfx_conv3x3_f32, rfx_conv3x3_conv1x1_f32, rfx_stem_conv7x7_maxpool_f32) validate and RECORD
+ * their launch instead of issuing it; rfx_group_end(stream) issues, per kernel instance, one launch whose blockIdx.y
+ * selects the problem (up to 8 per launch).  The device code of a problem is the single launch's, so results are
+ * bit-identical.  Recording is per host thread, groups do not nest, every other entry point launches immediately;
+ * the caller keeps all operands alive until rfx_group_end and records only mutually independent calls.
+ * rfx_group_abort() drops a recording without launching.
+ * ------------------------------------------------------------------------------------------ */
+int rfx_group_begin(void);
+int rfx_group_end(void* stream);
+int rfx_group_abort(void);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (ResNet-50 conv1..layer3 trunk: model/resnet50.py:68-104,112-169 as used by

@@ -22,6 +22,7 @@
 // along the pixel dimension (the MFMA C/D column index is the pixel).
 #include "common.h"
 #include "conv_epilogue.h"
+#include "group.h"
 #include <stdlib.h>
 
 struct ConvArgs {
@@ -60,7 +61,7 @@ extern "C" long long* rfx_debug_trace_ptr() { return g_trace; }
 // with one 16-byte load (the im2col row of a 1x1 convolution is the NCHW plane itself), mirroring the weight side:
 // 4x fewer gather instructions.
 template <int TM, int TN, bool ONE, bool WS, bool VECB>
-__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsigned bx) {
     constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, KK = BK / 2;  // KK k-pairs per step
     constexpr int B_NI = BN / 8;                                      // gathered values per thread per step
     constexpr int A_MG = BM / 4;                                        // groups of 4 consecutive m per tile
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
     // XCD-aware bijective remap: each XCD (observed: block b -> XCD b%8) walks a contiguous chunk of
     // the tile space, m-tile fastest, so the blocks that share one im2col pixel tile run on one L2.
     const int nwg = a.tilesM * a.tilesP;
-    int bid = blockIdx.x;
+    int bid = (int)bx;
     RFX_STAMP(0);
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
@@ -335,6 +336,24 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel
 #endif
 }
 
+template <int TM, int TN, bool ONE, bool WS, bool VECB>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_kernel(ConvArgs a) {
+    conv2d_mfma_body<TM, TN, ONE, WS, VECB>(a, blockIdx.x);
+}
+
+// grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
+template <int TM, int TN, bool ONE, bool WS, bool VECB>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv2d_mfma_group_kernel(RfxGroupArgs<ConvArgs> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv2d_mfma_body<TM, TN, ONE, WS, VECB>(g.p[y], blockIdx.x);
+}
+
+template <int TM, int TN, bool ONE, bool WS, bool VECB>
+static int conv_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<ConvArgs>(conv2d_mfma_group_kernel<TM, TN, ONE, WS, VECB>, WS ? 512 : 256, blob, gx, n, st);
+}
+
 template <int TM, int TN, bool ONE, bool WS, bool VECB = false>
 static int launch_conv(ConvArgs& a, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -345,6 +364,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 #ifdef RFX_TRACE
     a.trace = g_trace;
 #endif
+    if (rfx_group_recording()) return rfx_group_record(&conv_group_launch<TM, TN, ONE, WS, VECB>, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL((conv2d_mfma_kernel<TM, TN, ONE, WS, VECB>), dim3((unsigned)nwg), dim3(WS ? 512 : 256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

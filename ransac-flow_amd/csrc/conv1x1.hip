@@ -19,6 +19,7 @@
 // k runs in the same pairs and the same order as in conv.hip: bit-identical results.
 #include "common.h"
 #include "conv_epilogue.h"
+#include "group.h"
 
 // experiments only (scripts/ubench/conv_bench.py, make c1dbgN): RFX_C1_DBG removes pieces of the main loop to price them
 //   1 no LDS stores in the loop   2 no global loads in the loop   3 neither   4 neither, no barrier   6 no output stores
@@ -42,7 +43,7 @@ struct C1Args {
 // the epilogue of the tile before.  A tile's folded-BN vectors live in a double-buffered LDS pair (a fast wavefront may be
 // one tile ahead of a slow one's epilogue).
 template <int TM, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
+__device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsigned bx, const unsigned gsz) {
     constexpr int BM = 64 * TM, BN = 128, BK = 32;
     constexpr int A_C4 = BM / 4;                 // float4 per A row: 32 / 16
     constexpr int A_RS = 256 / A_C4;             // rows covered by one round of the 256 threads: 8 / 16
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
         }
     };
 
-    int v = blockIdx.x;
+    int v = (int)bx;
     int m0; long long n0;
     tile_origin(v, m0, n0);
     const float *wsrc, *bsrc;
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
     const float* arow = &As[0][lrow][wm * TM * 32 + lcol];
     const float* brow_p = &Bs[0][lrow][wn * 64 + lcol];
     int g = 0;                                    // global step counter of this workgroup: LDS buffer = g & 1
-    for (int it = 0; v < nwg; ++it, v += gridDim.x) {
+    for (int it = 0; v < nwg; ++it, v += (int)gsz) {
         // the workgroup's next tile (none: this tile again -- its loads are harmless and nobody consumes them)
-        const int vn = v + (int)gridDim.x < nwg ? v + (int)gridDim.x : v;
+        const int vn = v + (int)gsz < nwg ? v + (int)gsz : v;
         int m0n; long long n0n;
         tile_origin(vn, m0n, n0n);
         const float *wsrc_n, *bsrc_n;
@@ -230,6 +231,24 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
 }
 
 template <int TM, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
+    conv1x1_kmajor_body<TM, VEC>(a, blockIdx.x, gridDim.x);
+}
+
+// grouped form (group.h): blockIdx.y = problem; a problem's persistent workgroups stride by that problem's own grid
+template <int TM, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv1x1_kmajor_group_kernel(RfxGroupArgs<C1Args> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv1x1_kmajor_body<TM, VEC>(g.p[y], blockIdx.x, g.gx[y]);
+}
+
+template <int TM, bool VEC>
+static int c1_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<C1Args>(conv1x1_kmajor_group_kernel<TM, VEC>, 256, blob, gx, n, st);
+}
+
+template <int TM, bool VEC>
 int launch_1x1(C1Args& a, hipStream_t st) {
     a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
     a.tilesP = (int)((a.P + 127) / 128);
@@ -243,6 +262,7 @@ int launch_1x1(C1Args& a, hipStream_t st) {
         slots = (2 * cus + 7) / 8 * 8;
     }
     const unsigned grid = (unsigned)(nwg < slots ? (nwg + 7) / 8 * 8 : slots);
+    if (rfx_group_recording()) return rfx_group_record(&c1_group_launch<TM, VEC>, &a, sizeof(a), grid);
     hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3(grid), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

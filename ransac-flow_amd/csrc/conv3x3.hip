@@ -22,6 +22,7 @@
 // result is bit-identical to the implicit-GEMM kernel.
 #include "common.h"
 #include "conv_epilogue.h"
+#include "group.h"
 
 namespace {
 
@@ -74,8 +75,8 @@ extern "C" long long* rfx_debug_trace_ptr();
 // intermediate never touches HBM, the expansion's launch, prologue and B-operand staging disappear, and its residual /
 // output traffic overlaps the MFMA-bound 3x3 main loops of the neighbouring workgroups.  k order and pairing of the
 // expansion are those of conv.hip: bit-identical to the two separate kernels.
-template <int TM, int PTC, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
+template <int TM, int PTC, bool FUSE>
+__device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsigned bx) {
     using G = Patch<PTC>;
     constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
     constexpr int NB = (CH * PR * PC + 255) / 256;   // patch elements per thread (6; 7 for the 32x4 patch)
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 
     const int tilesP = a.tilesH * a.tilesW;     // tilesH counts patch rows of the whole stack
     const int nwg = a.tilesM * tilesP;
-    int bid = blockIdx.x;
+    int bid = (int)bx;
     RFX_STAMP(0);
     {   // XCD-aware bijective remap, m-tile fastest: the workgroups sharing one input patch sit on one L2
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
@@ -347,6 +348,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
 #endif
 }
 
+template <int TM, int PTC, bool FUSE = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
+    conv3x3_direct_body<TM, PTC, FUSE>(a, blockIdx.x);
+}
+
+// grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
+template <int TM, int PTC, bool FUSE = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_group_kernel(RfxGroupArgs<C3Args> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv3x3_direct_body<TM, PTC, FUSE>(g.p[y], blockIdx.x);
+}
+
+template <int TM, int PTC, bool FUSE>
+static int c3_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<C3Args>(conv3x3_direct_group_kernel<TM, PTC, FUSE>, 256, blob, gx, n, st);
+}
+
 }  // namespace
 
 // Patch shape for a batch of N H x W maps stacked as above: the fewest padded pixels (ties: the widest, whose row segments
@@ -376,6 +395,7 @@ static int launch_direct(C3Args& a, hipStream_t st) {
     // 32-bit byte offsets inside the images one input patch can touch
     const long long span = (G::PR + a.H) / (a.H + 1) + 1;
     if (span * a.Cin * a.H * a.W * 4 > 0xffffffffLL) return RFX_E_LIMIT;
+    if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

@@ -14,6 +14,7 @@
 //      outputs from a 6x6 window (border blocks take the per-output path that reflects indices).
 // Only the /2 map is written: HBM traffic per image drops from (3 + 64 + 64 + 16) to (3 + 16) full-resolution planes.
 #include "common.h"
+#include "group.h"
 
 namespace {
 
@@ -212,7 +213,7 @@ struct Stem7Args {
     int N, H, W, Cout, Mpad, Hc, Wc, Hp, Wp, tilesH, tilesW, chGroups;
 };
 
-__global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a) {
+__device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, const unsigned bx) {
     constexpr int TH = r50::TH, TW = r50::TW, CR = r50::CR, CC = r50::CC, PR = r50::PR, PCW = r50::PCW, PHALF = r50::PHALF,
                   PST = r50::PST, CST = r50::CST, NPX = r50::NPX, NSUB = r50::NSUB, KKS = r50::KKS, MCH = r50::MCH;
     using r50::koff;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = lane >> 5, lcol = lane & 31;
-    int bid = blockIdx.x;
+    int bid = (int)bx;
     const int cg = bid % a.chGroups; bid /= a.chGroups;
     const int tw = bid % a.tilesW; bid /= a.tilesW;
     const int th = bid % a.tilesH;
@@ -325,6 +326,21 @@ __global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a)
     }
 }
 
+__global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_kernel(Stem7Args a) {
+    stem7_conv_maxpool_body(a, blockIdx.x);
+}
+
+// grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
+__global__ __launch_bounds__(256, 2) void stem7_conv_maxpool_group_kernel(RfxGroupArgs<Stem7Args> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    stem7_conv_maxpool_body(g.p[y], blockIdx.x);
+}
+
+static int stem7_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<Stem7Args>(stem7_conv_maxpool_group_kernel, 256, blob, gx, n, st);
+}
+
 }  // namespace
 
 extern "C" int rfx_stem_conv3x3_maxblur_f32(const float* in, const float* wT, const float* scale, const float* shift,
@@ -355,6 +371,7 @@ extern "C" int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, co
     a.tilesH = (a.Hp + r50::TH - 1) / r50::TH; a.tilesW = (a.Wp + r50::TW - 1) / r50::TW; a.chGroups = Cout / r50::MCH;
     const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    if (rfx_group_recording()) return rfx_group_record(&stem7_group_launch, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL(stem7_conv_maxpool_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

@@ -91,6 +91,34 @@ class Profiler:
         return e1
 
 
+class launch_group:
+    """``with ops.launch_group(device):`` -- the convolution ops issued inside are RECORDED by the library and launched at exit
+    as ONE launch per kernel instance (rfx_group_begin / rfx_group_end: blockIdx.y selects the problem).  For the same layer
+    of several independent inputs of different sizes (the 8 images of a single pair's trunk pass); the calls inside must not
+    depend on each other, and their tensors must stay referenced until the block ends (the returned outputs do).  Not used
+    under a Profiler (per-launch events are meaningless for a recorded launch)."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+
+    def __enter__(self):
+        _lib.check(_lib.load().rfx_group_begin(), "rfx_group_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        lib = _lib.load()
+        if et is not None:
+            lib.rfx_group_abort()
+            return False
+        if self.dev.index is not None and self.dev.index != torch.cuda.current_device():
+            with torch.cuda.device(self.dev):
+                rc = lib.rfx_group_end(_stream(self.dev))
+        else:
+            rc = lib.rfx_group_end(_stream())
+        _lib.check(rc, "rfx_group_end")
+        return False
+
+
 def _dev(t, name="tensor", dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s must be a torch.Tensor" % name)

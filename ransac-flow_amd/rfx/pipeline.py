@@ -241,21 +241,46 @@ class AlignPipeline:
         # Default: one stream per level for small batches (B <= 4: a layer of one level has too few workgroups to fill 256 CUs
         # -- a single 480x640 pair drops from 15.9 to 10.6 ms), one stream otherwise (at batch 64 two streams give +2 %, but
         # overlapping launches distort the per-kernel event timing bench.py's roofline is computed from).
+        # (measured, coarse stage of 480x640 pairs: B = 1 7.73 -> 6.83 ms, B = 2 10.15 -> 9.99 ms, B = 4 16.7 -> 18.3 ms: from four
+        # pairs on the per-level batches are large enough for the 8-stream form to win)
+        grouped = (B <= 2 and os.environ.get("RFX_GROUPED", "1") != "0" and ops.Profiler.active() is None
+                   and not os.environ.get("RFX_TRUNK_STREAMS"))
+        ft_raw = None
+        if grouped:
+            # Small batches: the 8 images of a pair (7 pyramid levels + target) have 8 different sizes, so a layer is 8 launches
+            # of 2-150 workgroups on 256 CUs and the pass is bound by one workgroup lifetime per layer AND level.  All levels
+            # go through the trunk layer by layer with ONE grouped launch per kernel instance and layer (nets.forward_group:
+            # blockIdx.y selects the image); bit-identical to the per-level passes.
+            xs, shared = [], None
+            for i, x in enumerate(prep["src"]):
+                if shared is None and x.shape == tgt.shape:
+                    xs.append(torch.cat((x, tgt), dim=0))           # the scale-1 level and the target: one problem of 2B images
+                    shared = i
+                else:
+                    xs.append(x)
+            if shared is None:
+                xs.append(tgt)
+            fs = self.trunk.forward_group(xs)
+            for i, (r, c) in enumerate(dims):
+                f = fs[i][:B] if i == shared else fs[i]
+                ops.l2norm(f, out=featA[:, :, offs[i]:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
+            ft_raw = fs[shared][B:] if shared is not None else fs[-1]
         env = os.environ.get("RFX_TRUNK_STREAMS")
         nstream = max(1, int(env)) if env else (len(prep["src"]) if B <= 4 else 1)
         if ops.Profiler.active() is not None:
             nstream = 1          # per-launch event timing: overlapping streams would charge one kernel with another's time
         main = torch.cuda.current_stream(self.dev)
-        if nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
+        if not grouped and nstream > 1 and (getattr(self, "_streams", None) is None or len(self._streams) != nstream):
             # (stream priorities for the largest levels -- the critical path of a small-batch pass -- were measured: 7.7 ->
             # 9.1-9.2 ms with one or two high-priority queues; all queues stay equal)
             self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstream)]
-        ft_raw = None
         ready = torch.cuda.Event()
-        if nstream > 1:
+        if nstream > 1 and not grouped:
             ready.record(main)
         done = []
         for i, (x, (r, c)) in enumerate(zip(prep["src"], dims)):
+            if grouped:
+                break
             st = self._streams[i % nstream] if nstream > 1 else main
             with torch.cuda.stream(st):
                 if nstream > 1:
@@ -274,7 +299,7 @@ class AlignPipeline:
                     done.append(ev)
         for ev in done:
             main.wait_event(ev)
-        if ft_raw is not None and nstream > 1:
+        if ft_raw is not None and nstream > 1 and not grouped:
             ft_raw.record_stream(main)
         ft = ops.l2norm(ft_raw if ft_raw is not None else self.trunk(tgt))
         rt, ct = ft.shape[2], ft.shape[3]

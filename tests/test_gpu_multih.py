@@ -170,7 +170,12 @@ def test_graphed_trunk_pass_equals_the_eager_pass(dev, monkeypatch):
                          device=dev)
     preps = [pipe.prepare([synth.make_pair(128, 160, seed=s)]) for s in (1, 2, 3)]
     monkeypatch.setenv("RFX_GRAPH", "0")
-    eager = [pipe.features(p) for p in preps]
+    monkeypatch.setenv("RFX_GROUPED", "0")
+    eager = [pipe.features(p) for p in preps]              # one launch per layer AND level, 8 streams: the reference form
+    monkeypatch.setenv("RFX_GROUPED", "1")
+    grouped = [pipe.features(p) for p in preps]            # one grouped launch per kernel instance and layer (blockIdx.y = image)
+    for got, ref in zip(grouped, eager):
+        assert torch.equal(got["featA"], ref["featA"]) and torch.equal(got["featB"], ref["featB"])
     monkeypatch.setenv("RFX_GRAPH", "1")
     first = pipe.features(preps[0])                        # first sighting: eager
     assert not getattr(pipe, "_graphs", {})
@@ -274,3 +279,33 @@ def test_lock_step_driver_with_hopeless_pairs(dev):
     pipe.reseed(11); a = pipe.multi_h_batched(prep, maxCoarse=2, It_bg=bg)
     pipe.reseed(11); b = pipe.multi_h_batched(prep, maxCoarse=2, It_bg=bg)
     assert [o["nbH"] for o in a] == [o["nbH"] for o in b] and all(torch.equal(x["mask"], y["mask"]) for x, y in zip(a, b))
+
+
+def test_grouped_launches_are_bit_identical_to_single_launches(dev):
+    """ops.launch_group on every convolution family the trunk uses (stem, k-major 1x1, generic 1x1 / strided, direct 3x3, fused
+    Bottleneck tail) with 5 inputs of different sizes incl. a batch of 2: the recorded launches come back as ONE launch per
+    kernel instance and must reproduce the single launches bit for bit; more than 8 problems split into several launches; an
+    exception inside the block drops the recording."""
+    from rfx import nets
+    trunk = nets.ResNet50Trunk(weights.resnet50_trunk_sd(0), dev)
+    g = torch.Generator().manual_seed(3)
+    sizes = [(1, 96, 128), (1, 80, 112), (2, 64, 96), (1, 48, 80), (1, 112, 144)]
+    xs = [torch.randn(n, 3, h, w, generator=g).to(dev) for n, h, w in sizes]
+    ref = [trunk(x) for x in xs]
+    got = trunk.forward_group(xs)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # 11 problems of one kernel instance: 8 + 3
+    blk = trunk.blocks[0]
+    ys = [ops.stem_conv7_maxpool(x, trunk.conv1) for x in xs] * 2 + [ops.stem_conv7_maxpool(xs[0], trunk.conv1)]
+    single = [blk["c1"](y) for y in ys]
+    with ops.launch_group(dev):
+        many = [blk["c1"](y) for y in ys]
+    for a, b in zip(many, single):
+        assert torch.equal(a, b)
+    # an error inside the block aborts the recording; the next launch is immediate again
+    with pytest.raises(ValueError):
+        with ops.launch_group(dev):
+            blk["c1"](ys[0])
+            raise ValueError("boom")
+    assert torch.equal(blk["c1"](ys[0]), single[0])
