@@ -21,6 +21,32 @@ struct Recorder {
     std::vector<Pending> buckets;  // one per kernel instance, in first-seen order
 };
 thread_local Recorder g_rec;
+
+// The kernel instances of one group are independent: the second and third run on side streams forked from / joined to the
+// caller's stream with events (also inside a HIP-graph capture, where this becomes a fork/join of the captured graph).
+constexpr int NSIDE = 2;
+struct SidePool {
+    int dev = -1;
+    hipStream_t s[NSIDE];
+    hipEvent_t fork, join[NSIDE];
+};
+thread_local SidePool g_pool;
+
+bool side_pool_ready() {
+    static const bool on = !(getenv("RFX_GROUP_STREAMS") && atoi(getenv("RFX_GROUP_STREAMS")) == 0);
+    if (!on) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (g_pool.dev == dev) return true;
+    if (g_pool.dev >= 0) return false;                      // one device per host thread: others fall back to the serial form
+    for (int i = 0; i < NSIDE; ++i) {
+        if (hipStreamCreateWithFlags(&g_pool.s[i], hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    if (hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming) != hipSuccess) return false;
+    g_pool.dev = dev;
+    return true;
+}
 }  // namespace
 
 bool rfx_group_recording() { return g_rec.on; }
@@ -61,14 +87,34 @@ extern "C" int rfx_group_end(void* stream) {
         }
         fprintf(stderr, "\n");
     }
+    hipStream_t main = rfx_stream(stream);
+    const bool fork = g_rec.buckets.size() > 1 && side_pool_ready();
+    if (fork && hipEventRecord(g_pool.fork, main) != hipSuccess) rc = RFX_E_ARG;
+    bool used[NSIDE] = {false, false};
+    int bi = 0;
     for (auto& b : g_rec.buckets) {
+        hipStream_t st = main;
+        if (fork && bi > 0) {
+            const int k = (bi - 1) % NSIDE;
+            st = g_pool.s[k];
+            if (!used[k]) {
+                if (hipStreamWaitEvent(st, g_pool.fork, 0) != hipSuccess) rc = RFX_E_ARG;
+                used[k] = true;
+            }
+        }
         const int n = (int)b.gx.size();
         for (int i = 0; i < n && rc == RFX_OK; i += RFX_MAX_GROUP) {
             const int m = n - i < RFX_MAX_GROUP ? n - i : RFX_MAX_GROUP;
-            rc = b.fn(b.blob.data() + (size_t)i * b.arg_size, b.gx.data() + i, m, rfx_stream(stream));
+            rc = b.fn(b.blob.data() + (size_t)i * b.arg_size, b.gx.data() + i, m, st);
         }
         if (rc != RFX_OK) break;
+        ++bi;
     }
+    for (int k = 0; k < NSIDE; ++k)                         // join: always, also after an error (a capture must not end forked)
+        if (used[k]) {
+            if (hipEventRecord(g_pool.join[k], g_pool.s[k]) != hipSuccess || hipStreamWaitEvent(main, g_pool.join[k], 0) != hipSuccess)
+                if (rc == RFX_OK) rc = RFX_E_ARG;
+        }
     g_rec.buckets.clear();
     return rc;
 }

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "group.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -373,6 +374,10 @@ static int c3_group_launch(const void* blob, const unsigned* gx, int n, hipStrea
 // measured on equal work its 16x8 patch is ~9 % and its 32x4 patch ~40 % slower than 8x16, while the plain 3x3 kernel is
 // indifferent (scripts/ubench/conv_bench.py on the 25x33 ... 112x148 maps of the pyramid) -- hence the weights.
 int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
+    // grouped launches (group.h): ONE patch shape for every problem of the group, so that a layer is one launch and not
+    // one per shape -- the group is latency-bound, a few padded pixels on the small maps cost less than a serial launch
+    static const int uniform = getenv("RFX_GROUP_UNIFORM") ? atoi(getenv("RFX_GROUP_UNIFORM")) : 1;
+    if (uniform && rfx_group_recording()) return 16;
     int best = 16;
     long long best_cost = -1;
     for (int pc = 16; pc >= 4; pc >>= 1) {
