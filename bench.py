@@ -418,6 +418,13 @@ def rooflines(prof, elapsed, rank):
                "per_direction_accounting": {"bytes_per_launch": pb, "achieved": round(pb / cd / 1e9, 1), "frac": round(pb / cd / 1e9 / PEAK_HBM_GBS, 4),
                                             "note": "SURVEY 8d's (2C+49)*4 B per pair-direction x the 2 directions one launch produces"},
                "traffic_note": "PMC per-launch traffic of this kernel: profiles/ (static, separate --pmc passes)"}
+        # the rounds of the multi-homography loop shrink the batch (64, 64, ~40, ... active pairs: the late launches are 100-160
+        # workgroups on 256 CUs); the launches over the FULL batch separately
+        top = max(x[0] for x in prof.corr_bidir)
+        full = [x for x in prof.corr_bidir if x[0] == top]
+        fd = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1 in full) / len(full)
+        bid["full_batch_launches"] = {"launches": len(full), "bytes_per_launch": top, "avg_launch_us": round(fd * 1e6, 2),
+                                      "achieved": round(top / fd / 1e9, 1), "frac": round(top / fd / 1e9 / PEAK_HBM_GBS, 4)}
         if corr is None:
             corr = bid
         else:
