@@ -34,6 +34,7 @@ struct C1Args {
     int Cin, HW, Cout, act, Mpad;
     long long P;   // N*HW
     int tilesM, tilesP;
+    unsigned stagger;   // common.h: rfx_stagger
 };
 
 // Persistent form: gridDim.x (= 2 workgroups per CU, a multiple of 8) workgroups walk the output tiles v = blockIdx.x,
@@ -101,6 +102,7 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
         }
     };
 
+    rfx_stagger(a.stagger, bx, gsz);
     int v = (int)bx;
     int m0; long long n0;
     tile_origin(v, m0, n0);
@@ -262,6 +264,8 @@ int launch_1x1(C1Args& a, hipStream_t st) {
         slots = (2 * cus + 7) / 8 * 8;
     }
     const unsigned grid = (unsigned)(nwg < slots ? (nwg + 7) / 8 * 8 : slots);
+    static const unsigned stagger = rfx_stagger_env("RFX_C1_STAGGER", "RFX_C1_STAGGER_MODE");
+    a.stagger = (rfx_group_recording() || (int)grid < slots) ? 0u : stagger;      // only when every CU holds its two workgroups
     if (rfx_group_recording()) return rfx_group_record(&c1_group_launch<TM, VEC>, &a, sizeof(a), grid);
     hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3(grid), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();

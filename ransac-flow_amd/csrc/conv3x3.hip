@@ -54,6 +54,7 @@ struct C3Args {
     // FUSE: the 1x1 expansion that follows (Bottleneck conv3 + bn3 + residual + ReLU, model/resnet50.py:77-79,99-103)
     const float* wT3; const float* scale3; const float* shift3;
     int Cexp, Mpad3, act3;
+    unsigned stagger;   // common.h: rfx_stagger
 #ifdef RFX_TRACE
     long long* trace;
 #endif
@@ -97,6 +98,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
     const int tilesP = a.tilesH * a.tilesW;     // tilesH counts patch rows of the whole stack
     const int nwg = a.tilesM * tilesP;
     int bid = (int)bx;
+    rfx_stagger(a.stagger, bx, 512u);
     RFX_STAMP(0);
     {   // XCD-aware bijective remap, m-tile fastest: the workgroups sharing one input patch sit on one L2
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
@@ -400,6 +402,9 @@ static int launch_direct(C3Args& a, hipStream_t st) {
     // 32-bit byte offsets inside the images one input patch can touch
     const long long span = (G::PR + a.H) / (a.H + 1) + 1;
     if (span * a.Cin * a.H * a.W * 4 > 0xffffffffLL) return RFX_E_LIMIT;
+    static const unsigned stagger = FUSE ? rfx_stagger_env("RFX_C3F_STAGGER", "RFX_C3F_STAGGER_MODE")
+                                         : rfx_stagger_env("RFX_C3_STAGGER", "RFX_C3_STAGGER_MODE");
+    a.stagger = (rfx_group_recording() || nwg < 1024) ? 0u : stagger;
     if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();

@@ -37,6 +37,9 @@ def find_nbH(pairID, flowList):
 
 
 def _to_dev(a, device):
+    """numpy array (the saved .npy files) or tensor (the views of an ops.MultiHRecords: no host round trip) -> float32 on ``device``."""
+    if torch.is_tensor(a):
+        return a.to(device=device, dtype=torch.float32).contiguous()
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.float32))).to(device)
 
 

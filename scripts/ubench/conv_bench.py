@@ -45,6 +45,9 @@ SHAPES = {
     "s2_128_128_120x160": (128, 128, 120, 160, 128, 3, 2, 0),  # layer2.0 conv2 (stride 2): generic implicit-GEMM kernel
     "ds_256_512_s2_120x160": (128, 256, 120, 160, 512, 1, 2, 0),   # layer2.0 downsample (1x1 stride 2)
     "head49_512_60x80": (64, 49, 60, 80, 512, 3, 1, 0),         # NetFlowCoarse conv1 (Cin = 49)
+    "tail64_240x320": (64, 64, 240, 320, 64, 3, 1, 256),        # config 3, scale-2 level: the largest fused tail of the step
+    "pw256_1024_60x80_res": (64, 256, 60, 80, 1024, 1, 1, 0, True),   # config 3, scale-2 level: layer3 conv3 + residual
+    "pw64_256_240x320_res": (64, 64, 240, 320, 256, 1, 1, 0, True),   # layer1 conv3 un-fused (HBM-bound: 14 FLOP/B)
 }
 
 

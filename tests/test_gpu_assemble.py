@@ -157,3 +157,39 @@ def test_getresults_dropin_reads_the_on_disk_format(dev, tmp_path):
     f = getResults.kitti.getFlow_all(3, str(kit), 3, "Finetune", None, True, grid_org, 0.25, 0.01, True)
     rf, _, _ = restate.assemble_flow_kitti(t(fd2), t(fd), t(pm), t(md), (hd * 8, wd * 8), 0.25, True, 0.01, True)
     _close(f, rf, "kitti drop-in", max_bad=0.01)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_online_records_feed_offline_assembly_like_the_reference(dev, tag):
+    """SURVEY rows 8f1 -> 8f3 in one piece: the device multi-homography driver fills its per-pair record
+    (evaluation/evalHpatch/evaluation.py:254-260 saves exactly these arrays), rfx.assemble composes the final flow from the
+    record's views (evalHpatch/getResults.py:48-80), and the result is compared with the oracle's assembly of the arrays the
+    REFERENCE's own loop produced for the same pair and index draws (tests/golden/multi_h.npz).  Owner changes at pixels whose
+    score sits at the threshold are counted, everything else must agree to 1e-3 (normalised flow units)."""
+    from rfx import weights
+    from rfx.pipeline import AlignPipeline
+    g = np.load(os.path.join(GOLD, "multi_h.npz"))
+    seed, maxCoarse, th, draw_seed = g["%s_cfg" % tag]
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=float(g["match_std"])))
+    I1, I2 = synth.make_pair(240, 320, seed=int(seed), homography=True)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev, draw="host")
+    prep = pipe.prepare([(I1, I2)])
+    h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
+    R = ops.MultiHRecords(1, h // 8, w // 8, dev)
+    torch.manual_seed(int(draw_seed))
+    pipe.multi_h_batched(prep, maxCoarse=int(maxCoarse), maskRegionTh=float(th), records=R, want_lists=False)
+    nbH, status, Hs, f8, m8, _ = R.views()
+    nb = int(nbH[0])
+    assert int(status[0]) == 0 and nb == int(g["%s_nb" % tag])
+    t = torch.from_numpy
+    for a_th, multiH, cycle in ((0.5, True, False), (0.3, True, True), (0.5, False, False)):
+        fg, mg, b = assemble.assemble(f8[0, :nb], Hs[0, :nb], m8[0, :nb], (h, w), a_th,
+                                      multiH, cycle, dev)
+        rf, rm, rb = restate.assemble_flow(t(g["%s_flowDown8" % tag]), t(g["%s_H" % tag]), t(g["%s_matchDown8" % tag]), (h, w),
+                                           a_th, multiH, cycle)
+        same = (b.cpu() == rb)
+        assert float((~same).float().mean()) < 5e-3, (a_th, multiH, cycle, float((~same).float().mean()))
+        d = (fg.cpu() - rf).abs().amax(dim=3)
+        bad = float(((d > 1e-3) & same).float().mean())
+        assert bad < 5e-3, (a_th, multiH, cycle, bad, float(d.max()))
