@@ -196,6 +196,10 @@ def parse_args():
     ap.add_argument("--host-prep", action="store_true",
                     help="build the LANCZOS pyramid with PIL on the host before the timed region (default: raw uint8 images "
                          "resident in HBM, pyramid + ToTensor + Normalize on the device inside the timed step)")
+    ap.add_argument("--pcie", action="store_true",
+                    help="PCIe-inclusive variant (configs qs / 3 / 4; never the headline): the raw uint8 images start in pinned HOST "
+                         "memory and are uploaded inside every timed step, and the step ends with the result records copied back to "
+                         "pinned host memory")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal WITHOUT a GPU: the real rank code (self-spawn, process group, barriers, all_gather, "
                          "max-over-ranks timing, JSON) around a CPU stand-in step that fabricates records; value is meaningless")
@@ -225,6 +229,25 @@ def self_spawn(args):
 # ------------------------------------------------------------------------------------------------ workloads
 
 
+def _pinned(raw):
+    """--pcie: the step's input as the boundary hands it over -- raw uint8 images in pinned host memory."""
+    return tuple(t.cpu().pin_memory() for t in raw)
+
+
+def _upload(raw_h, dev):
+    return tuple(t.to(dev, non_blocking=True) for t in raw_h)
+
+
+def _download(rec, keep):
+    """--pcie: the records back in pinned host memory (asynchronous copy on the step's stream; the timed region ends with a
+    synchronize).  The device tensor is returned for the gather."""
+    if "buf" not in keep or keep["buf"].shape != rec.shape:
+        import torch
+        keep["buf"] = torch.empty(rec.shape, dtype=rec.dtype).pin_memory()
+    keep["buf"].copy_(rec, non_blocking=True)
+    return rec
+
+
 def build_workload(args, dev, rank, world):
     """Returns (step() -> (B, width) float32 record tensor on ``dev``, meta dict, extras for the parity leg).  Record columns:
     meta["col"] = dict(status=..., nbh=... or None, rank=...)."""
@@ -247,10 +270,14 @@ def build_workload(args, dev, rank, world):
         prep0 = pipe.prepare(pairs) if args.host_prep else None
         fine = cfg == "qs"
 
+        raw_h, rec_h = _pinned(raw) if args.pcie else None, {}
+
         def step():
-            p = prep0 if prep0 is not None else pipe.prepare_device(*raw)
+            r = _upload(raw_h, dev) if raw_h is not None else raw
+            p = prep0 if prep0 is not None else pipe.prepare_device(*r)
             res = pipe.align_prepared(p, fine=fine)
-            return rdist.pack_records(res, rank=rank) if fine else _coarse_records(res, dev, rank)
+            rec = rdist.pack_records(res, rank=rank) if fine else _coarse_records(res, dev, rank)
+            return _download(rec, rec_h) if raw_h is not None else rec
         if fine:
             wl = ("batch of %d %dx%d pairs per GPU per step, full pipeline: ResNet-50 conv4 feat x%d scales + mutual NN + RANSAC("
                   "nbIter=%d, 4-pt DLT) + FeatureExtractor + 7x7 corr + NetFlowCoarse + grid_sample (quick_start semantics, one "
@@ -268,12 +295,14 @@ def build_workload(args, dev, rank, world):
                              draw=draw, seed=1000 + rank)
         raw = pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True) for s in seeds])
 
+        raw_h, rec_h = _pinned(raw) if args.pcie else None, {}
+
         def step():
-            prep = pipe.prepare_device(*raw)
+            prep = pipe.prepare_device(*(_upload(raw_h, dev) if raw_h is not None else raw))
             R = ops.MultiHRecords(B, prep["ItTensor"].shape[2] // 8, prep["ItTensor"].shape[3] // 8, dev, max_h=11)
             R.rec[:, 2] = float(rank)
             pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False)
-            return R.rec
+            return _download(R.rec, rec_h) if raw_h is not None else R.rec
         wl = ("BASELINE config %s as worded: batch of %d %dx%d pairs per GPU per step, each target warped by a seeded random "
               "homography; evaluation semantics (variant B, minSize %d, %d scales x2, coarseIter %d) + multi-homography loop "
               "(maxCoarse 10, maskRegionTh 0.01, lock-step over the batch, device-resident rounds) with FeatureExtractor + 7x7 corr "
@@ -518,6 +547,10 @@ def main():
                            collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
                            preprocessing="host PIL, outside the timed region" if args.host_prep else
                            "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step")}
+    if args.pcie:
+        line["config"]["pcie_inclusive"] = ("NOT the headline: raw uint8 images uploaded from pinned host memory and the result records copied "
+                                            "back to pinned host memory inside every timed step (%.1f + %.1f MB per step)"
+                                            % (2.0 * B * args.height * args.width * 3 / 1e6, out.shape[0] / world * out.shape[1] * 4 / 1e6))
     if not args.dry_run:
         if col["nbh"] is not None:
             nbh = out[:, col["nbh"]]
