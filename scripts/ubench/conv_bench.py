@@ -45,6 +45,8 @@ SHAPES = {
     "s2_128_128_120x160": (128, 128, 120, 160, 128, 3, 2, 0),  # layer2.0 conv2 (stride 2): generic implicit-GEMM kernel
     "ds_256_512_s2_120x160": (128, 256, 120, 160, 512, 1, 2, 0),   # layer2.0 downsample (1x1 stride 2)
     "head49_512_60x80": (64, 49, 60, 80, 512, 3, 1, 0),         # NetFlowCoarse conv1 (Cin = 49)
+    "stem7_960x1280": (64, 3, 960, 1280, 64, 7, 2, 0),          # ResNet stem fused with its max-pool, config 3's scale-2 level
+    "stem7_480x640": (128, 3, 480, 640, 64, 7, 2, 0),
     "tail64_240x320": (64, 64, 240, 320, 64, 3, 1, 256),        # config 3, scale-2 level: the largest fused tail of the step
     "pw256_1024_60x80_res": (64, 256, 60, 80, 1024, 1, 1, 0, True),   # config 3, scale-2 level: layer3 conv3 + residual
     "pw64_256_240x320_res": (64, 64, 240, 320, 256, 1, 1, 0, True),   # layer1 conv3 un-fused (HBM-bound: 14 FLOP/B)
@@ -81,6 +83,10 @@ def main():
             run = lambda x: ops.bottleneck_tail(x, plan, plan3, res)     # noqa: E731
             Ho, Wo = H, W
             flops = 2.0 * N * H * W * (Cout * Cin * 9 + Cexp * Cout)
+        elif k == 7 and Cin == 3:
+            Ho, Wo = plan.out_hw(H, W)
+            run = lambda x: ops.stem_conv7_maxpool(x, plan)             # noqa: E731
+            flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
         else:
             Ho, Wo = plan.out_hw(H, W)
             r1 = torch.randn(N, Cout, Ho, Wo, device=dev, generator=gd) if with_res else None

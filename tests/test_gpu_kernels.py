@@ -550,6 +550,19 @@ def test_fused_resnet_stem_equals_conv_then_maxpool(dev, shape):
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
 
 
+@pytest.mark.parametrize("cout", [32, 96, 128])
+def test_fused_resnet_stem_channel_group_passes(dev, cout):
+    """The fused stem with 1, 3 and 4 channel groups of 32: bit for bit equal to the separate kernels."""
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(2, 3, 70, 58, generator=g)
+    w = torch.randn(cout, 3, 7, 7, generator=g) / 147 ** 0.5
+    bn = dict(weight=1 + 0.3 * torch.randn(cout, generator=g), bias=0.2 * torch.randn(cout, generator=g),
+              running_mean=0.2 * torch.randn(cout, generator=g), running_var=0.5 + torch.rand(cout, generator=g))
+    plan = ops.ConvPlan(w, bn, 2, 3, ops.ACT_RELU, dev)
+    xd = x.to(dev)
+    assert torch.equal(ops.stem_conv7_maxpool(xd, plan), ops.maxpool2d(plan(xd), 3, 2, 1))
+
+
 @pytest.mark.parametrize("case", [
     # N, Cin, H, W, Cmid, Cexp, residual
     (2, 64, 30, 40, 64, 256, True),       # layer1-like, 16x8 patch
