@@ -394,6 +394,13 @@ def test_assembly_file_lookup_follows_reference():
     # a pair without saved arrays gives the reference's [] sentinels before any device work
     assert assemble.hpatch_getFlow_all(99, "/nonexistent", "/nonexistent", names, True, None, None, 0.5, 8, 8) == []
     assert assemble.corr_getFlow(99, "/nonexistent", names, "/nonexistent", "/nonexistent", True, 0.5) == ([], [])
+    # inputs: the saved .npy arrays (any float dtype) or tensors (the views of a device record, no host round trip)
+    a64 = np.arange(6, dtype=np.float64).reshape(2, 3)[:, ::2]
+    t32 = assemble._to_dev(a64, "cpu")
+    assert t32.dtype == torch.float32 and t32.is_contiguous() and torch.equal(t32, torch.tensor([[0., 2.], [3., 5.]]))
+    tv = torch.arange(12, dtype=torch.float64).reshape(3, 4)[:, 1:3]
+    t2 = assemble._to_dev(tv, "cpu")
+    assert t2.dtype == torch.float32 and t2.is_contiguous() and torch.equal(t2, tv.float())
 
 
 @pytest.mark.reference
