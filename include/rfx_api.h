@@ -89,18 +89,19 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 /* Full kernel-instance id a convolution of this geometry runs as: bits 0-1 = tile variant above, bit 2 = 1x1 specialisation, bit 3 =
  * wave-specialised form (4 MFMA + 4 loader wavefronts), bit 4 = 16-byte pixel-side loads (1x1, stride 1):
  * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints.  Bit 5 = the direct 3x3 / stride 1 / pad 1 kernel
- * conv3x3_direct_kernel<TM, PT_C> (Cin % 8 == 0), TM = 2 if bits 0-1 are 0 else 1; bits 6-7 = output patch shape
+ * conv3x3_direct_kernel<TM, PT_C> (Cin >= 8), TM = 2 if bits 0-1 are 0 else 1; bits 6-7 = output patch shape
  * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least).  Bit 10 = the k-major 1x1 / stride 1 kernel
  * conv1x1_kmajor_kernel<TM, VEC> (Cin % 32 == 0; TM = 2 - bits 0-1, VEC = bit 4).  Bit 5 set = the geometry is served by
  * rfx_conv3x3_f32 below (the host mirrors call it then); rfx_conv2d_f32 itself always runs the implicit-GEMM kernel. */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
 
-/* 3x3 / stride 1 / pad 1 convolution, Cin % 8 == 0 (ResNet Bottleneck conv2 at stride 1, model/resnet50.py:75; the
+/* 3x3 / stride 1 / pad 1 convolution, Cin >= 8 (a Cin that is not a multiple of 8 -- the 49-channel correlation volume in
+ * front of the heads -- takes ceil(Cin/8) K steps, the packed weights carrying zero rows for the missing channels) (ResNet Bottleneck conv2 at stride 1, model/resnet50.py:75; the
  * FeatureExtractor BasicBlocks, model/model.py:32-35; the NetFlowCoarse / NetMatchability stacks, model/model.py:170-181):
  * the direct kernel that stages the raw input patch in LDS.  Same epilogue and the same result, bit for bit, as
  * rfx_conv2d_f32; the weights come packed in the kernel's own LDS order so that staging is a straight copy:
  *     wP[mt][s][h][m][kk] = w[mt*128 + m, c, kh, kw]   with k = (c*3 + kh)*3 + kw = s*72 + 2*kk + h,
- *     mt < roundup(Cout,128)/128, s < Cin/8, h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout; 16-byte aligned. */
+ *     mt < roundup(Cout,128)/128, s < ceil(Cin/8), h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout and for c >= Cin; 16-byte aligned. */
 int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
                     float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 

@@ -404,7 +404,7 @@ static int conv_ws_env() {
 // output patch 128/PT_C x PT_C with PT_C = 16 / 8 / 4 for bits 6-7 = 0 / 1 / 2).
 static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct) {
     static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
-    if (allow_direct && direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 8 == 0) {
+    if (allow_direct && direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= 8) {
         const int pc = rfx_conv3x3_patch_cols(N, Hout, Wout, false), pr = 128 / pc;
         const long long tiles = (((long long)N * (Hout + 1) + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
@@ -432,7 +432,7 @@ extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, in
 extern "C" int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift,
                                const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int act,
                                void* stream) {
-    if (!in || !wP || !out || N <= 0 || Cin <= 0 || Cin % 8 != 0 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (!in || !wP || !out || N <= 0 || Cin < 8 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
     if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
     if ((long long)Cin * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
     const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true);

@@ -134,12 +134,19 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         aoff[j] = TM == 2 ? (unsigned)(L * 16) : (unsigned)((L / (A_F4 / 2)) * PLANE_B + (L % (A_F4 / 2)) * 16);
     }
     const size_t step_b = (size_t)2 * PLANE_B;                         // bytes per (tile, step)
-    const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * (a.Cin / CH) * step_b +
+    // Cin need not be a multiple of CH (the 49-channel correlation volume in front of the heads, model/model.py:213): the
+    // packed weights carry zero rows for the missing channels of the last K step, and the patch slots of those channels are
+    // zero filled (their loads point at the first channel of the step: a valid address) -- the sum gains exact zeros only.
+    const int nsteps = (a.Cin + CH - 1) / CH;
+    const int crem = a.Cin - (nsteps - 1) * CH;                        // channels of the last K step
+    const bool ragged = crem != CH;
+    const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * nsteps * step_b +
                         (TM == 1 ? ((m0 >> 6) & 1) * (PLANE_B / 2) : 0);
     // input patch: NB of the CH*PR*PC (1440 or 1632) patch elements per thread (the surplus slots land in the unused
     // columns of the last patch row, so that every load is consumed unconditionally: no divergent store).
     unsigned boffB[NB];   // byte offset inside one channel group (cl*HW + gy*W + gx)*4; 0 with bok=false -> zero
     bool bok[NB];
+    unsigned clok = 0;    // bit u: the channel of slot u exists in the LAST K step
     int blds[NB];        // LDS float index
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -150,6 +157,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         const int Rin = R0 - 1 + pr, gx = ow0 - 1 + px;                      // stack row -> (image, row); row H is virtual
         const int ni = (Rin >= 0 ? Rin : 0) / Hs, gy = Rin - ni * Hs;
         bok[u] = real && Rin >= 0 && Rin < Rtot && gy < a.H && (unsigned)gx < (unsigned)a.W;
+        clok |= (cl < crem) ? (1u << u) : 0u;
         boffB[u] = bok[u] ? ((unsigned)((ni - nbase) * a.Cin + cl) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : 0u;
         blds[u] = real ? (cl * PR + pr) * BS + px : ((CH - 1) * PR + PR - 1) * BS + PC + (idx - CH * PR * PC) % (BS - PC);
     }
@@ -159,23 +167,24 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
     constexpr int NLD = NB + NA;                 // global loads per thread and step: patch first, then weights
     constexpr int LPC = 2;                       // ... dealt out LPC per 16-MFMA chunk
     static_assert(LPC * 8 >= NLD, "all loads of a step are issued before its last chunk");
-    auto load_one = [&](int id, const char* wstep, const char* base) {
-        if (id < NB) rb[id] = *reinterpret_cast<const float*>(base + boffB[id]);   // masked at store time
+    // `last` (wave-uniform): the tile is the ragged last K step -- slots of channels >= Cin load from offset 0 and store zeros
+    auto load_one = [&](int id, const char* wstep, const char* base, bool last) {
+        if (id < NB) rb[id] = *reinterpret_cast<const float*>(base + ((last && !((clok >> id) & 1u)) ? 0u : boffB[id]));   // masked at store time
         else if (id < NLD) ra[id - NB] = *reinterpret_cast<const f32x4*>(wstep + aoff[id - NB]);
     };
-    auto load_global = [&](int s) {
+    auto load_global = [&](int s, bool last) {
         const char* wstep = wtile + (size_t)s * step_b;
         const char* base = reinterpret_cast<const char*>(inn + (size_t)s * CH * HW);
 #pragma unroll
-        for (int id = 0; id < NLD; ++id) load_one(id, wstep, base);
+        for (int id = 0; id < NLD; ++id) load_one(id, wstep, base, last);
     };
-    auto store_lds = [&]() {
+    auto store_lds = [&](bool last) {
         f32x4* a4 = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
         for (int j = 0; j < NA; ++j) a4[alds[j]] = ra[j];
         float* bflat = &Bs[0][0][0];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) bflat[blds[u]] = bok[u] ? rb[u] : 0.0f;
+        for (int u = 0; u < NB; ++u) bflat[blds[u]] = (bok[u] && (!last || ((clok >> u) & 1u))) ? rb[u] : 0.0f;
     };
 
     // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
@@ -197,14 +206,14 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nsteps = a.Cin / CH;
-    load_global(0);
-    store_lds();
+    load_global(0, ragged && nsteps == 1);
+    store_lds(ragged && nsteps == 1);
     __syncthreads();
     RFX_STAMP(1);
     const float* bflat = &Bs[0][0][0];
     for (int s = 0; s < nsteps; ++s) {
         const int sn = s + 1 < nsteps ? s + 1 : s;     // the last step re-loads its own tile: harmless
+        const bool lastn = ragged && sn == nsteps - 1;
         const char* wstep = wtile + (size_t)sn * step_b;
         const char* base = reinterpret_cast<const char*>(inn + (size_t)sn * CH * HW);
         // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
@@ -227,7 +236,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
             if (q + 1 < 9) read_chunk(q + 1, cur ^ 1);
             if (RFX_C3_DBG != 2 && RFX_C3_DBG != 3 && RFX_C3_DBG != 4) {
 #pragma unroll
-                for (int i = 0; i < LPC; ++i) load_one(q * LPC + i, wstep, base);   // tile s+1, in the MFMA shadow
+                for (int i = 0; i < LPC; ++i) load_one(q * LPC + i, wstep, base, lastn);   // tile s+1, in the MFMA shadow
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -241,7 +250,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         }
         if (RFX_C3_DBG != 4) __syncthreads();   // everyone is done reading the tile
         if (RFX_C3_DBG != 1 && RFX_C3_DBG != 3 && RFX_C3_DBG != 4)
-            store_lds();   // tile s+1
+            store_lds(lastn);   // tile s+1
         else if (RFX_C3_DBG == 1) {   // keep the loads alive (and waited for) without the LDS stores
 #pragma unroll
             for (int j = 0; j < NA; ++j) asm volatile("" ::"v"(ra[j]));

@@ -148,11 +148,13 @@ class ConvPlan:
         self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
         self._wq = None
         self.wP = None
-        if self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.Cin % 8 == 0:
-            # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]
-            wp = torch.zeros(Mpad, K, dtype=torch.float32)
-            wp[:self.Cout] = w.reshape(self.Cout, K)
-            wp = wp.view(Mpad // 128, 128, K // 72, 36, 2).permute(0, 2, 4, 1, 3).contiguous()
+        if self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.Cin >= 8:
+            # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]; a Cin that is not a multiple of 8
+            # (the 49-channel correlation volume) gets zero rows for the missing channels of its last K step
+            Kp = (self.Cin + 7) // 8 * 72
+            wp = torch.zeros(Mpad, Kp, dtype=torch.float32)
+            wp[:self.Cout, :K] = w.reshape(self.Cout, K)
+            wp = wp.view(Mpad // 128, 128, Kp // 72, 36, 2).permute(0, 2, 4, 1, 3).contiguous()
             self.wP = wp.to(device or "cuda")
         k = torch.arange(K)
         c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)

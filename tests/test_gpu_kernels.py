@@ -143,7 +143,10 @@ def test_conv2d_matches_cpu(dev, case):
                                    (48, 16, 30, 40, 256), (3, 24, 28, 37, 40), (5, 72, 33, 47, 192),
                                    # the images of a batch are tiled as one stack (conv3x3.hip): patches that span several tiny
                                    # images, one-row / one-pixel images, a stack that ends inside a patch
-                                   (7, 16, 5, 3, 64), (9, 8, 1, 1, 8), (5, 8, 2, 70, 32), (33, 8, 3, 17, 136), (2, 8, 31, 5, 64)])
+                                   (7, 16, 5, 3, 64), (9, 8, 1, 1, 8), (5, 8, 2, 70, 32), (33, 8, 3, 17, 136), (2, 8, 31, 5, 64),
+                                   # Cin not a multiple of the 8-channel K step (the heads' 49-channel correlation volume): zero
+                                   # weight rows + zero-filled patch slots for the missing channels of the last step
+                                   (4, 49, 60, 80, 512), (2, 9, 7, 11, 64), (3, 15, 12, 9, 40), (1, 49, 5, 3, 49), (2, 17, 20, 33, 130)])
 def test_direct_3x3_equals_implicit_gemm_bit_for_bit(dev, shape):
     """rfx_conv3x3_f32 (weights packed in the kernel's LDS order, include/rfx_api.h) == rfx_conv2d_f32 (generic wT / ktab
     packing) on the same layer, bit for bit: same k order in both kernels."""
