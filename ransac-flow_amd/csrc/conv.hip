@@ -374,6 +374,7 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
 int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused);                                       // conv3x3.hip
+bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols);                          // conv3x3.hip
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
                               hipStream_t st);                                          // conv1x1.hip
@@ -408,7 +409,7 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
         const int pc = rfx_conv3x3_patch_cols(N, Hout, Wout, false), pr = 128 / pc;
         const long long tiles = (((long long)N * (Hout + 1) + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
-        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128));
+        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (!big && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0);
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);

@@ -36,8 +36,12 @@ namespace {
 // the stack, so a patch may straddle two (or, on tiny maps, several) images and only the LAST patch row of the whole batch
 // is ragged: a 25x33 map costs 26/25 instead of 32/25 in the row direction (the 7-level pyramid puts a quarter of the
 // 3x3 work on such maps).  Outputs that fall on a virtual row are computed and dropped (1/(H+1) of the work).
-template <int PT_C_> struct Patch {
-    static constexpr int PT_C = PT_C_, PT_R = 128 / PT_C_;
+// TN = 32-pixel MFMA sub-tiles per wavefront: 2 -> 128 pixels per workgroup; 4 -> 256 pixels (16 x 16 patch) for the layers
+// whose output channels all fit one 64-channel tile (TM = 1): there the 18 KB weight image of a K step dwarfs the 6 KB input
+// patch, and twice the pixels per workgroup halve the weight bytes a CU pulls per MFMA (the 64-channel layers sit on the CU's
+// load path).  Same k order per output element: bit-identical to TN = 2.
+template <int PT_C_, int TN_ = 2> struct Patch {
+    static constexpr int PT_C = PT_C_, PT_R = 64 * TN_ / PT_C_;
     static constexpr int PR = PT_R + 2, PC = PT_C + 2;        // input patch incl. halo
     static constexpr int BS = PT_C_ == 16 ? 48 : (PT_C_ == 8 ? 24 : 12);
     static constexpr int RH = 32 / PT_C_;                     // patch rows per 32-pixel MFMA sub-tile
@@ -77,14 +81,16 @@ extern "C" long long* rfx_debug_trace_ptr();
 // intermediate never touches HBM, the expansion's launch, prologue and B-operand staging disappear, and its residual /
 // output traffic overlaps the MFMA-bound 3x3 main loops of the neighbouring workgroups.  k order and pairing of the
 // expansion are those of conv.hip: bit-identical to the two separate kernels.
-template <int TM, int PTC, bool FUSE>
+template <int TM, int PTC, bool FUSE, int TN = 2>
 __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsigned bx) {
-    using G = Patch<PTC>;
+    using G = Patch<PTC, TN>;
+    static_assert(TN == 2 || (TN == 4 && TM == 1 && PTC == 16), "the 256-pixel patch is built for 64-channel tiles, 16 x 16");
+    constexpr int NPX = 64 * TN;                     // output pixels of the workgroup
     constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
     constexpr int NB = (CH * PR * PC + 255) / 256;   // patch elements per thread (6; 7 for the 32x4 patch)
     static_assert(PC < BS, "the surplus staging slots live in the never-read padding columns");
     constexpr int BM = 64 * TM;
-    constexpr int AS_F = 2 * BM * KK, BS_F = CH * PR * BS, T2_F = FUSE ? BM * 128 : 0;
+    constexpr int AS_F = 2 * BM * KK, BS_F = CH * PR * BS, T2_F = FUSE ? BM * NPX : 0;
     constexpr int SMEM_F = AS_F + BS_F > T2_F ? AS_F + BS_F : T2_F;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_F];   // FUSE: the main-loop buffers are reused for the mid tile
     float (*As)[BM][KK] = reinterpret_cast<float (*)[BM][KK]>(smem);
@@ -188,7 +194,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
     };
 
     // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
-    const int pixb = (wn * 2 * RH + lcol / PT_C) * BS + lcol % PT_C;   // sub-tile tn adds RH rows = RH*BS
+    const int pixb = (wn * TN * RH + lcol / PT_C) * BS + lcol % PT_C;   // sub-tile j adds RH rows = RH*BS
     int baddr[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -198,11 +204,11 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         baddr[kk] = pixb + cl * (PR * BS) + kh * BS + kw;
     }
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -218,15 +224,15 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         const char* base = reinterpret_cast<const char*>(inn + (size_t)sn * CH * HW);
         // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
         f32x4 af[2][TM];
-        float bv[2][8];
+        float bv[2][4 * TN];
         auto read_chunk = [&](int q, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 af[slot][i] = *reinterpret_cast<const f32x4*>(&As[lrow][(wm * TM + i) * 32 + lcol][q * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                bv[slot][2 * e] = bflat[baddr[q * 4 + e]];
-                bv[slot][2 * e + 1] = bflat[baddr[q * 4 + e] + RH * BS];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[baddr[q * 4 + e] + j * RH * BS];
             }
         };
         read_chunk(0, 0);
@@ -242,10 +248,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][2 * e], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][2 * e + 1], acc[i][1], 0, 0, 0);
-                }
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][TN * e + j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (RFX_C3_DBG != 4) __syncthreads();   // everyone is done reading the tile
@@ -264,7 +270,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
         if (sacc == 123.456f) a.out[t] = sacc;
@@ -273,38 +279,47 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 
     RFX_STAMP(2);
     // ---- epilogue (conv_epilogue.h) ----
-    size_t pix_off[2];
-    bool pix_ok[2];
     const int Cfinal = FUSE ? a.Cexp : a.Cout;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int R = R0 + wn * 2 * RH + j * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
+    // element offset / existence of this lane's pixel in MFMA sub-tile st (32 consecutive pixels = RH patch rows) of the patch
+    auto pixel_of = [&](int st, size_t& off, bool& ok) {
+        const int R = R0 + st * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
         const int n = R / Hs, oh = R - n * Hs;
-        pix_ok[j] = R < Rtot && oh < a.H && ow < a.W;
-        pix_off[j] = pix_ok[j] ? (size_t)n * Cfinal * HW + (size_t)oh * a.W + ow : 0;
-    }
+        ok = R < Rtot && oh < a.H && ow < a.W;
+        off = ok ? (size_t)n * Cfinal * HW + (size_t)oh * a.W + ow : 0;
+    };
     if constexpr (!FUSE) {
+        size_t pix_off[TN];
+        bool pix_ok[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) pixel_of(wn * TN + j, pix_off[j], pix_ok[j]);
         const bool full = m0 + BM <= a.Cout;
-        conv_epilogue<TM, 2, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+        conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
     } else {
         // ---- mid tile -> LDS: T2[channel][pixel], pixel = MFMA column numbering (wn*2 + j)*32 + lcol
         float* T2 = smem;   // every wavefront is past the last barrier of the main loop: As / Bs are free
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
                     float v = fmaf(acc[i][j][r], s_scale[ch], s_shift[ch]);
                     if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
-                    T2[ch * 128 + (wn * 2 + j) * 32 + lcol] = v;
+                    T2[ch * NPX + (wn * TN + j) * 32 + lcol] = v;
                 }
         __syncthreads();
         // ---- 1x1 expansion: out[Cexp x 128 px] = W3[Cexp x BM] * T2, 128 output channels per pass, waves 2 x 2.
         // The weights come in "quad" order wQ[q][lrow][m][4] = W3[m][8q + 2j + lrow] (j = 0..3): the four A operands a lane
         // needs for k-pairs 4q..4q+3 are ONE 16-byte load, and consecutive lanes (channels) read consecutive 16 bytes.
-        const float* t2col = T2 + lrow * 128 + wn * 64 + lcol;               // + 2kk*128 (+ 32 for the second sub-tile)
+        // (a 256-pixel patch runs the expansion over its two 128-pixel halves one after the other: sub-tiles ph*4 + wn*2 + j)
+#pragma unroll 1
+        for (int ph = 0; ph < TN / 2; ++ph) {
+        size_t pix_off[2];
+        bool pix_ok[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pixel_of(ph * 4 + wn * 2 + j, pix_off[j], pix_ok[j]);
+        const float* t2col = T2 + lrow * NPX + ph * 128 + wn * 64 + lcol;    // + 2kk*NPX (+ 32 for the second sub-tile)
         for (int mp = 0; mp < a.Cexp; mp += 128) {
             const f32x4* wq0 = reinterpret_cast<const f32x4*>(a.wT3) + (size_t)lrow * a.Cexp + mp + wm * 64 + lcol;   // + q*2*Cexp (+ 32)
             f32x16 acc2[2][2];
@@ -315,6 +330,8 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
             // L2 -> registers, two quads (8 k-pairs = 32 MFMAs) ahead of use
+            // (measured, round 3: 4 quads ahead +-0; the pass's residual values fetched in front of this loop -6 %, 64 more live
+            // registers -- profiles/r03_fused_tail_expansion_experiment.jsonl)
             constexpr int NQ = BM / 8, AHEAD = 2;
             f32x4 wq[AHEAD + 1][2];
             auto load_w = [&](int q, int slot) {
@@ -326,8 +343,8 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
             auto read_b = [&](int q, int slot) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bq[slot][e][0] = t2col[2 * (q * 4 + e) * 128];
-                    bq[slot][e][1] = t2col[2 * (q * 4 + e) * 128 + 32];
+                    bq[slot][e][0] = t2col[2 * (q * 4 + e) * NPX];
+                    bq[slot][e][1] = t2col[2 * (q * 4 + e) * NPX + 32];
                 }
             };
 #pragma unroll
@@ -353,6 +370,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
             conv_epilogue<2, 2, false>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
                                        pix_ok, true);
         }
+        }   // pixel halves
     }
 #ifdef RFX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -360,9 +378,9 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #endif
 }
 
-template <int TM, int PTC, bool FUSE = false>
+template <int TM, int PTC, bool FUSE = false, int TN = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
-    conv3x3_direct_body<TM, PTC, FUSE>(a, blockIdx.x);
+    conv3x3_direct_body<TM, PTC, FUSE, TN>(a, blockIdx.x);
 }
 
 // grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
@@ -379,6 +397,15 @@ static int c3_group_launch(const void* blob, const unsigned* gx, int n, hipStrea
 }
 
 }  // namespace
+
+// 256-pixel (16 x 16) patches for a layer whose output channels fit ONE 64-channel tile: only for launches that still fill the
+// chip two generations deep with the larger patch, never inside a grouped launch (latency-bound: more, smaller workgroups win).
+bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols) {
+    static const int en = getenv("RFX_C3_WIDE") ? atoi(getenv("RFX_C3_WIDE")) : 1;
+    if (!en || rfx_group_recording() || patch_cols != 16 || Cout > 64) return false;
+    const long long tiles = (((long long)N * (H + 1) + 15) / 16) * ((W + 15) / 16);
+    return tiles >= 1024;
+}
 
 // Patch shape for a batch of N H x W maps stacked as above: the fewest padded pixels (ties: the widest, whose row segments
 // coalesce best).  The fused Bottleneck tail writes Cexp channels per pixel from a narrow patch in short row segments:
@@ -400,9 +427,9 @@ int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     return best;
 }
 
-template <int TM, int PTC, bool FUSE = false>
+template <int TM, int PTC, bool FUSE = false, int TN = 2>
 static int launch_direct(C3Args& a, hipStream_t st) {
-    using G = Patch<PTC>;
+    using G = Patch<PTC, TN>;
     const long long rows = (long long)a.N * (a.H + 1);
     a.tilesH = (int)((rows + G::PT_R - 1) / G::PT_R);
     a.tilesW = (a.W + G::PT_C - 1) / G::PT_C;
@@ -414,8 +441,10 @@ static int launch_direct(C3Args& a, hipStream_t st) {
     static const unsigned stagger = FUSE ? rfx_stagger_env("RFX_C3F_STAGGER", "RFX_C3F_STAGGER_MODE")
                                          : rfx_stagger_env("RFX_C3_STAGGER", "RFX_C3_STAGGER_MODE");
     a.stagger = (rfx_group_recording() || nwg < 1024) ? 0u : stagger;
-    if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
-    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    if constexpr (TN == 2) {
+        if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
+    }
+    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE, TN>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -439,7 +468,7 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
         if (patch_cols == 8) return launch_direct<2, 8>(a, st);
         return launch_direct<2, 4>(a, st);
     }
-    if (patch_cols == 16) return launch_direct<1, 16>(a, st);
+    if (patch_cols == 16) return rfx_conv3x3_wide_patch(N, H, W, Cout, 16) ? launch_direct<1, 16, false, 4>(a, st) : launch_direct<1, 16>(a, st);
     if (patch_cols == 8) return launch_direct<1, 8>(a, st);
     return launch_direct<1, 4>(a, st);
 }
@@ -476,7 +505,7 @@ extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const 
         if (pc == 8) return launch_direct<2, 8, true>(a, st);
         return launch_direct<2, 4, true>(a, st);
     }
-    if (pc == 16) return launch_direct<1, 16, true>(a, st);
+    if (pc == 16) return launch_direct<1, 16, true>(a, st);   // the 256-pixel patch buys the fused tail nothing (100.9 vs 100.5 TFLOP/s): its loss is the expansion phase
     if (pc == 8) return launch_direct<1, 8, true>(a, st);
     return launch_direct<1, 4, true>(a, st);
 }

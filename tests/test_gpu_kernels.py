@@ -146,7 +146,9 @@ def test_conv2d_matches_cpu(dev, case):
                                    (7, 16, 5, 3, 64), (9, 8, 1, 1, 8), (5, 8, 2, 70, 32), (33, 8, 3, 17, 136), (2, 8, 31, 5, 64),
                                    # Cin not a multiple of the 8-channel K step (the heads' 49-channel correlation volume): zero
                                    # weight rows + zero-filled patch slots for the missing channels of the last step
-                                   (4, 49, 60, 80, 512), (2, 9, 7, 11, 64), (3, 15, 12, 9, 40), (1, 49, 5, 3, 49), (2, 17, 20, 33, 130)])
+                                   (4, 49, 60, 80, 512), (2, 9, 7, 11, 64), (3, 15, 12, 9, 40), (1, 49, 5, 3, 49), (2, 17, 20, 33, 130),
+                                   # one 64-channel tile + a launch large enough: 256-pixel (16x16) patches, TN = 4
+                                   (24, 64, 120, 160, 64), (70, 8, 50, 70, 24), (170, 16, 33, 47, 64), (64, 49, 60, 80, 49)])
 def test_direct_3x3_equals_implicit_gemm_bit_for_bit(dev, shape):
     """rfx_conv3x3_f32 (weights packed in the kernel's LDS order, include/rfx_api.h) == rfx_conv2d_f32 (generic wT / ktab
     packing) on the same layer, bit for bit: same k order in both kernels."""
@@ -575,6 +577,8 @@ def test_fused_resnet_stem_channel_group_passes(dev, cout):
     (1, 8, 5, 3, 128, 384, True),         # one K step of the 3x3, three passes of the 1x1
     (24, 64, 30, 40, 64, 256, True),      # big enough for the unfused 1x1 to run on the k-major kernel (conv1x1.hip)
     (20, 128, 17, 23, 128, 512, True),    # ... with an odd plane (scalar pixel loads)
+    (32, 64, 120, 160, 64, 256, True),    # 64-channel tail on a launch large enough for the 256-pixel (16x16) patch
+    (200, 64, 30, 44, 64, 128, False),    # ... ragged in both directions, images straddling the patches, single pass
 ])
 def test_fused_bottleneck_tail_equals_two_convs(dev, case):
     """rfx_conv3x3_conv1x1_f32 == rfx_conv2d_f32(3x3) -> rfx_conv2d_f32(1x1 + residual), bit for bit."""
