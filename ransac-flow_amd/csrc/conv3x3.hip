@@ -330,8 +330,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
             // L2 -> registers, two quads (8 k-pairs = 32 MFMAs) ahead of use
-            // (measured, round 3: 4 quads ahead +-0; the pass's residual values fetched in front of this loop -6 %, 64 more live
-            // registers -- profiles/r03_fused_tail_expansion_experiment.jsonl)
+            // (measured, round 3, profiles/r03_fused_tail_expansion_experiment.jsonl + r03_fused_tail_late_prefetch.jsonl: 4 quads
+            // ahead +-0; the pass's residual values fetched in front of this loop -6 % (vmcnt retires in order: the loop's weight
+            // waits then wait for the residuals too); fetched inside the loop behind its last weight load -3 % on the 64-channel
+            // tail, +1 % on the 128-channel one.  The epilogue's cost is not the latency of its residual loads.)
             constexpr int NQ = BM / 8, AHEAD = 2;
             f32x4 wq[AHEAD + 1][2];
             auto load_w = [&](int q, int slot) {
