@@ -91,7 +91,8 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
  * the template arguments <TM,TN,ONE,WS,VECB> rocprofv3 prints.  Bit 5 = the direct 3x3 / stride 1 / pad 1 kernel
  * conv3x3_direct_kernel<TM, PT_C> (Cin >= 8), TM = 2 if bits 0-1 are 0 else 1; bits 6-7 = output patch shape
  * (0: 8x16, 1: 16x8, 2: 32x4 -- the one that pads the H x W map least); bit 11 = 256-pixel (16x16) patches, conv3x3_direct_kernel<1, 16, false, 4>
- * (Cout <= 64 on launches of >= 1024 such patches: twice the pixels per staged weight image).  Bit 10 = the k-major 1x1 / stride 1 kernel
+ * (Cout <= 64 on launches of >= 1024 such patches: twice the pixels per staged weight image); bit 12 = the instance with a ragged last K
+ * step (Cin % 8 != 0), conv3x3_direct_kernel<TM, PT_C, false, 2, true>.  Bit 10 = the k-major 1x1 / stride 1 kernel
  * conv1x1_kmajor_kernel<TM, VEC> (Cin % 32 == 0; TM = 2 - bits 0-1, VEC = bit 4).  Bit 5 set = the geometry is served by
  * rfx_conv3x3_f32 below (the host mirrors call it then); rfx_conv2d_f32 itself always runs the implicit-GEMM kernel. */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);

@@ -409,7 +409,9 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
         const int pc = rfx_conv3x3_patch_cols(N, Hout, Wout, false), pr = 128 / pc;
         const long long tiles = (((long long)N * (Hout + 1) + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
-        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (!big && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0);
+        const bool rag = Cin % 8 != 0;
+        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (!big && !rag && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) |
+               (rag ? 4096 : 0);
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);

@@ -81,7 +81,7 @@ extern "C" long long* rfx_debug_trace_ptr();
 // intermediate never touches HBM, the expansion's launch, prologue and B-operand staging disappear, and its residual /
 // output traffic overlaps the MFMA-bound 3x3 main loops of the neighbouring workgroups.  k order and pairing of the
 // expansion are those of conv.hip: bit-identical to the two separate kernels.
-template <int TM, int PTC, bool FUSE, int TN = 2>
+template <int TM, int PTC, bool FUSE, int TN = 2, bool RAG = false>
 __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsigned bx) {
     using G = Patch<PTC, TN>;
     static_assert(TN == 2 || (TN == 4 && TM == 1 && PTC == 16), "the 256-pixel patch is built for 64-channel tiles, 16 x 16");
@@ -145,7 +145,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
     // zero filled (their loads point at the first channel of the step: a valid address) -- the sum gains exact zeros only.
     const int nsteps = (a.Cin + CH - 1) / CH;
     const int crem = a.Cin - (nsteps - 1) * CH;                        // channels of the last K step
-    const bool ragged = crem != CH;
+    const bool ragged = RAG && crem != CH;                             // RAG: its own kernel instance (the host picks it when Cin % 8 != 0)
     const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * nsteps * step_b +
                         (TM == 1 ? ((m0 >> 6) & 1) * (PLANE_B / 2) : 0);
     // input patch: NB of the CH*PR*PC (1440 or 1632) patch elements per thread (the surplus slots land in the unused
@@ -381,9 +381,9 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 }
 
 // (three workgroups per CU for the 64-channel fused tail -- 168 VGPRs, 4 spilled -- measured -2.4 %: profiles/r03_fused_tail_3wgs.jsonl)
-template <int TM, int PTC, bool FUSE = false, int TN = 2>
+template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
-    conv3x3_direct_body<TM, PTC, FUSE, TN>(a, blockIdx.x);
+    conv3x3_direct_body<TM, PTC, FUSE, TN, RAG>(a, blockIdx.x);
 }
 
 // grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
@@ -430,7 +430,7 @@ int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     return best;
 }
 
-template <int TM, int PTC, bool FUSE = false, int TN = 2>
+template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false>
 static int launch_direct(C3Args& a, hipStream_t st) {
     using G = Patch<PTC, TN>;
     const long long rows = (long long)a.N * (a.H + 1);
@@ -444,10 +444,10 @@ static int launch_direct(C3Args& a, hipStream_t st) {
     static const unsigned stagger = FUSE ? rfx_stagger_env("RFX_C3F_STAGGER", "RFX_C3F_STAGGER_MODE")
                                          : rfx_stagger_env("RFX_C3_STAGGER", "RFX_C3_STAGGER_MODE");
     a.stagger = (rfx_group_recording() || nwg < 1024) ? 0u : stagger;
-    if constexpr (TN == 2) {
+    if constexpr (TN == 2 && !RAG) {
         if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
     }
-    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE, TN>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE, TN, RAG>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -466,6 +466,16 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
 #endif
     const int BM = 64 * tm;
     a.tilesM = (Cout + BM - 1) / BM;
+    if (Cin % CH != 0) {          // ragged last K step: separate instances (never recorded into a grouped launch: launched at once)
+        if (tm == 2) {
+            if (patch_cols == 16) return launch_direct<2, 16, false, 2, true>(a, st);
+            if (patch_cols == 8) return launch_direct<2, 8, false, 2, true>(a, st);
+            return launch_direct<2, 4, false, 2, true>(a, st);
+        }
+        if (patch_cols == 16) return launch_direct<1, 16, false, 2, true>(a, st);
+        if (patch_cols == 8) return launch_direct<1, 8, false, 2, true>(a, st);
+        return launch_direct<1, 4, false, 2, true>(a, st);
+    }
     if (tm == 2) {
         if (patch_cols == 16) return launch_direct<2, 16>(a, st);
         if (patch_cols == 8) return launch_direct<2, 8>(a, st);
