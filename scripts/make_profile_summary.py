@@ -29,7 +29,8 @@ def bench_log(name, cmd, out):
 
 bench_log("bench", "python bench.py --gpus 1 --steps 20 --warmup 5", RND + "_bench_default.log")
 for c in ("2", "3", "4", "5", "qs"):
-    bench_log("bench_c" + c, "python bench.py --config %s --steps 5 --warmup 2" % c, RND + "_bench_config%s.log" % c)
+    bench_log("bench_c" + c, ("python bench.py --config 2 --steps 60 --warmup 10 --no-cpu-baseline" if c == "2" else
+                              "python bench.py --config %s --steps 5 --warmup 2 --no-cpu-baseline --no-qs-leg" % c), RND + "_bench_config%s.log" % c)
 bench_log("bench_c3_2ranks_1gpu_gloo", "RFX_BENCH_BACKEND=gloo RFX_BENCH_DEVICE=0 python bench.py --config 3 --gpus 2 --steps 3 --warmup 1 --batch 32 "
           "--no-cpu-baseline  (two ranks rehearsed on ONE GPU)", RND + "_bench_config3_2ranks_on_1gpu_gloo.log")
 
