@@ -42,7 +42,7 @@ const char* rfx_version(void);
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
  * round kernels, two-direction correlation, grouped launches).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 4
+#define RFX_ABI_VERSION 5
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -55,11 +55,15 @@ int rfx_abi_version(void);
  * selects the problem (up to 8 per launch).  The device code of a problem is the single launch's, so results are
  * bit-identical.  Recording is per host thread, groups do not nest, every other entry point launches immediately;
  * the caller keeps all operands alive until rfx_group_end and records only mutually independent calls.
- * rfx_group_abort() drops a recording without launching.
+ * rfx_group_abort() drops a recording without launching.  The kernel instances of one group that remain distinct run
+ * concurrently on two library-owned side streams forked from / joined to `stream`; rfx_group_side_streams(0) turns that off
+ * for the calling host thread (returns the previous setting) -- a caller that already runs several grouped chains on streams
+ * of its own (rfx/pipeline.py: the images of a single pair as two chains) wants each chain serial on its stream.
  * ------------------------------------------------------------------------------------------ */
 int rfx_group_begin(void);
 int rfx_group_end(void* stream);
 int rfx_group_abort(void);
+int rfx_group_side_streams(int enable);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution family (ResNet-50 conv1..layer3 trunk: model/resnet50.py:68-104,112-169 as used by

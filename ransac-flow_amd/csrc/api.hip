@@ -27,25 +27,36 @@ thread_local Recorder g_rec;
 constexpr int NSIDE = 2;
 struct SidePool {
     int dev = -1;
+    hipStream_t owner = nullptr;            // the caller's stream this pool forks from
     hipStream_t s[NSIDE];
     hipEvent_t fork, join[NSIDE];
 };
-thread_local SidePool g_pool;
+// One pool per (device, caller stream): two chains of grouped launches on two caller streams (rfx/pipeline.py) must not share
+// side streams -- the second chain's side work would queue behind the first's -- nor re-record each other's fork / join events.
+constexpr int NPOOL = 4;
+thread_local SidePool g_pools[NPOOL];
+thread_local bool g_side_on = true;      // rfx_group_side_streams
 
-bool side_pool_ready() {
+SidePool* side_pool_for(hipStream_t main) {
     static const bool on = !(getenv("RFX_GROUP_STREAMS") && atoi(getenv("RFX_GROUP_STREAMS")) == 0);
-    if (!on) return false;
+    if (!on || !g_side_on) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (g_pool.dev == dev) return true;
-    if (g_pool.dev >= 0) return false;                      // one device per host thread: others fall back to the serial form
-    for (int i = 0; i < NSIDE; ++i) {
-        if (hipStreamCreateWithFlags(&g_pool.s[i], hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&g_pool.join[i], hipEventDisableTiming) != hipSuccess) return false;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SidePool* free_slot = nullptr;
+    for (auto& p : g_pools) {
+        if (p.dev == dev && p.owner == main) return &p;
+        if (p.dev < 0 && !free_slot) free_slot = &p;
     }
-    if (hipEventCreateWithFlags(&g_pool.fork, hipEventDisableTiming) != hipSuccess) return false;
-    g_pool.dev = dev;
-    return true;
+    if (!free_slot) return nullptr;                          // more caller streams than pools: those run the serial form
+    SidePool& p = *free_slot;
+    for (int i = 0; i < NSIDE; ++i) {
+        if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    p.dev = dev;
+    p.owner = main;
+    return &p;
 }
 }  // namespace
 
@@ -88,17 +99,18 @@ extern "C" int rfx_group_end(void* stream) {
         fprintf(stderr, "\n");
     }
     hipStream_t main = rfx_stream(stream);
-    const bool fork = g_rec.buckets.size() > 1 && side_pool_ready();
-    if (fork && hipEventRecord(g_pool.fork, main) != hipSuccess) rc = RFX_E_ARG;
+    SidePool* pool = g_rec.buckets.size() > 1 ? side_pool_for(main) : nullptr;
+    const bool fork = pool != nullptr;
+    if (fork && hipEventRecord(pool->fork, main) != hipSuccess) rc = RFX_E_ARG;
     bool used[NSIDE] = {false, false};
     int bi = 0;
     for (auto& b : g_rec.buckets) {
         hipStream_t st = main;
         if (fork && bi > 0) {
             const int k = (bi - 1) % NSIDE;
-            st = g_pool.s[k];
+            st = pool->s[k];
             if (!used[k]) {
-                if (hipStreamWaitEvent(st, g_pool.fork, 0) != hipSuccess) rc = RFX_E_ARG;
+                if (hipStreamWaitEvent(st, pool->fork, 0) != hipSuccess) rc = RFX_E_ARG;
                 used[k] = true;
             }
         }
@@ -112,7 +124,7 @@ extern "C" int rfx_group_end(void* stream) {
     }
     for (int k = 0; k < NSIDE; ++k)                         // join: always, also after an error (a capture must not end forked)
         if (used[k]) {
-            if (hipEventRecord(g_pool.join[k], g_pool.s[k]) != hipSuccess || hipStreamWaitEvent(main, g_pool.join[k], 0) != hipSuccess)
+            if (hipEventRecord(pool->join[k], pool->s[k]) != hipSuccess || hipStreamWaitEvent(main, pool->join[k], 0) != hipSuccess)
                 if (rc == RFX_OK) rc = RFX_E_ARG;
         }
     g_rec.buckets.clear();
@@ -123,4 +135,10 @@ extern "C" int rfx_group_abort(void) {       // drop a recording without launchi
     g_rec.on = false;
     g_rec.buckets.clear();
     return RFX_OK;
+}
+
+extern "C" int rfx_group_side_streams(int enable) {
+    const int prev = g_side_on ? 1 : 0;
+    g_side_on = enable != 0;
+    return prev;
 }

@@ -18,6 +18,7 @@ SIGNATURES = {
     "rfx_group_begin": (c_int, []),
     "rfx_group_end": (c_int, [c_void_p]),
     "rfx_group_abort": (c_int, []),
+    "rfx_group_side_streams": (c_int, [c_int]),
     "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
     "rfx_conv2d_tile_variant": (c_int, [c_int] * 4),
     "rfx_conv2d_kernel_id": (c_int, [c_int] * 9),
@@ -68,7 +69,7 @@ SIGNATURES = {
                               + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),
 }
 
-ABI_VERSION = 4     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
+ABI_VERSION = 5     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
 
 _lib = None
 

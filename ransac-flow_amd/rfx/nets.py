@@ -50,24 +50,24 @@ class ResNet50Trunk:
         return x
 
 
-    def forward_group(self, xs):
+    def forward_group(self, xs, side_streams=True):
         """The same pass over several inputs of DIFFERENT sizes (a single pair's 7 pyramid levels + target), layer by layer
         with one grouped launch per kernel instance and layer (ops.launch_group) instead of one launch per layer and input:
         bit-identical to [self(x) for x in xs]."""
         dev = xs[0].device
-        with ops.launch_group(dev):
+        with ops.launch_group(dev, side_streams):
             xs = [ops.stem_conv7_maxpool(x, self.conv1) for x in xs]
         for blk in self.blocks:
-            with ops.launch_group(dev):          # c1 and the projection shortcut both read x only: one group
+            with ops.launch_group(dev, side_streams):          # c1 and the projection shortcut both read x only: one group
                 os_ = [blk["c1"](x) for x in xs]
                 rs = [blk["ds"](x) for x in xs] if blk["ds"] is not None else xs
             if ops.bottleneck_tail_eligible(blk["c2"], blk["c3"]):
-                with ops.launch_group(dev):
+                with ops.launch_group(dev, side_streams):
                     xs = [ops.bottleneck_tail(o, blk["c2"], blk["c3"], residual=r) for o, r in zip(os_, rs)]
             else:
-                with ops.launch_group(dev):
+                with ops.launch_group(dev, side_streams):
                     os_ = [blk["c2"](o) for o in os_]
-                with ops.launch_group(dev):
+                with ops.launch_group(dev, side_streams):
                     xs = [blk["c3"](o, residual=r) for o, r in zip(os_, rs)]
         return xs
 

@@ -98,8 +98,10 @@ class launch_group:
     depend on each other, and their tensors must stay referenced until the block ends (the returned outputs do).  Not used
     under a Profiler (per-launch events are meaningless for a recorded launch)."""
 
-    def __init__(self, device):
-        self.dev = torch.device(device)
+    def __init__(self, device, side_streams=True):
+        # side_streams=False: the group's kernel instances stay on the caller's stream (rfx_group_side_streams) -- for callers that
+        # run several grouped chains on streams of their own
+        self.dev, self.side = torch.device(device), bool(side_streams)
 
     def __enter__(self):
         _lib.check(_lib.load().rfx_group_begin(), "rfx_group_begin")
@@ -110,11 +112,15 @@ class launch_group:
         if et is not None:
             lib.rfx_group_abort()
             return False
-        if self.dev.index is not None and self.dev.index != torch.cuda.current_device():
-            with torch.cuda.device(self.dev):
-                rc = lib.rfx_group_end(_stream(self.dev))
-        else:
-            rc = lib.rfx_group_end(_stream())
+        prev = lib.rfx_group_side_streams(1 if self.side else 0)
+        try:
+            if self.dev.index is not None and self.dev.index != torch.cuda.current_device():
+                with torch.cuda.device(self.dev):
+                    rc = lib.rfx_group_end(_stream(self.dev))
+            else:
+                rc = lib.rfx_group_end(_stream())
+        finally:
+            lib.rfx_group_side_streams(prev)
         _lib.check(rc, "rfx_group_end")
         return False
 
