@@ -273,8 +273,8 @@ class AlignPipeline:
                 # instances serial on its stream.  RFX_GROUP_CHAINS=1: one chain + the library's side streams (round 3's first form).
                 order = sorted(range(len(xs)), key=lambda i: -xs[i].numel())
                 chains, load = [[] for _ in range(nch)], [0] * nch
-                for i in order:
-                    k = load.index(min(load))
+                for i in order:                      # largest first to the lighter chain (measured against "the two largest levels
+                    k = load.index(min(load))        # vs the rest" 5.63 ms and alternating 5.99 ms: 5.38-5.43 ms)
                     chains[k].append(i)
                     load[k] += xs[i].numel()
                 if getattr(self, "_chain_streams", None) is None or len(self._chain_streams) != nch - 1:
