@@ -274,8 +274,8 @@ def build_workload(args, dev, rank, world):
 
         def step():
             r = _upload(raw_h, dev) if raw_h is not None else raw
-            p = prep0 if prep0 is not None else pipe.prepare_device(*r)
-            res = pipe.align_prepared(p, fine=fine)
+            p, feats = (prep0, None) if prep0 is not None else pipe.prepare_and_features(*r)
+            res = pipe.align_prepared(p, fine=fine, feats=feats)
             rec = rdist.pack_records(res, rank=rank) if fine else _coarse_records(res, dev, rank)
             return _download(rec, rec_h) if raw_h is not None else rec
         if fine:

@@ -281,8 +281,17 @@ __global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __rest
     const int px = (int)(pc - n * HW);
     const float* src = in + (size_t)n * C * HW + px;
     float* dst = out + (size_t)n * obs + px;
+    // 32 loads in flight per thread (the chain of fmas stays sequential in c: same value): on the trunk's 1-5 k-pixel maps the
+    // kernel is a handful of wavefronts walking 1024 channels twice, i.e. pure load latency -- 8 in flight took 40 us per call
     float s = 0.f;
     int c = q;
+    for (; c + 124 < C; c += 128) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s = fmaf(v[u], v[u], s);
+    }
     for (; c + 28 < C; c += 32) {
         float v[8];
 #pragma unroll
@@ -297,6 +306,13 @@ __global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __rest
     const float d = nrm > 1e-12f ? nrm : 1e-12f;
     if (!pv) return;
     c = q;
+    for (; c + 124 < C; c += 128) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) dst[(size_t)(c + 4 * u) * ocs] = v[u] / d;
+    }
     for (; c + 28 < C; c += 32) {
         float v[8];
 #pragma unroll

@@ -220,6 +220,55 @@ class AlignPipeline:
             res["featA"], res["featB"] = out["featA"].clone(), out["featB"].clone()   # the graph's own buffers are reused by the next replay
         return res
 
+    def prepare_and_features(self, src_u8, tgt_u8):
+        """prepare_device + features -> (prep, feats).  Small batches (B <= 4): ONE HIP graph from the raw uint8 images to the
+        normalised features -- the device pyramid (24 launches of tiny kernels per pair) is as launch-bound as the trunk pass, and
+        a graph that starts at the raw images needs 2 input copies instead of 8.  Same capture policy as _features_graphed (second
+        sighting, LRU of MAX_GRAPHS, non-empty check); the returned ``prep`` tensors belong to the graph and are valid until its
+        next replay.  Larger batches, RFX_GRAPH=0 or an active Profiler: the two eager calls."""
+        import collections
+        B = src_u8.shape[0]
+        if not (B <= 4 and os.environ.get("RFX_GRAPH", "1") != "0" and ops.Profiler.active() is None):
+            prep = self.prepare_device(src_u8, tgt_u8)
+            return prep, self.features(prep)
+        key = ("raw", tuple(src_u8.shape), tuple(tgt_u8.shape))
+        cache = self.__dict__.setdefault("_graphs", collections.OrderedDict())
+        seen = self.__dict__.setdefault("_graph_seen", collections.OrderedDict())
+        ent = cache.get(key)
+        if ent is None:
+            if key not in seen:
+                seen[key] = True
+                while len(seen) > 64:
+                    seen.popitem(last=False)
+                prep = self.prepare_device(src_u8, tgt_u8)
+                return prep, self._features_eager(prep)
+            with torch.cuda.device(self.dev):
+                self._features_eager(self.prepare_device(src_u8, tgt_u8))     # warm-up: lazily built state must exist
+                torch.cuda.synchronize(self.dev)
+                static = (src_u8.clone(), tgt_u8.clone())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    prep = self.prepare_device(*static)
+                    out = self._features_eager(prep)
+                out["featA"].zero_()
+                g.replay()
+                torch.cuda.synchronize(self.dev)
+                if not bool(out["featA"].abs().sum() > 0):
+                    raise RuntimeError("HIP-graph capture of the pyramid + trunk pass is empty (kernels did not go to the capture stream)")
+            ent = cache[key] = (g, static, (prep, out))
+            while len(cache) > self.MAX_GRAPHS:
+                cache.popitem(last=False)
+        else:
+            cache.move_to_end(key)
+        g, static, (prep, out) = ent
+        with torch.cuda.device(self.dev):
+            static[0].copy_(src_u8)
+            static[1].copy_(tgt_u8)
+            g.replay()
+            res = dict(out)
+            res["featA"], res["featB"] = out["featA"].clone(), out["featB"].clone()   # the graph's own buffers are reused by the next replay
+        return prep, res
+
     def _features_eager(self, prep):
         B = prep["B"]
         dims = [(x.shape[2] // 16, x.shape[3] // 16) for x in prep["src"]]
@@ -793,8 +842,8 @@ class AlignPipeline:
         return outs
 
     # ---------------------------------------------------------------- whole path
-    def align_prepared(self, prep, fine=True, samples=None):
-        res = self.coarse(prep, samples=samples)
+    def align_prepared(self, prep, fine=True, samples=None, feats=None):
+        res = self.coarse(prep, feats=feats, samples=samples)
         if fine:
             eye = torch.eye(3, device=self.dev)
             Hs = torch.stack([r["H"] if r["H"] is not None else eye for r in res])

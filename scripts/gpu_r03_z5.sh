@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3, call z5: l2norm with 32 loads in flight: tests + single-pair latency
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_multih.py -x -q -m gpu 2>&1 | tail -2
+for r in 1 2; do
+timeout 200 python bench.py --config 2 --steps 60 --warmup 10 --no-cpu-baseline > gpurun_out/bench_c2.log 2> gpurun_out/bench_c2.err
+python -c "import json; j=json.loads([l for l in open('gpurun_out/bench_c2.log') if l.startswith('{')][0]); print('config 2', j['ms_per_step'], j['config']['aligned_ok_last_step'])" 2>&1 | tail -1
+done
+timeout 300 python scripts/dbg/latency_split.py 2>&1 | grep "ms$\|l2norm\|mnn_tile" | cut -c1-200

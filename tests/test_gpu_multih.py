@@ -193,6 +193,30 @@ def test_graphed_trunk_pass_equals_the_eager_pass(dev, monkeypatch):
     assert len(pipe._graphs) <= pipe.MAX_GRAPHS
 
 
+def test_graph_from_raw_images_equals_the_eager_calls(dev, monkeypatch):
+    """prepare_and_features: device pyramid + trunk pass as ONE graph from the raw uint8 images (B <= 4).  Three different pairs of
+    one shape through first sighting (eager), capture and replay must equal the eager prepare_device + features, bit for bit,
+    for the features AND the tensors the fine stage reads afterwards."""
+    pipe = AlignPipeline(dict(trunk=weights.resnet50_trunk_sd(0)), nbScale=3, nbIter=10, tolerance=0.05, minSize=160, scaleR=1.2,
+                         device=dev)
+    raws = [pipe.upload_raw([synth.make_pair(128, 160, seed=s)]) for s in (4, 5, 6)]
+    monkeypatch.setenv("RFX_GRAPH", "0")
+    refs = []
+    for r in raws:
+        p = pipe.prepare_device(*r)
+        f = pipe.features(p)
+        refs.append((p["IsTensor"].clone(), p["ItTensor"].clone(), f["featA"].clone(), f["featB"].clone()))
+    monkeypatch.setenv("RFX_GRAPH", "1")
+    for k in (0, 1, 2, 0):
+        p, f = pipe.prepare_and_features(*raws[k])
+        got = (p["IsTensor"], p["ItTensor"], f["featA"], f["featB"])
+        for g, r in zip(got, refs[k]):
+            assert torch.equal(g, r), k
+    assert any(key[0] == "raw" for key in pipe._graphs)
+    res = pipe.align_prepared(p, fine=False, feats=f)
+    assert len(res) == 1
+
+
 def test_lock_step_driver_device_draw_records_and_determinism(dev):
     """The throughput form as bench.py runs it: device-side draw (no explicit samples), result records filled on the device.
     Same seed + same call sequence -> the same homographies; the records hold exactly what the per-pair lists hold; the
