@@ -434,16 +434,19 @@ def test_assemble_restatement_matches_live_reference(seed, tmp_path):
 def test_conv_dispatch_table_is_stable():
     """Host-side dispatch of rfx_conv2d_f32 (no GPU needed): which kernel instance a layer geometry gets.  Bits: 0-1 tile
     variant, 2 = 1x1 specialisation, 3 = wave-specialised form (off by default), 4 = 16-byte pixel loads, 5 = direct 3x3
-    kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4), 10 = k-major 1x1 kernel."""
+    kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4), 10 = k-major 1x1 kernel, 11 = 256-pixel patches of the
+    direct kernel (one 64-channel tile, large launch), 12 = its instance with a ragged last K step (Cin % 8 != 0)."""
     lib = _lib.load()
     kid = lambda N, Cin, Cout, k, s, p, Ho, Wo: lib.rfx_conv2d_kernel_id(N, Cin, Cout, k, k, s, p, Ho, Wo)
     # direct 3x3 / stride 1: big layers -> 128-channel tiles, 8x16 patches
     assert kid(128, 128, 128, 3, 1, 1, 120, 160) == 32
-    assert kid(128, 64, 64, 3, 1, 1, 240, 320) == 33                       # Cout = 64 -> 64-channel tiles
+    assert kid(128, 64, 64, 3, 1, 1, 240, 320) == 33 | 2048                # Cout = 64 -> 64-channel tiles, 256-pixel patches
+    assert kid(2, 64, 64, 3, 1, 1, 240, 320) == 33                         # ... only on launches of >= 1024 such patches
     assert kid(64, 256, 256, 3, 1, 1, 30, 40) == 32 | 64                    # 30x40 pads least with 16x8 patches
     assert kid(64, 256, 256, 3, 1, 1, 25, 33) == 32 | 128                   # 25x33 -> 32x4 patches
-    assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 0                           # Cin % 8 != 0 -> implicit GEMM, 128x128 tile
-    assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 2                            # ... a single image: 64x64 tiles fill the chip
+    assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 32 | 4096                   # Cin % 8 != 0 -> the direct kernel's ragged instance
+    assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 32 | 1 | 4096                # ... a single image: 64-channel tiles fill the chip
+    assert kid(64, 3, 64, 3, 1, 1, 480, 640) & 32 == 0                      # Cin < 8 (the stems' own kernels aside): implicit GEMM
     assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 0                          # strided 3x3 -> implicit GEMM, 128x128 tile
     # 1x1: 16-byte pixel loads only for stride 1 and H*W % 4 == 0
     # ... on the k-major kernel of conv1x1.hip (bit 10) when Cin % 32 == 0 and the tile is not the 64x64 one
