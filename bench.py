@@ -30,9 +30,10 @@ Prints one JSON line on rank 0 (the driver's contract): value = pairs/s over all
   roofline      -- the conv-class kernel instance with the most GPU time (fp32 MFMA bound): algorithmic FLOP per launch /
                    average launch duration, HIP events on the launch stream inside the timed region (ops.Profiler);
   roofline_corr -- the same for the HBM-bound 7x7 correlation kernel, SURVEY 8d algorithmic bytes;
-  cpu_baseline  -- the CPU oracle (oracle/restate.py, a port of the reference path; profiles/r03_cpu_reference_vs_port.json
-                   holds the reference/port ratio measured where the reference exists) on this host's cores: bounded sample
-                   of the SAME workload as ``value``;
+  cpu_baseline  -- the REFERENCE ITSELF on this host's cores (kind "reference": its own classes / functions / loop statement,
+                   byte-compiled into oracle/_ref by oracle/make_ref.py so that it exists on the GPU box; "port" =
+                   oracle/restate.py only where no reference is present): bounded sample of the SAME workload as ``value``,
+                   thread count chosen by a one-pair scan;
   parity        -- oracle/parity_sweep.py over pairs of the timed batch, bounded by a wall-clock budget (pairs not reached
                    are reported): config 3 = every round of the multi-homography loop replayed on the oracle from the
                    device's state + the oracle's own loop end to end ("ev_loop"); extra.quick_start.parity = the oracle end to
@@ -82,43 +83,47 @@ def cpu_baseline_subprocess(args):
     """The CPU leg in a child process with a hard wall-clock limit so that it can never stall the bench."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config, "--height", str(args.height),
            "--width", str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs", str(args.cpu_pairs)]
-    fail = {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "port"}
+    fail = {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "reference"}
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         for ln in out.stdout.splitlines():
             if ln.startswith("{"):
                 return json.loads(ln)
         return dict(fail, sample="cpu leg failed: " + out.stderr[-300:])
     except subprocess.TimeoutExpired:
-        return dict(fail, sample="cpu leg exceeded its 150 s limit")
+        return dict(fail, sample="cpu leg exceeded its 300 s limit")
 
 
 def cpu_baseline(args):
-    """Bounded CPU sample: the oracle restatement (kind = "port": /root/reference does not exist on the GPU box) on
-    `cpu_pairs` pairs of the workload ``--config`` names (3: the multi-homography loop of evaluation semantics; qs: the
-    quick_start path)."""
+    """Bounded CPU sample of the SAME workload as ``value`` on this host's cores.  kind = "reference": the reference itself
+    (oracle/ref_oracle.py: its CoarseAlign class, its outil.RANSAC, its nn.Modules, its PredFlowMask and its multi-homography
+    ``while`` statement, loaded from /root/reference or from the byte-compiled oracle/_ref that travels to the GPU box);
+    kind = "port" (oracle/restate.py) only where neither exists.  The thread count is chosen by a short scan (one pair each at
+    8 / 16 / 32 / 64 threads, as many as the box has): oneDNN's small convolutions do not scale to every core of a 2-socket host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import torch
-    import restate
+    import parity_sweep
     from rfx import synth, weights
-    torch.set_num_threads(cpu_threads())
+    O = parity_sweep.oracle_backend()
+    kind = "reference" if hasattr(O, "KIND") else "port"
     H, W = args.height, args.width
     if args.config == "3":
         sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
                    match=weights.net_matchability_sd(3, last_std=MULTIH_MATCH_STD))
-        ca = restate.CoarseAlignOracle(sds["trunk"], 7, 10000, 0.05, min(H, W), 2.0, variant="B")
+        ca = O.CoarseAlignOracle(sds["trunk"], 7, 10000, 0.05, min(H, W), 2.0, variant="B")
         nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
         nh = []
 
         def one(seed):
             I1, I2 = synth.make_pair(H, W, seed=seed, homography=True)
             ca.setPair(I1, I2)
-            nh.append(len(restate.multi_h_loop(ca, nets, max_coarse=10, mask_region_th=0.01)["H"]))
-        what = "BASELINE config 3 as worded (variant B, 7 scales x2, coarseIter 10 000, multi-homography loop, PredFlowMask per homography)"
+            nh.append(len(O.multi_h_loop(ca, nets, max_coarse=10, mask_region_th=0.01)["H"]))
+        what = ("BASELINE config 3 as worded (variant B CoarseAlign.setPair, 7 scales x2, coarseIter 10 000, the multi-homography "
+                "loop of evaluation/evalHpatch/evaluation.py:211-243 with a PredFlowMask per homography)")
     else:
         sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2))
-        ca = restate.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
+        ca = O.CoarseAlignOracle(sds["trunk"], args.nb_scale, args.nb_iter, 0.05, max(H, W), 1.2, variant="A")
         nets = dict(feat=sds["feat"], flow=sds["flow"])
         nh = None
 
@@ -128,13 +133,26 @@ def cpu_baseline(args):
             ca.setTarget(I2)
             r = ca.getCoarse(np.zeros((ca.It.size[1], ca.It.size[0])))
             with torch.no_grad():
-                fc = restate.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
-                restate.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
-        what = "full coarse+fine quick_start path"
+                fc = O.warp_grid(torch.from_numpy(r["H"])[None], ca.It.size[1], ca.It.size[0])
+                O.fine_step_quickstart(nets, ca.IsTensor, ca.ItTensor, fc)
+        what = "full coarse+fine quick_start path (quick_start/align2images.py:53-97)"
 
+    avail = cpu_threads()
+    cand = sorted({t for t in (8, 16, 32, 64) if t <= avail} | ({avail} if avail < 8 else set()))
+    torch.set_num_threads(cand[0])
     t0 = time.perf_counter()
-    one(1000)  # warm-up
+    one(1000)  # warm-up (oneDNN primitive caches, lazy imports)
     warm = time.perf_counter() - t0
+    scan = {}
+    for t in cand:
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        one(1500)
+        scan[t] = round(time.perf_counter() - t0, 2)
+        if warm > 30:
+            break
+    best = min(scan, key=scan.get)
+    torch.set_num_threads(best)
     if nh:
         nh.clear()
     t0 = time.perf_counter()
@@ -145,10 +163,11 @@ def cpu_baseline(args):
         if time.perf_counter() - t0 > 25 or (n == 1 and warm > 30):
             break
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d synthetic %dx%d pairs, %s (oracle/restate.py: a CPU port of the reference path, not the reference "
-                      "itself; reference/port time ratio measured in the authoring container: profiles/r03_cpu_reference_vs_port.json)"
-                      "%s, %.1f s" % (n, H, W, what, (", %.1f homographies per pair" % (sum(nh) / len(nh))) if nh else "", dt)}
+    return {"value": n / dt, "unit": "pairs/s", "cores": best, "kind": kind, "oracle": parity_sweep.oracle_name(O),
+            "threads_scan_s_per_pair": {str(k): v for k, v in scan.items()}, "host_logical_cpus": os.cpu_count(),
+            "sample": "%d synthetic %dx%d pairs, %s, executed by %s on %d threads (best of a one-pair scan over %s threads)"
+                      "%s, %.1f s" % (n, H, W, what, parity_sweep.oracle_name(O), best, "/".join(str(c) for c in cand),
+                                      (", %.1f homographies per pair" % (sum(nh) / len(nh))) if nh else "", dt)}
 
 
 def parity_subprocess(cfg, dump_dir, seeds, H, W, budget):
@@ -224,6 +243,47 @@ def self_spawn(args):
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("--gpus %d without WORLD_SIZE: launching %d ranks via torch.distributed.run (port %d)" % (args.gpus, args.gpus, port))
     sys.exit(subprocess.call(cmd))
+
+
+def preflight(dist, backend, rank, world, dev):
+    """Process-group bring-up with a diagnosis instead of a hang: init (RCCL: eager communicator on this rank's GPU) -> a 1 MB
+    ``all_gather_into_tensor`` whose content is checked -> barrier, all under a 60 s limit BEFORE the workload is built.  On
+    failure every rank prints one line (visible devices, HSA_ENABLE_IPC_MODE_LEGACY, RCCL version, rendezvous) and re-raises."""
+    import datetime
+    import torch
+    t0 = time.perf_counter()
+    stage = "init_process_group"
+    try:
+        kw = dict(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("RFX_PREFLIGHT_TIMEOUT", "60"))))
+        if backend == "nccl":
+            kw["device_id"] = dev
+        dist.init_process_group(**kw)
+        stage = "all_gather_into_tensor (1 MB)"
+        n = 262144
+        mine = torch.full((n,), float(rank), dtype=torch.float32, device=dev if backend == "nccl" else None)
+        allr = torch.empty((world * n,), dtype=torch.float32, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)
+        stage = "barrier"
+        dist.barrier()
+        if dev is not None:
+            torch.cuda.synchronize()
+        got = allr.view(world, n)[:, 0].tolist()
+        if got != [float(r) for r in range(world)]:
+            raise RuntimeError("all_gather returned ranks %s" % got)
+        log("preflight ok: %s, %d rank(s), 1 MB all_gather + barrier in %.2f s" % (backend, world, time.perf_counter() - t0))
+    except Exception as e:  # noqa: BLE001 -- diagnose, then fail
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "-"
+        except Exception:  # noqa: BLE001
+            ver = "?"
+        sys.stderr.write("[bench preflight FAILED] rank %d/%d at %s after %.1f s: %s: %s | backend=%s rccl=%s visible_devices=%d "
+                         "HIP_VISIBLE_DEVICES=%s ROCR_VISIBLE_DEVICES=%s HSA_ENABLE_IPC_MODE_LEGACY=%s MASTER=%s:%s device=%s\n"
+                         % (rank, world, stage, time.perf_counter() - t0, type(e).__name__, str(e)[:300], backend, ver,
+                            torch.cuda.device_count() if torch.cuda.is_available() else 0, os.environ.get("HIP_VISIBLE_DEVICES"),
+                            os.environ.get("ROCR_VISIBLE_DEVICES"), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                            os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), dev))
+        sys.stderr.flush()
+        raise
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -501,10 +561,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        preflight(dist, backend, rank, world, dev)
     sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
 
     if args.dry_run:
@@ -608,12 +665,18 @@ def main():
             d = tempfile.mkdtemp(prefix="rfx_parity_")
             parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
             line["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.parity_budget)
+    if dist is not None:
+        # all collectives are done: leave the group BEFORE rank 0's CPU leg, so that no rank waits in a communicator for it
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and world > 1 and not args.dry_run and args.config in ("3", "qs") and not args.no_cpu_baseline:
+        # N > 1: the line still carries the host baseline (bounded, ~1 min); the parity sweeps stay with the N = 1 run
+        log("rank 0: timing the CPU reference (bounded sample, child process)")
+        line["cpu_baseline"] = cpu_baseline_subprocess(args)
     if extras:
         line["extra"] = extras
     if rank == 0:
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

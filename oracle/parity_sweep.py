@@ -50,6 +50,24 @@ for p in (HERE, os.path.join(ROOT, "ransac-flow_amd")):
         sys.path.insert(0, p)
 
 DRAW_SEED = 10_000
+
+
+def oracle_backend():
+    """The checker the sweeps run: the REFERENCE ITSELF (oracle/ref_oracle.py: /root/reference, or its byte-compiled form
+    oracle/_ref on the GPU box) whenever it is present, else the port (oracle/restate.py).  ``RFX_ORACLE=port`` forces the port."""
+    import ref_loader
+    if os.environ.get("RFX_ORACLE", "auto") != "port" and ref_loader.available():
+        import ref_oracle
+        ref_oracle.kind()
+        return ref_oracle
+    import restate
+    return restate
+
+
+def oracle_name(O=None):
+    O = O or oracle_backend()
+    return O.KIND if getattr(O, "KIND", None) else "port (oracle/restate.py)"
+
 TIE_EPS = 2e-5          # feature round-off is <= 2e-5 per element: a flip whose evidence exceeds this is NOT explained by it -> failure
 
 MULTIH_MATCH_STD = 3.0   # saturating matchability head of the multi-H workloads (bench.py, tests/golden/make_golden.py)
@@ -209,8 +227,8 @@ def _worker_init(threads, match_std=None):
 def oracle_pair(cfg_name, seed, H, W, sds=None):
     """The CPU oracle end to end on its own homography.  Returns (result dict, CoarseAlignOracle)."""
     import torch
-    import restate
     from rfx import synth
+    restate = oracle_backend()
     c = CONFIGS[cfg_name]
     sds = sds or _W.get("sds") or state_dicts()
     ca = restate.CoarseAlignOracle(sds["trunk"], c["nbScale"], c["nbIter"], 0.05, _min_size(c, H, W), c["scaleR"], variant=c["variant"],
@@ -230,6 +248,7 @@ def oracle_pair(cfg_name, seed, H, W, sds=None):
         else:
             i1, i2 = ca.index1, ca.index2
         return dict(ok=False, index1=i1.numpy(), index2=i2.numpy()), ca
+    r = dict(r)
     nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
     with torch.no_grad():
         fc = restate.warp_grid(torch.from_numpy(r["H"])[None], h, w)
@@ -246,7 +265,7 @@ def oracle_pair(cfg_name, seed, H, W, sds=None):
 def fine_given_h(cfg_name, ca, Hm, sds=None):
     """The oracle's fine stage with a homography handed over (isolates the fine stage from the match list)."""
     import torch
-    import restate
+    restate = oracle_backend()
     sds = sds or _W.get("sds") or state_dicts()
     nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
     h, w = ca.It.size[1], ca.It.size[0]
@@ -281,7 +300,7 @@ def compare(cfg_name, seed, H, W, gpu_npz):
     ref = set(zip(r["index1"].tolist(), r["index2"].tolist()))
     got = set(zip(g["index1"].tolist(), g["index2"].tolist()))
     same = bool(np.array_equal(r["index1"], g["index1"]) and np.array_equal(r["index2"], g["index2"]))
-    rec = dict(seed=int(seed), n_matches_oracle=len(ref), n_matches_gpu=len(got), identical_list=same,
+    rec = dict(seed=int(seed), oracle=oracle_name(), n_matches_oracle=len(ref), n_matches_gpu=len(got), identical_list=same,
                n_differing=len(ref ^ got), oracle_ok=bool(r["ok"]), gpu_ok=bool(g["ok"]))
     if not same:
         rec["flips"] = tie_evidence(ca, sorted(ref - got), sorted(got - ref))
@@ -320,7 +339,7 @@ def downstream_given_matches(cfg_name, seed, ca, g):
     """Everything downstream of the arg-max on the DEVICE's match list: the oracle's RANSAC with the same draw (the draw the
     device made: ``draw(seed, nMatch_device, nbIter)``) and the oracle's fine stage on the oracle's own H from it.  Shows that
     a pair whose match list differs by a near-tie is exact from there on."""
-    import restate
+    restate = oracle_backend()
     c = CONFIGS[cfg_name]
     m1, m2 = matches_from_indices(ca, g["index1"], g["index2"])
     Hb, cnt, inl, _ = restate.ransac(m1, m2, 0.05, draw(seed, len(m1), c["nbIter"]))
@@ -344,7 +363,8 @@ def compare_loop(cfg_name, seed, gpu_npz):
     the oracle from the device's own state (teacher-forced); (3) the oracle's own loop end to end (free run)."""
     import torch
     import torch.nn.functional as F
-    import restate
+    restate = oracle_backend()
+    is_ref = hasattr(restate, "KIND")
     c = CONFIGS[cfg_name]
     H, W = c["H"], c["W"]
     g = np.load(gpu_npz)
@@ -372,7 +392,7 @@ def compare_loop(cfg_name, seed, gpu_npz):
     ref = set(zip(ca.index1.tolist(), ca.index2.tolist()))
     got = set(zip(g["index1"].tolist(), g["index2"].tolist()))
     same = bool(np.array_equal(ca.index1.numpy(), g["index1"]) and np.array_equal(ca.index2.numpy(), g["index2"]))
-    rec = dict(seed=int(seed), nA=int(ca.featsMultiScale.shape[1]), nB=int(ca.featt.shape[2] * ca.featt.shape[3]),
+    rec = dict(seed=int(seed), oracle=oracle_name(restate), nA=int(ca.featsMultiScale.shape[1]), nB=int(ca.featt.shape[2] * ca.featt.shape[3]),
                n_matches_oracle=len(ref), n_matches_gpu=len(got), identical_list=same, n_differing=len(ref ^ got),
                rounds=int(len(g["n"])), nbH_gpu=int(g["nbH"]))
     if not same:
@@ -396,7 +416,16 @@ def compare_loop(cfg_name, seed, gpu_npz):
             if n_or < 4 and int(g["n"][k]) < 4:
                 r["both_below_4"] = True
             continue
-        Hb, cnt, inl, _ = restate.ransac(m1_all[valid], m2_all[valid], 0.05, draw_round(seed, k, n_or, c["nbIter"]))
+        if is_ref:
+            # the REFERENCE's own getCoarse(fgMask) on the device's cached match list: its mask interpolation, its selection of
+            # the surviving matches, its outil.RANSAC -- with this round's draw handed to utils/outil.py:120
+            ca.set_matches(i1d, i2d)
+            res = ca.getCoarse(fg, sample_fn=lambda n, it, k=k: draw_round(seed, k, n, it))
+            ca.set_matches(None, None)
+            assert ca.last["n"] == n_or, "the reference kept %d matches, the restated mask lines %d" % (ca.last["n"], n_or)
+            Hb, inl = (None, None) if res is None else (res["H"], res["inlier"])
+        else:
+            Hb, cnt, inl, _ = restate.ransac(m1_all[valid], m2_all[valid], 0.05, draw_round(seed, k, n_or, c["nbIter"]))
         r["status_equal"] = (Hb is None) == (int(g["status"][k]) != 0)
         if Hb is None or int(g["status"][k]) != 0:
             rr.append(r)
@@ -503,7 +532,8 @@ def summarise_loop(cfg_name, records, n_requested, elapsed):
     fr = [r["free_run"] for r in done]
     mx = lambda key, rows=full: max([q[key] for q in rows if key in q], default=None)
     thr = [q for q in full if "mask_diff_at_threshold" in q]
-    s = dict(config=cfg_name, size="%dx%d" % (c["H"], c["W"]), pairs=len(done), pairs_requested=n_requested,
+    s = dict(config=cfg_name, oracle=(done[0].get("oracle") if done else oracle_name()), size="%dx%d" % (c["H"], c["W"]), pairs=len(done),
+             pairs_requested=n_requested,
              errors=[r for r in records if "error" in r],
              nA=done[0]["nA"] if done else None, nB=done[0]["nB"] if done else None,
              identical_lists=sum(1 for r in done if r["identical_list"]), total_matches=sum(r["n_matches_oracle"] for r in done),
@@ -578,7 +608,7 @@ def _stab_job(args):
 def summarise_stability(cfg_name, records, H, W, ta, tb):
     done = [r for r in records if "error" not in r]
     flips = [f for r in done for f in r.get("flips", [])]
-    return dict(kind="oracle_vs_oracle", config=cfg_name, size="%dx%d" % (H, W),
+    return dict(kind="oracle_vs_oracle", oracle=oracle_name(), config=cfg_name, size="%dx%d" % (H, W),
                 settings=["%d threads, oneDNN on" % ta, "%d thread(s), oneDNN off" % tb], pairs=len(done),
                 errors=[r for r in records if "error" in r],
                 pairs_with_flips=sum(1 for r in done if not r["identical_list"]),
@@ -606,7 +636,8 @@ def summarise(cfg_name, records, n_requested, elapsed, H, W):
     diff = [r for r in done if not r["identical_list"]]
     flips = [f for r in diff for f in r["flips"]]
     both_ok = [r for r in done if "max_abs_flow_delta_e2e" in r]
-    s = dict(config=cfg_name, size="%dx%d" % (H, W), pairs=len(done), pairs_requested=n_requested,
+    s = dict(config=cfg_name, oracle=(done[0].get("oracle") if done else oracle_name()), size="%dx%d" % (H, W), pairs=len(done),
+             pairs_requested=n_requested,
              errors=[r for r in records if "error" in r],
              identical_lists=len(ident),
              inlier_exact=sum(1 for r in ident if r.get("inlier_indices_bit_exact")),

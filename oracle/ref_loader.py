@@ -10,10 +10,14 @@ stubs so that they run on a GPU-less host:
 3. a fake ``kornia.geometry.HomographyWarper`` whose ``warp_grid`` restates kornia 0.1.4's
    documented behaviour (requirements.txt:59; kornia itself is not in /root/reference).
 
-It exists ONLY in the authoring container (``/root/reference`` is absent on the GPU box): it is
-used by ``tests/golden/make_golden.py`` to generate the committed golden vectors and by the
-``-m "not gpu"`` tests that pin ``oracle/restate.py`` against the real reference.  Nothing in the
-product path (``ransac-flow_amd/``) may import it.
+Where it finds the reference (``REF_ROOT``): ``$RFX_REFERENCE_ROOT`` if set; else ``/root/reference`` (the source tree:
+authoring container only); else ``oracle/_ref`` -- the reference BYTE-COMPILED from where it lies by the committed recipe
+``oracle/make_ref.py`` (run by ``__graft_entry__.build()``), git-ignored, which travels to the GPU box like a built ``.so``.
+Both forms execute the same code objects: ``tests/test_oracle_pins.py::test_staged_reference_equals_the_source_tree``.
+
+It is used by ``tests/golden/make_golden.py`` to generate the committed golden vectors, by the tests that pin
+``oracle/restate.py`` against the real reference, and (through ``oracle/ref_oracle.py``) by the parity sweeps and
+``bench.py``'s ``cpu_baseline`` leg.  Nothing in the product path (``ransac-flow_amd/``) may import it.
 """
 import os
 import sys
@@ -24,11 +28,67 @@ import io
 import numpy as np
 import torch
 
-REF_ROOT = os.environ.get("RFX_REFERENCE_ROOT", "/root/reference")
+STAGED_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _default_root():
+    env = os.environ.get("RFX_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/utils"):
+        return "/root/reference"
+    return STAGED_ROOT
+
+
+REF_ROOT = _default_root()
 
 
 def available() -> bool:
     return os.path.isdir(os.path.join(REF_ROOT, "utils"))
+
+
+def staged() -> bool:
+    """True when REF_ROOT holds the byte-compiled form (oracle/make_ref.py), not the source tree."""
+    return available() and not os.path.isfile(os.path.join(REF_ROOT, "utils", "outil.py"))
+
+
+def kind() -> str:
+    return "reference (byte-compiled by oracle/make_ref.py)" if staged() else "reference (source tree)"
+
+
+def ref_path(rel):
+    """Path of a reference file: the source where the tree is mounted, else its compiled form under oracle/_ref."""
+    p = os.path.join(REF_ROOT, rel)
+    if os.path.isfile(p) or not rel.endswith(".py"):
+        return p
+    pc = p[:-3] + ".pyc"
+    if os.path.isfile(pc):
+        _check_magic()
+        return pc
+    raise FileNotFoundError("reference file %s not found under %s (run oracle/make_ref.py where /root/reference exists)" % (rel, REF_ROOT))
+
+
+_magic_ok = []
+
+
+def _check_magic():
+    if _magic_ok:
+        return
+    import importlib.util
+    import json
+    m = json.load(open(os.path.join(REF_ROOT, "MANIFEST.json")))
+    if m["magic"] != importlib.util.MAGIC_NUMBER.hex():
+        raise RuntimeError("oracle/_ref was compiled by python %s (bytecode magic %s), this interpreter has %s: rebuild it"
+                           % (m["python"], m["magic"], importlib.util.MAGIC_NUMBER.hex()))
+    _magic_ok.append(True)
+
+
+def _extract(rel_path):
+    """Code objects oracle/make_ref.py compiled out of a reference script (staged form only)."""
+    import marshal
+    _check_magic()
+    with open(os.path.join(REF_ROOT, "_extract", rel_path[:-3] + ".marshal"), "rb") as f:
+        return marshal.load(f)
 
 
 _loaded = {}
@@ -46,10 +106,19 @@ def _install_stubs():
     tvt = types.ModuleType("torchvision.transforms")
 
     def _resnet50(pretrained=False, **kw):
-        sys.path.insert(0, os.path.join(REF_ROOT, "model"))
-        import importlib
-        r50 = importlib.import_module("resnet50")
-        return r50.resnet50()
+        if "resnet50" not in sys.modules:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("resnet50", ref_path("model/resnet50.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            sys.modules["resnet50"] = mod
+        net = sys.modules["resnet50"].resnet50()
+        pth = os.environ.get("RFX_TRUNK_WEIGHTS")          # shared with the drop-in (dropin/coarseAlignFeatMatch.py): no ImageNet weights offline
+        if pth:
+            sd = torch.load(pth, map_location="cpu")
+            missing = net.load_state_dict(sd, strict=False)
+            assert not missing.unexpected_keys, missing.unexpected_keys
+        return net
 
     tvm.resnet50 = _resnet50
 
@@ -143,20 +212,20 @@ def load():
     sys.path.insert(0, os.path.join(REF_ROOT, "model"))
     sys.path.insert(0, os.path.join(REF_ROOT, "utils"))
     with contextlib.redirect_stdout(io.StringIO()):
-        outil = _imp("outil", os.path.join(REF_ROOT, "utils", "outil.py"))
+        outil = _imp("outil", ref_path("utils/outil.py"))
         sys.modules["outil"] = outil
-        downsample = _imp("downsample", os.path.join(REF_ROOT, "model", "downsample.py"))
+        downsample = _imp("downsample", ref_path("model/downsample.py"))
         sys.modules["downsample"] = downsample
-        resnet50 = _imp("resnet50", os.path.join(REF_ROOT, "model", "resnet50.py"))
+        resnet50 = _imp("resnet50", ref_path("model/resnet50.py"))
         sys.modules["resnet50"] = resnet50
-        model = _imp("ref_model", os.path.join(REF_ROOT, "model", "model.py"))
+        model = _imp("ref_model", ref_path("model/model.py"))
         cwd = os.getcwd()
         try:
             os.chdir(os.path.join(REF_ROOT, "quick_start"))
-            caA = _imp("ref_coarseAlignA", os.path.join(REF_ROOT, "quick_start", "coarseAlignFeatMatch.py"))
+            caA = _imp("ref_coarseAlignA", ref_path("quick_start/coarseAlignFeatMatch.py"))
             os.chdir(os.path.join(REF_ROOT, "evaluation", "evalHpatch"))
             # variant B refers to a module-level name `resnet50` only when imageNet=False
-            caB = _imp("ref_coarseAlignB", os.path.join(REF_ROOT, "evaluation", "evalHpatch", "coarseAlignFeatMatch.py"))
+            caB = _imp("ref_coarseAlignB", ref_path("evaluation/evalHpatch/coarseAlignFeatMatch.py"))
         finally:
             os.chdir(cwd)
     _loaded.update(dict(outil=outil, model=model, resnet50=resnet50, downsample=downsample,
@@ -172,10 +241,16 @@ def script_functions(rel_path, names):
     and executed from where it lies; nothing is copied."""
     import ast
     _install_stubs()
-    path = os.path.join(REF_ROOT, rel_path)
-    tree = ast.parse(open(path).read(), filename=path)
-    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
-    missing = set(names) - {n.name for n in keep}
+    if staged():
+        have = _extract(rel_path)["functions"]
+        missing = set(names) - set(have)
+        codes = [have[n] for n in have if n in names]            # dicts keep the script's definition order
+    else:
+        path = os.path.join(REF_ROOT, rel_path)
+        tree = ast.parse(open(path).read(), filename=path)
+        keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        missing = set(names) - {n.name for n in keep}
+        codes = [compile(ast.Module(body=keep, type_ignores=[]), path, "exec")]
     if missing:
         raise KeyError("not in %s: %s" % (rel_path, sorted(missing)))
     from scipy import ndimage
@@ -184,7 +259,8 @@ def script_functions(rel_path, names):
         label=lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0])
     ns = {"np": np, "torch": torch, "F": torch.nn.functional, "os": os, "tgm": sys.modules["kornia.geometry"],
           "nd": ndimage, "measure": measure}
-    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    for code in codes:
+        exec(code, ns)
     return {n: ns[n] for n in names}
 
 
@@ -196,17 +272,19 @@ def script_loop(rel_path, test_src, extra_ns=None):
     would have set up before the loop).  Nothing is copied: the source is parsed and executed in place."""
     import ast
     _install_stubs()
-    path = os.path.join(REF_ROOT, rel_path)
-    tree = ast.parse(open(path).read(), filename=path)
     want = ast.dump(ast.parse(test_src, mode="eval").body)
-    loop = None
-    for node in ast.walk(tree):
-        if isinstance(node, ast.While) and ast.dump(node.test) == want:
-            loop = node
-            break
-    if loop is None:
+    if staged():
+        code = _extract(rel_path)["loops"].get(want)
+    else:
+        path = os.path.join(REF_ROOT, rel_path)
+        tree = ast.parse(open(path).read(), filename=path)
+        code = None
+        for node in ast.walk(tree):
+            if isinstance(node, ast.While) and ast.dump(node.test) == want:
+                code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+                break
+    if code is None:
         raise KeyError("no `while %s` in %s" % (test_src, rel_path))
-    code = compile(ast.Module(body=[loop], type_ignores=[]), path, "exec")
     from scipy import ndimage
     measure = types.SimpleNamespace(
         label=lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0])

@@ -12,7 +12,8 @@ them), picks the CoarseAlign variant from the script's directory, installs small
 script imports but this image lacks (kornia's HomographyWarper -> librfx warp_grid kernel; torchvision
 transforms; scipy.misc.imresize; segEval), optionally rebinds ``torch.nn.functional.grid_sample`` /
 ``interpolate`` / ``normalize`` to the librfx kernels for float32 HIP tensors (``RFX_PATCH_FUNCTIONAL=1``,
-default on), and then runs the script with ``runpy`` from its own directory.
+default on), and then runs the script with ``runpy`` from its own directory.  ``RFX_RANSAC_SEED=S`` makes the RANSAC draws
+reproducible (see ``seed_ransac_calls``).  A byte-compiled deployment of the reference tree (``align2images.pyc``) runs as is.
 """
 import importlib
 import os
@@ -159,6 +160,24 @@ def setup(script_path):
         sys.modules[name] = importlib.import_module(name)
     if os.environ.get("RFX_PATCH_FUNCTIONAL", "1") == "1":
         patch_functional()
+    if os.environ.get("RFX_RANSAC_SEED"):
+        seed_ransac_calls(int(os.environ["RFX_RANSAC_SEED"]))
+
+
+def seed_ransac_calls(seed):
+    """Reproducible runs (``RFX_RANSAC_SEED=S``): reseed the CPU generator with S + k before the k-th ``outil.RANSAC`` call.  The
+    drop-in draws its hypotheses from that generator exactly like a CPU run of the reference does (utils/outil.py:120), so a
+    CPU run of the reference seeded the same way scores the same 4-point samples (evaluation/evalKITTI/evaluation.py:182 seeds
+    once per process; per call makes the draw independent of how much of the stream earlier stages consumed)."""
+    import torch
+    outil, n = sys.modules["outil"], [0]
+    real = outil.RANSAC
+
+    def RANSAC(*a, **k):
+        torch.manual_seed(seed + n[0])
+        n[0] += 1
+        return real(*a, **k)
+    outil.RANSAC = RANSAC
 
 
 def main():
@@ -173,11 +192,16 @@ def main():
         print(__doc__)
         sys.exit(2)
     script = os.path.abspath(argv[0])
+    if not os.path.isfile(script) and script.endswith(".py") and os.path.isfile(script + "c"):
+        script += "c"                      # a byte-compiled deployment of the reference tree (align2images.pyc): runpy runs it as is
     if not os.path.isfile(script):
         sys.exit("run_reference_script: no such script: %s" % script)
     setup(script)
     sys.argv = [script] + argv[1:]
     os.chdir(os.path.dirname(script))
+    # ``python script.py`` puts the script's directory first on sys.path (evaluation/evalHpatch/evaluation.py:9 imports its
+    # sibling ``utils``); the drop-ins stay in front of same-named siblings because they are already in sys.modules
+    sys.path.insert(0, os.path.dirname(script))
     runpy.run_path(script, run_name="__main__")
 
 

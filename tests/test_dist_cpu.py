@@ -76,8 +76,25 @@ def test_bench_rank_code_self_spawns_two_gloo_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
     assert j["config"]["ranks_seen_in_gather"] == [0, 1] and j["config"]["gathered_records"] == 8
     assert j["value"] > 0 and abs(j["value"] - 4 * 3 * 2 / (j["ms_per_step"] * 3e-3)) < 1e-2 * j["value"]
+    assert "preflight ok: gloo, 2 rank(s)" in out.stderr        # init + 1 MB all_gather + barrier before the workload is built
     # a single rank stays a single process and says so
     out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0", "--batch", "3"],
                           capture_output=True, text=True, timeout=120, env=env)
     j1 = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][0])
     assert j1["n_gpus"] == 1 and j1["config"]["ranks_seen_in_gather"] == [0] and j1["config"]["gathered_records"] == 3
+
+
+def test_bench_preflight_diagnoses_a_missing_rank_instead_of_hanging():
+    """A rank whose peers never arrive (here: WORLD_SIZE=2 with only rank 0 started) must fail within the preflight limit with the
+    one-line diagnosis (stage, backend, visible devices, IPC mode, rendezvous), not hang until the driver's clock runs out."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFX_PREFLIGHT_TIMEOUT="5")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0
+    assert "[bench preflight FAILED] rank 0/2 at init_process_group" in out.stderr, out.stderr[-1500:]
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=" in out.stderr and "MASTER=127.0.0.1:%d" % port in out.stderr

@@ -1,10 +1,10 @@
-"""The reference's entry scripts replayed on the drop-in modules (ransac-flow_amd/dropin) on a real GPU.
+"""The reference's entry scripts on the drop-in modules (ransac-flow_amd/dropin) on a real GPU.
 
-/root/reference is not present on the GPU box, so the scripts themselves cannot be run there; these tests
-execute the same call sequences (quick_start/align2images.py:30-97 and the multi-homography loop of
-evaluation/evalHpatch/evaluation.py:164-243) against the drop-in ``outil`` / ``model`` / ``coarseAlignFeatMatch``
-modules exactly as ``run_reference_script.py`` sets them up (sys.modules names, kornia/torchvision stand-ins,
-F.grid_sample / F.interpolate / F.normalize rebound to librfx), and compare with the CPU oracle."""
+Two kinds of test.  (1) Replays: the scripts' call sequences (quick_start/align2images.py:30-97, the multi-homography loop of
+evaluation/evalHpatch/evaluation.py:164-243) typed out against the drop-in ``outil`` / ``model`` / ``coarseAlignFeatMatch``
+modules exactly as ``run_reference_script.py`` sets them up, compared with the CPU oracle stage by stage.  (2) The scripts
+THEMSELVES, unmodified, end to end through the launcher, compared with the reference's own CPU run of the same command on
+the same box -- the reference travels to the GPU box byte-compiled (oracle/_ref, recipe oracle/make_ref.py)."""
 import importlib
 import os
 import sys
@@ -235,20 +235,102 @@ def test_coarse_align_variant_c_yfcc(dev, launcher_env):
         cam.CoarseAlign(3, 300, 0.05, "Homography", 240, 1, True, False, True, False, 1.2, trunk_state_dict=trunk_sd)
 
 
-def test_unchanged_reference_script_end_to_end_if_a_tree_is_mounted(dev, tmp_path):
-    """quick_start/align2images.py itself, unmodified, through dropin/run_reference_script.py on the GPU.  The GPU box has no
-    /root/reference (nothing of the reference is shipped), so this runs only where RFX_REFERENCE_ROOT points at a mounted
-    tree (the driver / judge can do that); the CPU-side test tests/test_dropin_cpu.py::test_unchanged_reference_script_...
-    proves in the authoring container that the same command reaches the script's first device call."""
+def _reference_tree():
+    """The reference on THIS machine: /root/reference (authoring container) or the byte-compiled oracle/_ref that
+    __graft_entry__.build() stages through oracle/make_ref.py and that travels to the GPU box like a built .so."""
+    import ref_loader
+    if not ref_loader.available():
+        pytest.fail("no reference on this machine: neither /root/reference nor oracle/_ref -- run __graft_entry__.build() where "
+                    "/root/reference exists (oracle/make_ref.py) before shipping the tree to the GPU box")
+    return ref_loader
+
+
+def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16):
+    """One unchanged reference script, same command line twice: on the MI355X drop-ins (dropin/run_reference_script.py) and as
+    the reference itself on this box's host cores (oracle/run_ref_script.py); the k-th RANSAC call of both runs draws from the
+    CPU generator seeded with seed + k.  Returns the two output prefixes."""
     import subprocess
-    root = os.environ.get("RFX_REFERENCE_ROOT", "/root/reference")
-    script = os.path.join(root, "quick_start", "align2images.py")
-    if not os.path.isfile(script):
-        pytest.skip("no reference tree on this machine (set RFX_REFERENCE_ROOT)")
+    rl = _reference_tree()
+    trunk = tmp_path / "trunk.pth"
+    torch.save(weights.resnet50_trunk_sd(0), str(trunk))
+    outs = {}
+    for side in ("gpu", "cpu"):
+        out = str(tmp_path / ("out_" + side)) + ("/" if out_flag == "--outdir" else "")
+        if out_flag == "--outdir":
+            os.makedirs(out)
+        env = dict(os.environ, MPLBACKEND="Agg", RFX_TRUNK_WEIGHTS=str(trunk), RFX_REFERENCE_ROOT=rl.REF_ROOT)
+        if side == "gpu":
+            env["RFX_RANSAC_SEED"] = str(seed)
+            cmd = [sys.executable, os.path.join(DROPIN, "run_reference_script.py"), os.path.join(rl.REF_ROOT, rel_script)]
+        else:
+            env["RFX_CPU_THREADS"] = str(cpu_threads)
+            cmd = [sys.executable, os.path.join(ROOT, "oracle", "run_ref_script.py"), rel_script, "--rfx-ransac-seed", str(seed)]
+        r = subprocess.run(cmd + args + [out_flag, out], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, "%s run of %s failed:\n%s" % (side, rel_script, r.stderr[-3000:])
+        outs[side] = out
+    return outs["gpu"], outs["cpu"]
+
+
+def test_unchanged_align2images_script_end_to_end_vs_the_reference_cpu_run(dev, tmp_path):
+    """quick_start/align2images.py:1-118 ITSELF, unmodified (its byte-compiled form on the GPU box), on its own two sample
+    images: once through dropin/run_reference_script.py on the MI355X and once as the reference on the host CPU.  Same
+    checkpoint, same trunk weights, same RANSAC draws -> the saved target is identical and the aligned source image agrees to
+    PNG quantisation."""
+    import PIL.Image as Image
     ck = tmp_path / "ck.pth"
-    torch.save(_save_ckpt(str(ck)), str(ck))
-    env = dict(os.environ, MPLBACKEND="Agg", RFX_ALLOW_RANDOM_TRUNK="1")
-    out = subprocess.run([sys.executable, os.path.join(DROPIN, "run_reference_script.py"), script, "--resumePth", str(ck), "--outdir",
-                          str(tmp_path / "out"), "--coarseIter", "1000"], capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert any(f.endswith(".png") or f.endswith(".jpg") for f in os.listdir(str(tmp_path / "out")))
+    _save_ckpt(str(ck))
+    g, c = _run_both("quick_start/align2images.py", ["--resumePth", str(ck), "--coarseIter", "2000"], tmp_path, 11, "--outdir")
+    for f in ("comb_coarse_alignment.png", "comb_fine_alignment.png", "fine_aligned_source.png", "resized_target.png"):
+        assert os.path.isfile(g + f) and os.path.isfile(c + f), f
+    tg, tc = (np.asarray(Image.open(d + "resized_target.png").convert("RGB")) for d in (g, c))
+    assert np.array_equal(tg, tc)                                              # LANCZOS resize: byte-exact
+    ag, ac = (np.asarray(Image.open(d + "fine_aligned_source.png").convert("RGB")).astype(np.int32) for d in (g, c))
+    assert ag.shape == ac.shape == tg.shape
+    d = np.abs(ag - ac)
+    print("align2images.py device vs reference CPU run: aligned image max |d| = %d grey levels, mean %.4f, pixels off by > 1: %.5f"
+          % (d.max(), d.mean(), (d > 1).mean()))
+    # flow agreement < 1e-3 (normalised) = < 0.2 px: a bilinear sample moves by a fraction of the local gradient, the uint8
+    # rounding by one level; a different homography (a flipped near-tie match changes nMatch and with it the draw) would move
+    # whole regions by many levels
+    assert d.mean() < 0.25 and (d > 2).mean() < 0.01
+
+
+def test_unchanged_evalhpatch_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):
+    """evaluation/evalHpatch/evaluation.py:164-260 ITSELF, unmodified, over a synthetic HPatches-shaped stream (5 scenes x 1
+    pair of 240x320 homography-warped images, csv + .ppm layout of the script): device drop-ins vs the reference on the host
+    CPU.  Compares what the script saves per pair (:254-260): the number of homographies, the homographies, the /8 flows and
+    matchability maps."""
+    sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+           "netMatch": weights.net_matchability_sd(3, last_std=3.0)}
+    ck = tmp_path / "ck.pth"
+    torch.save(sds, str(ck))
+    os.makedirs(str(tmp_path / "csv"))
+    for k in range(2, 7):
+        obj = "v_synth%d" % k
+        os.makedirs(str(tmp_path / "img" / obj))
+        I1, I2 = synth.make_pair(240, 320, seed=40 + k, homography=True)
+        I1.save(str(tmp_path / "img" / obj / "1.ppm"))
+        I2.save(str(tmp_path / "img" / obj / ("%d.ppm" % k)))
+        open(str(tmp_path / "csv" / ("hpatches_1_%d.csv" % k)), "w").write("obj,im1,im2\n%s,1,%d\n" % (obj, k))
+    args = ["--csv-path", str(tmp_path / "csv"), "--image-data-path", str(tmp_path / "img"), "--coarseIter", "1000", "--nbScale", "3",
+            "--minSize", "240", "--scaleR", "1.2", "--imageNet", "--resumePth", str(ck)]
+    g, c = _run_both("evaluation/evalHpatch/evaluation.py", args, tmp_path, 23, "--outDir")
+    same_nb, exact = 0, 0
+    for k in range(2, 7):
+        fg, fc = (sorted(os.listdir(os.path.join(d + "_Fine", str(k)))) for d in (g, c))
+        assert len(fg) == 3 and len(fc) == 3, (fg, fc)                        # flow_, mask_, maskBG_ of the scene's one pair
+        if fg != fc:                                                          # the file names carry the number of homographies
+            print("scene %d: %s vs %s" % (k, fg, fc))
+            continue
+        same_nb += 1
+        name = [f for f in fg if f.startswith("flow_")][0]
+        Hg, Hc = (np.load(os.path.join(d + "_Coarse", str(k), name)) for d in (g, c))
+        Fg, Fc = (np.load(os.path.join(d + "_Fine", str(k), name)) for d in (g, c))
+        Mg, Mc = (np.load(os.path.join(d + "_Fine", str(k), name.replace("flow_", "mask_"))) for d in (g, c))
+        dH, dF, dM = np.abs(Hg - Hc).max(), np.abs(Fg - Fc).max(), np.abs(Mg - Mc).max()
+        print("scene %d: %d homographies, max |dH| %.2e, |d flowDown8| %.2e, |d matchDown8| %.2e" % (k, len(Hg), dH, dF, dM))
+        if dH <= 1e-5 and dF < 1e-3 and dM < 1e-3:
+            exact += 1
+    # a scene whose cached match list differs by a float32 near-tie draws other samples (nMatch enters torch.randint) and may
+    # stop at another homography count: tests/test_gpu_parity_sweep.py counts and bounds those; here at most one scene may
+    assert same_nb >= 4 and exact >= 4, (same_nb, exact)

@@ -12,6 +12,7 @@ own functions / classes / loop statements, compiled from where they lie under /r
 (tests/golden/make_golden.py); they are checked on every machine.  The ``-m reference`` tests repeat the comparison
 live on fresh seeds in the authoring container.  CPU only."""
 import os
+import sys
 import types
 
 import numpy as np
@@ -259,3 +260,94 @@ def test_kitti_loop_matches_live_reference():
     assert np.abs(np.stack(o["H"]) - torch.cat(ns["Homography"]).numpy()).max() <= 1e-6
     assert np.abs(np.concatenate(o["flowDown8"]) - torch.cat(ns["Finetune"]).numpy()).max() < 1e-5
     assert float((o["masks"][-1] != ns["Mask"]).mean()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ the staged reference (oracle/_ref)
+
+_STAGED_PROBE = r'''
+import json, sys, os, hashlib
+import numpy as np, torch
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "ransac-flow_amd")]
+torch.set_num_threads(4)
+import ref_loader, ref_oracle, parity_sweep
+from rfx import synth, weights
+out = dict(kind=ref_loader.kind(), staged=ref_loader.staged())
+h = hashlib.sha256()
+# (1) quick_start: the reference's CoarseAlign (variant A) + outil.RANSAC + nn.Modules, end to end on its own homography
+r, ca = parity_sweep.oracle_pair("qs", 3, 128, 160)
+for k in ("index1", "index2", "H", "inlier", "flow12"):
+    h.update(np.ascontiguousarray(r[k]).tobytes())
+# (2) the multi-homography ``while`` statement of evaluation/evalHpatch/evaluation.py + PredFlowMask compiled out of the script
+sds = parity_sweep.state_dicts(parity_sweep.MULTIH_MATCH_STD)
+cb = ref_oracle.CoarseAlignOracle(sds["trunk"], 3, 300, 0.05, 128, 1.2, variant="B", sample_fn=lambda n, it: parity_sweep.draw(9, n, it))
+cb.setPair(*synth.make_pair(128, 160, seed=9, homography=True))
+o = ref_oracle.multi_h_loop(cb, dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]), max_coarse=3, mask_region_th=0.01)
+out["nbH"] = len(o["H"])
+for a in o["H"] + o["flowDown8"] + o["matchDown8"] + o["masks"]:
+    h.update(np.ascontiguousarray(a).tobytes())
+# (3) the KITTI ``while True`` statement, get_info, remove_small_cc
+ck = ref_oracle.CoarseAlignOracle(sds["trunk"], 3, 300, 0.05, 160, 1.2, variant="B", sample_fn=lambda n, it: parity_sweep.draw(12, n, it))
+Is, It = synth.make_pair(96, 312, seed=12, homography=True, amp=0.03)
+ck.setPair(Is, It)
+k = ref_oracle.multi_h_loop_kitti(ck, dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"]), Is, It, 128, mask_region_th=0.01, cc_th=0.002)
+out["nbH_kitti"] = len(k["H"])
+for a in k["H"] + k["flowD2"] + k["flowDown8"] + k["matchDown8"] + k["masks"]:
+    h.update(np.ascontiguousarray(a).tobytes())
+# (4) the offline assembly functions of the three getResults.py scripts resolve
+for rel, names in (("evaluation/evalHpatch/getResults.py", ["getFlow_all", "getFlow_onlyCoarse"]), ("evaluation/evalCorr/getResults.py", ["getFlow", "getFlow_Coarse"])):
+    assert all(callable(f) for f in ref_loader.script_functions(rel, names).values())
+out["sha"] = h.hexdigest()
+print("PROBE" + json.dumps(out))
+'''
+
+
+@pytest.mark.reference
+def test_staged_reference_equals_the_source_tree(tmp_path):
+    """oracle/make_ref.py byte-compiles the reference from where it lies; the compiled tree (what the GPU box gets) must BE the
+    reference: the same probe -- variant-A alignment end to end, the Hpatch multi-homography loop statement, the KITTI loop
+    statement, each on fresh seeds -- run once on /root/reference and once on a freshly staged tree gives bit-identical outputs."""
+    import json
+    import subprocess
+    if not os.path.isdir("/root/reference/utils"):
+        pytest.skip("needs the reference SOURCE tree (authoring container) to stage from")
+    import make_ref
+    staged = make_ref.build(out=str(tmp_path / "_ref"), verbose=False)
+    assert not any(f.endswith(".py") for _, _, fs in os.walk(staged) for f in fs)          # compiled form only: no source travels
+    res = {}
+    for name, root in (("source", "/root/reference"), ("staged", staged)):
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + _STAGED_PROBE], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, RFX_REFERENCE_ROOT=root))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("PROBE")][0][5:])
+    assert res["source"]["staged"] is False and res["staged"]["staged"] is True
+    assert res["source"]["nbH"] >= 1 and res["source"]["nbH_kitti"] >= 1
+    assert {k: v for k, v in res["source"].items() if k not in ("kind", "staged")} == \
+           {k: v for k, v in res["staged"].items() if k not in ("kind", "staged")}
+
+
+def test_product_path_never_touches_the_oracle_or_the_staged_reference():
+    """Nothing under ransac-flow_amd/ (the product) may import, open or mention oracle/, oracle/_ref, ref_loader, ref_oracle,
+    restate or parity_sweep; bench.py may do so only in its CPU legs (functions that run in child processes / after the timed
+    region)."""
+    import re
+    bad = re.compile(r"\b(oracle|_ref\b|ref_loader|ref_oracle|restate|parity_sweep|make_ref|/root/reference)")
+    hits = []
+    pkg = os.path.join(ROOT, "ransac-flow_amd")
+    for d, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                for i, ln in enumerate(open(os.path.join(d, f), errors="replace"), 1):
+                    code = ln.split("#", 1)[0] if f.endswith(".py") else ln
+                    if bad.search(code) and "import" in code or re.search(r"(open|load|join)\(.*(oracle|_ref)", code):
+                        hits.append("%s:%d: %s" % (os.path.relpath(os.path.join(d, f), ROOT), i, ln.strip()))
+    assert not hits, "\n".join(hits)
+    # and the only python modules that import the oracle side are tests/, oracle/ itself, bench.py and __graft_entry__.py
+    importers = set()
+    for d, _, fs in os.walk(ROOT):
+        if any(p in d for p in ("gpurun_out", ".git", "__pycache__")):
+            continue
+        for f in fs:
+            if f.endswith(".py") and re.search(r"^\s*(import|from)\s+(ref_loader|ref_oracle|restate|parity_sweep|make_ref)\b",
+                                               open(os.path.join(d, f), errors="replace").read(), re.M):
+                importers.add(os.path.relpath(os.path.join(d, f), ROOT).split(os.sep)[0])
+    assert importers <= {"tests", "oracle", "bench.py", "__graft_entry__.py", "scripts"}, importers
