@@ -317,14 +317,14 @@ def build_workload(args, dev, rank, world):
     from rfx import dist as rdist
     H, W, B, cfg = args.height, args.width, args.batch, args.config
     draw = "host" if args.host_draw else "device"
-    draw_txt = ("RANSAC index draw: Philox on the device from the device-side match counts" if draw == "device" else
+    draw_txt = ("RANSAC index draw: Philox on the device from the device-side match counts, keyed by (seed, absolute pair id, round)" if draw == "device" else
                 "RANSAC index draw: torch.randint on the CPU generator per pair and homography")
     sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
                match=weights.net_matchability_sd(3))
     seeds = [rank + world * i for i in range(B)]        # this rank's shard of the synthetic stream: pair i -> rank i mod world
     if cfg in ("qs", "2"):
         pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
-                             variant="A", device=dev, draw=draw, seed=1000 + rank)
+                             variant="A", device=dev, draw=draw, seed=1000)
         pairs = [synth.make_pair(H, W, seed=s) for s in seeds]
         raw = pipe.upload_raw(pairs)
         prep0 = pipe.prepare(pairs) if args.host_prep else None
@@ -335,7 +335,7 @@ def build_workload(args, dev, rank, world):
         def step():
             r = _upload(raw_h, dev) if raw_h is not None else raw
             p, feats = (prep0, None) if prep0 is not None else pipe.prepare_and_features(*r)
-            res = pipe.align_prepared(p, fine=fine, feats=feats)
+            res = pipe.align_prepared(p, fine=fine, feats=feats, pair_ids=seeds)
             rec = rdist.pack_records(res, rank=rank) if fine else _coarse_records(res, dev, rank)
             return _download(rec, rec_h) if raw_h is not None else rec
         if fine:
@@ -352,7 +352,7 @@ def build_workload(args, dev, rank, world):
     if cfg in ("3", "4"):
         nbScale, nbIter = (7, 10000) if cfg == "3" else (5, 50000)
         pipe = AlignPipeline(sds, nbScale=nbScale, nbIter=nbIter, tolerance=0.05, minSize=min(H, W), scaleR=2.0, variant="B", device=dev,
-                             draw=draw, seed=1000 + rank)
+                             draw=draw, seed=1000)
         raw = pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True) for s in seeds])
 
         raw_h, rec_h = _pinned(raw) if args.pcie else None, {}
@@ -361,7 +361,7 @@ def build_workload(args, dev, rank, world):
             prep = pipe.prepare_device(*(_upload(raw_h, dev) if raw_h is not None else raw))
             R = ops.MultiHRecords(B, prep["ItTensor"].shape[2] // 8, prep["ItTensor"].shape[3] // 8, dev, max_h=11)
             R.rec[:, 2] = float(rank)
-            pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False)
+            pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False, pair_ids=seeds)
             return _download(R.rec, rec_h) if raw_h is not None else R.rec
         wl = ("BASELINE config %s as worded: batch of %d %dx%d pairs per GPU per step, each target warped by a seeded random "
               "homography; evaluation semantics (variant B, minSize %d, %d scales x2, coarseIter %d) + multi-homography loop "
@@ -372,7 +372,7 @@ def build_workload(args, dev, rank, world):
         return step, dict(workload=wl, nbIter=nbIter, nbScale=nbScale, matchability_init_std=MULTIH_MATCH_STD, col=col), dict(pipe=pipe, seeds=seeds)
     # config 5: KITTI-shaped stream, two-resolution driver
     pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", device=dev, draw=draw,
-                         seed=1000 + rank)
+                         seed=1000)
     raws = [pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True, amp=0.02)]) for s in seeds]
 
     raw_all = (torch.cat([r[0] for r in raws]), torch.cat([r[1] for r in raws]))
@@ -382,7 +382,8 @@ def build_workload(args, dev, rank, world):
     def step():
         R = ops.MultiHRecords(B, h_r // 8, w_r // 8, dev, max_h=11, hd2=h_d2 // 8, wd2=w_d2 // 8)
         R.rec[:, 2] = float(rank)
-        pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01, records=R, want_lists=False)
+        pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01, records=R, want_lists=False,
+                                   pair_ids=seeds)
         return R.rec
     wl = ("BASELINE config 5: %d evalKITTI-shaped %dx%d pairs per GPU per step (coarseSize 800 -> 2640x800 target, 3 scales "
           "x1.2, nA = 25 747, coarseIter 50 000; fineSize 650: two-resolution fine pass, cycle-checked matchability, "

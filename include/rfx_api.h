@@ -40,9 +40,9 @@ const char* rfx_version(void);
 
 /* ABI revision of this header: bumped whenever an entry point changes its signature or its operand layout (round 2:
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
- * round kernels, two-direction correlation, grouped launches).  A binding
+ * round kernels, two-direction correlation, grouped launches; round 4: rfx_draw_samples_i64 keyed by pair id).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 5
+#define RFX_ABI_VERSION 6
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -363,11 +363,14 @@ int rfx_gather_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32
  * ------------------------------------------------------------------------------------------ */
 /* The RANSAC index draw on the device (utils/outil.py:120 draws torch.randint(0, nbMatch, (nbIter, nbPoint),
  * device=match1.device): on a GPU run the reference draws on the GPU).  samples (batch,N,4) int64;
- * samples[b,h,p] = word p of Philox4x32-10(counter = (h, b, stream_id lo, stream_id hi), key = (seed lo, seed hi))
+ * samples[b,h,p] = word p of Philox4x32-10(counter = (h, id(b), stream_id lo, stream_id hi), key = (seed lo, seed hi))
  * modulo n[b] (torch's mapping of 32 random bits to a range below 2^32); n (batch) int32 ON THE DEVICE, n[b] <= 0 -> zeros.
+ * id(b) = pair_ids[b] (batch int32 ON THE DEVICE: the caller's ABSOLUTE pair ids) or b when pair_ids is NULL.  With the
+ * drivers' stream_id = (epoch << 32) | round, a pair's draws depend on (seed, its id, the round) only -- not on which other
+ * pairs share the batch, are still active, or on how the stream is sharded over ranks.
  * No host value of nbMatch is needed: the draw is enqueued behind the kernel that produces the counts. */
 int rfx_draw_samples_i64(const int32_t* n, int64_t* samples, int N, int batch, uint64_t seed, uint64_t stream_id,
-                         void* stream);
+                         const int32_t* pair_ids, void* stream);
 
 /* CoarseAlign.getCoarse of the evaluation variant up to the match lists (evaluation/evalHpatch/coarseAlignFeatMatch.py:
  * 156-170) for the active pairs of a batch: fg = ((mask + (1 - bg)) > 0.5), MtExtend = 1 - fg bilinear-resized

@@ -28,12 +28,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 }
 
 __global__ __launch_bounds__(256) void draw_samples_kernel(const int32_t* __restrict__ n, int64_t* __restrict__ samples, int N,
-                                                           uint32_t seed_lo, uint32_t seed_hi, uint32_t str_lo, uint32_t str_hi) {
+                                                           uint32_t seed_lo, uint32_t seed_hi, uint32_t str_lo, uint32_t str_hi,
+                                                           const int32_t* __restrict__ ids) {
     const int b = blockIdx.y;
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= N) return;
     const int nb = n[b];
-    uint32_t c[4] = {(uint32_t)h, (uint32_t)b, str_lo, str_hi};
+    uint32_t c[4] = {(uint32_t)h, (uint32_t)(ids ? ids[b] : b), str_lo, str_hi};
     philox4x32_10(c, seed_lo, seed_hi);
     int64_t* o = samples + ((size_t)b * N + h) * 4;
     // torch's random_from_to for a range below 2^32: (32 random bits) % range + base
@@ -218,18 +219,23 @@ __global__ __launch_bounds__(1024) void accept_store_kernel(const int32_t* __res
     __syncthreads();
     if (t == 0) {
         nbH[b] = slot + 1;
-        if (rec) { rec[(size_t)b * rec_stride] = (float)(slot + 1); rec[(size_t)b * rec_stride + 1] = 0.0f; }
+        // the record's nbH field never exceeds the slots it holds; a pair that accepted more (only the unbounded KITTI loop
+        // can) is flagged with status 3, and the device counter nbH[] keeps the true number
+        if (rec) {
+            rec[(size_t)b * rec_stride] = (float)(slot + 1 < max_h ? slot + 1 : max_h);
+            rec[(size_t)b * rec_stride + 1] = slot + 1 > max_h ? 3.0f : 0.0f;
+        }
     }
 }
 
 }  // namespace
 
 extern "C" int rfx_draw_samples_i64(const int32_t* n, int64_t* samples, int N, int batch, uint64_t seed, uint64_t stream_id,
-                                    void* stream) {
+                                    const int32_t* pair_ids, void* stream) {
     if (!n || !samples || N <= 0 || batch <= 0) return RFX_E_ARG;
     if (batch > 65535) return RFX_E_LIMIT;
     hipLaunchKernelGGL(draw_samples_kernel, dim3((N + 255) / 256, batch), dim3(256), 0, rfx_stream(stream), n, samples, N,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32));
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32), pair_ids);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

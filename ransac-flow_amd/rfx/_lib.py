@@ -61,7 +61,7 @@ SIGNATURES = {
     "rfx_ransac_h4_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4
                               + [c_int, c_void_p]),
     "rfx_gather_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_void_p]),
-    "rfx_draw_samples_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_void_p]),
+    "rfx_draw_samples_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "rfx_filter_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4
                                + [c_void_p] * 9),
     "rfx_multih_accept_ws_bytes": (c_size_t, [c_int]),
@@ -69,7 +69,7 @@ SIGNATURES = {
                               + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),
 }
 
-ABI_VERSION = 5     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
+ABI_VERSION = 6     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
 
 _lib = None
 

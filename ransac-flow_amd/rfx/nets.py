@@ -61,14 +61,17 @@ class ResNet50Trunk:
             with ops.launch_group(dev, side_streams):          # c1 and the projection shortcut both read x only: one group
                 os_ = [blk["c1"](x) for x in xs]
                 rs = [blk["ds"](x) for x in xs] if blk["ds"] is not None else xs
+            # outputs get NEW names inside a group and are rebound after it: the recorded launches read their inputs when the
+            # group ends, so every input tensor must stay referenced until then (launch_group's contract)
             if ops.bottleneck_tail_eligible(blk["c2"], blk["c3"]):
                 with ops.launch_group(dev, side_streams):
-                    xs = [ops.bottleneck_tail(o, blk["c2"], blk["c3"], residual=r) for o, r in zip(os_, rs)]
+                    ys = [ops.bottleneck_tail(o, blk["c2"], blk["c3"], residual=r) for o, r in zip(os_, rs)]
             else:
                 with ops.launch_group(dev, side_streams):
-                    os_ = [blk["c2"](o) for o in os_]
+                    ms = [blk["c2"](o) for o in os_]
                 with ops.launch_group(dev, side_streams):
-                    xs = [blk["c3"](o, residual=r) for o, r in zip(os_, rs)]
+                    ys = [blk["c3"](m, residual=r) for m, r in zip(ms, rs)]
+            xs = ys
         return xs
 
 

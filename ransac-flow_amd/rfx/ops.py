@@ -683,13 +683,18 @@ def ransac_h4_batched(match1, match2, n, samples, tol):
 
 # ------------------------------------------------------------------------------------------------ multi-homography rounds (multih.hip)
 
-def draw_samples(n, nb_iter, seed, stream_id):
+def draw_samples(n, nb_iter, seed, stream_id, pair_ids=None):
     """RANSAC index draw on the device (utils/outil.py:120 on a GPU run): n (B,) int32 device match counts ->
-    samples (B, nb_iter, 4) int64, Philox4x32-10 keyed by (seed, stream_id, pair, hypothesis) modulo n[b].  No host sync."""
+    samples (B, nb_iter, 4) int64, Philox4x32-10 keyed by (seed, stream_id, pair id, hypothesis) modulo n[b]; pair id =
+    pair_ids[b] ((B,) int32 device tensor: the caller's absolute ids) or b.  No host sync."""
     n = _dev(n, "n", torch.int32)
     B = n.shape[0]
+    ids = _dev(pair_ids, "pair_ids", torch.int32) if pair_ids is not None else None
+    if ids is not None and ids.numel() != B:
+        raise ValueError("pair_ids must hold one id per count")
     smp = torch.empty((B, int(nb_iter), 4), dtype=torch.int64, device=n.device)
-    _call("rfx_draw_samples_i64", n.device, _p(n), _p(smp), int(nb_iter), B, int(seed) & (2 ** 64 - 1), int(stream_id) & (2 ** 64 - 1))
+    _call("rfx_draw_samples_i64", _one_device(n, ids), _p(n), _p(smp), int(nb_iter), B, int(seed) & (2 ** 64 - 1),
+          int(stream_id) & (2 ** 64 - 1), _p(ids))
     return smp
 
 
@@ -718,7 +723,7 @@ def filter_matches(idx1, idx2, count, active, mask, bg, rt, ct, xa, ya, xb, yb, 
 class MultiHRecords:
     """The fixed-size per-pair result records of the multi-homography drivers (what
     evaluation/evalHpatch/evaluation.py:254-260 saves per pair), one float32 row per pair so that ONE all_gather moves them:
-    [0] nbH | [1] status (0 ok, 1 no homography) | H (max_h,9) | flowDown8 (max_h,2,h8,w8) | matchDown8 (max_h,2,h8,w8)
+    [0] nbH (<= max_h) | [1] status (0 ok, 1 no homography, 3 more homographies accepted than the record holds) | H (max_h,9) | flowDown8 (max_h,2,h8,w8) | matchDown8 (max_h,2,h8,w8)
     [| flowD2 (max_h,2,hd2,wd2): the half-resolution /8 flow of the KITTI driver].  Filled on the device by multih_accept."""
 
     def __init__(self, B, h8, w8, device, max_h=11, hd2=0, wd2=0):
@@ -746,9 +751,10 @@ def multih_accept(match, mask, bg, active, ransac_result, n_match, nbH, th, mode
                   match21Down8=None, flowD2=None, records=None):
     """Accept rule + mask update + record store of one round (rfx_multih_accept_f32) -> (accept (a,) int32, gain (a,) f32),
     both on the device; ``mask`` (B,h,w) and ``nbH`` (B,) int32 are updated in place."""
+    for t, name in ((mask, "mask"), (nbH, "nbH")):          # updated IN PLACE: a silent .contiguous() copy would lose the update
+        if isinstance(t, torch.Tensor) and not t.is_contiguous():
+            raise ValueError("%s must be contiguous (updated in place)" % name)
     match, mask = _dev(match, "match"), _dev(mask, "mask")
-    if not mask.is_contiguous():
-        raise ValueError("mask must be contiguous (updated in place)")
     bg = _dev(bg, "bg") if bg is not None else None
     act = _dev(active, "active", torch.int32) if active is not None else None
     res, n_match, nbH = _dev(ransac_result, "ransac result", torch.int32), _dev(n_match, "n", torch.int32), _dev(nbH, "nbH", torch.int32)

@@ -50,12 +50,12 @@ _CELL_COORDS = {}
 
 def cell_coords_cached(n_rows, n_cols, device):
     """cell_coords() memoised per (shape, device): the grids are constants of the map size (a dozen tiny ATen launches per
-    pyramid level and step otherwise)."""
+    pyramid level and step otherwise).  Entries are NEVER evicted: captured HIP graphs (_features_graphed,
+    prepare_and_features) bake these tensors' addresses into their kernels and replay against them; two float32 vectors of one
+    value per cell (38 KB for a 60x80 map) per distinct map shape is nothing against 288 GB."""
     key = (n_rows, n_cols, str(device))
     v = _CELL_COORDS.get(key)
     if v is None:
-        if len(_CELL_COORDS) > 256:
-            _CELL_COORDS.clear()
         v = _CELL_COORDS[key] = cell_coords(n_rows, n_cols, device)
     return v
 
@@ -103,12 +103,22 @@ class AlignPipeline:
     def _pair_draw(self, n, it):
         """Index draw of the per-pair drivers: the pipeline's draw mode for one pair with n matches."""
         if self.draw == "device":
-            return self._device_draw(torch.tensor([n], dtype=torch.int32, device=self.dev))[0]
+            ids, epoch = self._draw_epoch(None)
+            return self._device_draw(torch.tensor([n], dtype=torch.int32, device=self.dev), ids, epoch, 0)[0]
         return torch.randint(n, (it, 4))
 
-    def _device_draw(self, n_dev):
-        self._draw_calls += 1
-        return ops.draw_samples(n_dev, self.nbIter, self.seed, self._draw_calls)
+    def _draw_epoch(self, pair_ids):
+        """The key of a driver call's device draws besides (seed, round): ``pair_ids`` given (the caller's ABSOLUTE pair ids,
+        one per pair of the batch) -> (ids on the device, epoch 0): a pair's hypotheses depend on (seed, its id, the round) only --
+        not on the batch it rides in, on which other pairs are still active, or on how a stream is sharded over ranks.
+        ``None`` -> ids = positions in the batch and a per-pipeline call counter as the epoch (calls draw afresh)."""
+        if pair_ids is None:
+            self._draw_calls += 1
+            return None, self._draw_calls
+        return torch.as_tensor(pair_ids, dtype=torch.int32).to(self.dev), 0
+
+    def _device_draw(self, n_dev, ids=None, epoch=0, rnd=0):
+        return ops.draw_samples(n_dev, self.nbIter, self.seed, (int(epoch) << 32) | int(rnd), ids)
 
     # ---------------------------------------------------------------- host pre-processing
     def _resize(self, I, size):
@@ -397,7 +407,7 @@ class AlignPipeline:
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
-    def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None):
+    def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None, pair_ids=None):
         """Per pair: mutual NN -> matches -> RANSAC.  Index draw (utils/outil.py:120): ``samples`` = list of (nbIter,4) int64
         CPU tensors, or ``sample_fn(b, nMatch, nbIter)`` -> such a tensor; otherwise the pipeline's ``draw`` mode -- "device":
         Philox on the device from the device-side match counts, ONE host sync per batch (the result records); "host":
@@ -409,7 +419,8 @@ class AlignPipeline:
         # ONE batched mutual-NN launch chain for all pairs
         idx1, idx2, cnt = self._mutual_batched(feats, B, maskB)
         if samples is None and sample_fn is None and self.draw == "device":
-            smp = self._device_draw(cnt)
+            ids, epoch = self._draw_epoch(pair_ids)
+            smp = self._device_draw(cnt, ids, epoch, 0)
             counts, draws = None, smp
         else:
             counts = cnt.cpu().tolist()  # <- sync: the host-side index draw needs nbMatch
@@ -589,19 +600,24 @@ class AlignPipeline:
         out["mask"] = Mask
         return out
 
-    def _round_draws(self, active, n_dev, sample_fn):
+    def _round_draws(self, active, n_dev, sample_fn, A=None, ids=None, epoch=0, rnd=0):
         """Index draws of one lock-step round -> (a,nbIter,4) int64 device tensor.  Device mode: Philox from the device-side
-        counts, no sync.  Host mode / explicit sample_fn: one sync for the counts, CPU draws for the active pairs in
-        ascending order, one upload."""
+        counts keyed by (seed, epoch, round, pair id) -- the id of the k-th active pair is ids[active[k]] (the caller's absolute
+        ids) or its position active[k] in the batch -- no sync.  Host mode / explicit sample_fn: one sync for the counts, CPU
+        draws for the active pairs in ascending order, one upload."""
         if sample_fn is None and self.draw == "device":
-            return self._device_draw(n_dev)
+            if ids is not None:
+                key = ids if A is None else ids.index_select(0, A)
+            else:
+                key = A                                                   # None = the whole batch in order = positions 0..B-1
+            return self._device_draw(n_dev, key, epoch, rnd)
         n_host = n_dev.cpu().tolist()                                                   # sync: sizes of the index draws
         draw = sample_fn or (lambda b, n, it: torch.randint(n, (it, 4)))
         return torch.stack([draw(b, n, self.nbIter) if n >= 4 else torch.zeros((self.nbIter, 4), dtype=torch.int64)
                             for b, n in zip(active, n_host)]).to(self.dev, non_blocking=True)
 
     def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None, records=None,
-                        want_lists=True, trace=None):
+                        want_lists=True, trace=None, pair_ids=None):
         """multi_h() for every pair of the batch in lock-step: round k computes the k-th homography of all pairs that are
         still active.  A round is device work end to end -- rfx_filter_matches_f32 (mask -> keep map -> ordered compaction of
         the cached matches), the index draw (device mode), rfx_ransac_h4_batched, the warp, PredFlowMask over the active
@@ -609,6 +625,8 @@ class AlignPipeline:
         accept flags, from which the host builds the next round's active list.  Semantics per pair =
         evaluation/evalHpatch/evaluation.py:184-243.
         ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; costs a second sync per round).
+        ``pair_ids``: absolute ids of the batch's pairs for the device draw (see _draw_epoch): with them a pair's homographies
+        are the same alone, in any batch and under any sharding.
         ``records``: an ops.MultiHRecords to fill (the fixed-size rows one all_gather moves); ``want_lists=False`` skips the
         per-pair Python lists (throughput drivers that only ship the records).  ``trace``: a list that receives one dict per
         round with the round's state (mask before the round, counts, H, PredFlowMask outputs, accept flags) -- the parity
@@ -628,12 +646,15 @@ class AlignPipeline:
         nb = [0] * B
         eye = torch.eye(3, device=dev)
         active = list(range(B))
+        ids, epoch = self._draw_epoch(pair_ids)
+        rnd = 0
         while active:
             full = len(active) == B
             A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
             M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
                                                feats["Wt"])
-            smp = self._round_draws(active, n_dev, sample_fn)
+            smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
+            rnd += 1
             bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flowCoarse = ops.warp_grid(Hs, h, w)
@@ -772,7 +793,7 @@ class AlignPipeline:
         return flow_d2, pm, match
 
     def multi_h_kitti_batched(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, sample_fn=None,
-                              remove_small_cc=None, records=None, want_lists=True, trace=None):
+                              remove_small_cc=None, records=None, want_lists=True, trace=None, pair_ids=None):
         """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
         computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
         the match filtering (rfx_filter_matches_f32), the index draw (device mode), RANSAC (rfx_ransac_h4_batched), the two
@@ -802,13 +823,16 @@ class AlignPipeline:
         nb = [0] * B
         eye = torch.eye(3, device=dev)
         active = list(range(B))
+        ids, epoch = self._draw_epoch(pair_ids)
+        rnd = 0
         while active:
             full = len(active) == B
             A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
             sel = (lambda t: t) if full else (lambda t: t.index_select(0, A))
             M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
                                                feats["Wt"])
-            smp = self._round_draws(active, n_dev, sample_fn)
+            smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
+            rnd += 1
             bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flow_d2, pm, match = self.kitti_fine_round(Hs, sel(tensor_s), sel(tensor_d2), sel(tensor_resize), (h_org, w_org),
@@ -833,6 +857,10 @@ class AlignPipeline:
                     outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
                     outs[b]["matchDown8"].append(md2[k:k + 1])
                 nb[b] += 1
+                if records is not None and nb[b] >= records.max_h:
+                    # the reference's ``while True`` has no round limit; a fixed-size record has: the pair stops at the
+                    # record's capacity (one more accepted homography would set the record's status to 3 = overflow)
+                    continue
                 nxt.append(b)
             active = nxt
         for b in range(B):
@@ -842,8 +870,8 @@ class AlignPipeline:
         return outs
 
     # ---------------------------------------------------------------- whole path
-    def align_prepared(self, prep, fine=True, samples=None, feats=None):
-        res = self.coarse(prep, feats=feats, samples=samples)
+    def align_prepared(self, prep, fine=True, samples=None, feats=None, pair_ids=None):
+        res = self.coarse(prep, feats=feats, samples=samples, pair_ids=pair_ids)
         if fine:
             eye = torch.eye(3, device=self.dev)
             Hs = torch.stack([r["H"] if r["H"] is not None else eye for r in res])

@@ -1,0 +1,29 @@
+#!/bin/bash
+# ONE parametrised GPU-box script (replaces the per-experiment gpu_r0N_*.sh wrappers of earlier rounds).
+#   gpurun --timeout 1800 -- 'bash scripts/gpu.sh <step> [<step> ...]'     outputs under gpurun_out/$TAG (default r04)
+# steps: ref tests smoke bench bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps ubench_corr ubench_conv
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+TAG=${TAG:-r04}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+for step in "$@"; do
+  echo "=== $step ($(date +%T))"
+  case $step in
+    ref)        ls oracle/_ref oracle/_ref/utils oracle/_ref/_extract 2>&1 | head -20; python -c "import sys; sys.path.insert(0,'oracle'); import ref_loader; print(ref_loader.REF_ROOT, ref_loader.kind() if ref_loader.available() else 'ABSENT')" ;;
+    tests)      timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -${TAIL:-25} ;;
+    smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ;;
+    bench)      RFX_PARITY_RECORDS=$OUT/bench_parity_records timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err | cut -c1-300
+                python scripts/bench_digest.py $OUT/bench.log ;;
+    bench_nocpu) timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nocpu.log 2> $OUT/bench_nocpu.err; python scripts/bench_digest.py $OUT/bench_nocpu.log ;;
+    feature_error_qs) timeout 1500 python scripts/feature_error.py --config qs --pairs ${FE_PAIRS:-12} --threads 16 --out $OUT/feature_error_qs.json > $OUT/feature_error_qs.log 2>&1; tail -40 $OUT/feature_error_qs.log | grep -A3 "differing_lists\|pairs\"" | head -60 ;;
+    feature_error_ev) timeout 1500 python scripts/feature_error.py --config ev --pairs ${FE_PAIRS:-6} --threads 16 --out $OUT/feature_error_ev.json > $OUT/feature_error_ev.log 2>&1; tail -5 $OUT/feature_error_ev.log ;;
+    c2)         timeout 300 python bench.py --config 2 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_c2.log 2> $OUT/bench_c2.err; python scripts/bench_digest.py $OUT/bench_c2.log ;;
+    c4)         timeout 600 python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c4.log 2> $OUT/bench_c4.err; python scripts/bench_digest.py $OUT/bench_c4.log ;;
+    c5)         timeout 600 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c5.log 2> $OUT/bench_c5.err; python scripts/bench_digest.py $OUT/bench_c5.log ;;
+    profile)    for c in ${CONFIGS:-3}; do rm -rf $OUT/prof_$c; timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$c -o k -- python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_$c.log 2>&1; f=$(find $OUT/prof_$c -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/rocprofv3_kernel_stats_config$c.csv; head -12 "$f" | cut -c1-150; find $OUT/prof_$c -name "*.csv" ! -name "*stats*" -delete; done ;;
+    pmc)        for c in ${CONFIGS:-3}; do for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do n=$(echo $grp | tr ' ' '_' | cut -c1-24); rm -rf $OUT/pmc_${c}_$n; timeout 900 rocprofv3 --pmc $grp --kernel-trace -d $OUT/pmc_${c}_$n -o p -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_${c}_$n.log 2>&1; done; python scripts/make_profile_summary.py --pmc-dirs $OUT/pmc_${c}_* --out $OUT/pmc_summary_config$c.json 2>&1 | tail -3; find $OUT -path "*pmc_${c}_*" -name "*.csv" -size +20M -delete; done ;;
+    sweeps)     timeout 2400 python tests/run_parity_sweep.py 2>&1 | tail -5 ;;
+    ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
+    ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;
+    *)          echo "unknown step $step" ;;
+  esac
+done
+echo "=== done ($(date +%T))"

@@ -25,13 +25,14 @@ def philox4x32_10(ctr, key):
     return c.astype(np.uint32)
 
 
-def draw_samples(n, nb_iter, seed, stream_id):
-    """rfx_draw_samples_i64: samples[b,h,p] = Philox(ctr = (h, b, stream lo, stream hi), key = (seed lo, seed hi))[p] % n[b]."""
+def draw_samples(n, nb_iter, seed, stream_id, pair_ids=None):
+    """rfx_draw_samples_i64: samples[b,h,p] = Philox(ctr = (h, id(b), stream lo, stream hi), key = (seed lo, seed hi))[p] % n[b],
+    id(b) = pair_ids[b] or b."""
     n = np.asarray(n, dtype=np.int64)
     B = len(n)
     ctr = np.zeros((B, nb_iter, 4), dtype=np.uint64)
     ctr[..., 0] = np.arange(nb_iter, dtype=np.uint64)[None, :]
-    ctr[..., 1] = np.arange(B, dtype=np.uint64)[:, None]
+    ctr[..., 1] = (np.arange(B, dtype=np.uint64) if pair_ids is None else np.asarray(pair_ids, dtype=np.uint64))[:, None]
     ctr[..., 2] = int(stream_id) & 0xFFFFFFFF
     ctr[..., 3] = (int(stream_id) >> 32) & 0xFFFFFFFF
     r = philox4x32_10(ctr, (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)).astype(np.int64)

@@ -245,13 +245,13 @@ def test_lock_step_driver_device_draw_records_and_determinism(dev):
             assert torch.equal(RH[b, k], o["H"][k]) and torch.equal(Rf[b, k], o["flowDown8"][k][0])
             assert torch.equal(Rm[b, k], o["matchDown8"][k][0])
         assert float(RH[b, o["nbH"]:].abs().max()) == 0
-    # first round by hand: the device draw of call 1 is Philox(seed 5, stream 1); RANSAC on the device's matches with that draw
-    # must be the oracle's
+    # first round by hand: the device draw of driver call 1, round 0 is Philox(seed 5, stream (1 << 32) | 0, ids = batch
+    # positions); RANSAC on the device's matches with that draw must be the oracle's
     idx1, idx2, cnt = pipe._mutual_batched(feats, 4)
     Mask = torch.zeros((4, 240, 320), device=dev)
     M1, M2, n = ops.filter_matches(idx1, idx2, cnt, None, Mask, None, feats["rt"], feats["ct"], feats["HA"], feats["WA"], feats["Ht"], feats["Wt"])
     assert torch.equal(n, cnt)
-    smp = philox_ref.draw_samples(n.cpu().numpy(), 300, 5, 1)
+    smp = philox_ref.draw_samples(n.cpu().numpy(), 300, 5, 1 << 32)
     for b in range(4):
         nb_ = int(n[b])
         Hb, c, inl, _ = restate.ransac(M1[b, :nb_].cpu(), M2[b, :nb_].cpu(), 0.05, torch.from_numpy(smp[b]))
@@ -333,3 +333,54 @@ def test_grouped_launches_are_bit_identical_to_single_launches(dev):
             blk["c1"](ys[0])
             raise ValueError("boom")
     assert torch.equal(blk["c1"](ys[0]), single[0])
+
+
+def test_device_draw_is_keyed_by_pair_id_and_round_not_by_batch_composition(dev):
+    """with absolute ``pair_ids`` a pair's hypotheses -- hence its homographies -- are a function of (seed, id,
+    round): the same pair gives bit-identical records alone, inside a batch of four, and in a batch where it sits at another
+    position next to pairs that stop at other rounds (which is what sharding a stream over N ranks changes)."""
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=3.0))
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev, seed=5)
+    seeds = [7, 8, 9, 10]
+    pairs = {s: synth.make_pair(240, 320, seed=s, homography=True) for s in seeds}
+
+    def run(order):
+        prep = pipe.prepare_device(*pipe.upload_raw([pairs[s] for s in order]))
+        R = ops.MultiHRecords(len(order), 30, 40, dev)
+        pipe.multi_h_batched(prep, maxCoarse=3, maskRegionTh=0.01, records=R, want_lists=False, pair_ids=order)
+        return {s: R.rec[k].clone() for k, s in enumerate(order)}
+    full = run(seeds)
+    assert len({int(r[0]) for r in full.values()}) >= 2          # pairs stop at different rounds: the active list shrinks unevenly
+    alone = run([9])
+    shuffled = run([10, 9, 7])
+    assert torch.equal(full[9], alone[9]) and torch.equal(full[9], shuffled[9])
+    assert torch.equal(full[10], shuffled[10]) and torch.equal(full[7], shuffled[7])
+    # the draw itself: ids enter the Philox counter where the batch position used to
+    n = torch.tensor([900, 900], dtype=torch.int32, device=dev)
+    a = ops.draw_samples(n, 64, 3, 2, torch.tensor([41, 5], dtype=torch.int32, device=dev)).cpu().numpy()
+    assert np.array_equal(a, philox_ref.draw_samples([900, 900], 64, 3, 2, pair_ids=[41, 5]))
+    assert np.array_equal(a[1], ops.draw_samples(n[:1], 64, 3, 2, torch.tensor([5], dtype=torch.int32, device=dev)).cpu().numpy()[0])
+
+
+def test_record_overflow_is_flagged_not_silent(dev):
+    """a pair that accepts more homographies than its record has slots gets status 3 and nbH clamped to max_h (the
+    device counter keeps the true number); contiguity of the in-place operands is checked before any copy."""
+    B, h, w, h8, w8 = 1, 16, 16, 2, 2
+    R = ops.MultiHRecords(B, h8, w8, dev, max_h=2)
+    mask = torch.zeros((B, h, w), device=dev)
+    nbH = torch.zeros(B, dtype=torch.int32, device=dev)
+    res = torch.zeros((1, 4), dtype=torch.int32, device=dev)
+    n = torch.tensor([10], dtype=torch.int32, device=dev)
+    for k in range(3):
+        match = torch.zeros((1, h, w), device=dev)
+        match[0, k * 4:(k + 1) * 4] = 1.0                              # every round explains a new band: always accepted
+        acc, _ = ops.multih_accept(match, mask, None, None, res, n, nbH, 0.01, 0, bestH=torch.eye(3, device=dev)[None] * (k + 1),
+                                   flowDown8=torch.full((1, 2, h8, w8), float(k), device=dev), match12Down8=torch.zeros((1, 1, h8, w8), device=dev),
+                                   match21Down8=torch.zeros((1, 1, h8, w8), device=dev), records=R)
+        assert int(acc[0]) == 1
+        nbv, status, RH, _, _, _ = R.views()
+        assert int(nbH[0]) == k + 1 and int(nbv[0]) == min(k + 1, 2) and float(status[0]) == (3.0 if k + 1 > 2 else 0.0)
+    assert float(RH[0, 1, 0, 0]) == 2.0                                  # the slots hold homographies 1 and 2; the third was not stored
+    with pytest.raises(ValueError):
+        ops.multih_accept(match, torch.zeros((B, h, 2 * w), device=dev)[:, :, ::2], None, None, res, n, nbH, 0.01, 0)
