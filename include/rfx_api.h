@@ -347,6 +347,27 @@ int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_
                           int N, float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, int batch,
                           void* stream);
 
+/* Rank-deficient 4-point samples (utils/outil.py:84: ``np.linalg.svd(A)`` on an 8x9 system of rank 7).  Three matched points
+ * collinear in BOTH images -- common on the feature-cell lattices -- leave a two-dimensional null space; which unit vector of
+ * it LAPACK's Vh[8] is depends on rounding inside the host BLAS (it differs between LAPACK builds), so no device restatement
+ * can be bit-exact there.  The DLT kernel therefore FLAGS such hypotheses (sigma_8 < 1e-8 * max|bidiagonal|, one Sturm count on
+ * the bidiagonal dgebd2 leaves; csrc/dlt.h) and the search can be run in two stages around a host re-solve:
+ *   rfx_ransac_h4_batched_stage(..., stages = 1)   pack + DLT: hypotheses and flags into ws (bestH / inlier / result untouched)
+ *   rfx_ransac_degenerate_list(ws, ...)            idx (batch,kcap) int32 = flagged hypotheses that survived the duplicate
+ *                                                  filter, ascending; count (batch) int32 (may exceed kcap: list truncated)
+ *   [host: numpy's LAPACK on exactly those systems -- what the reference itself computes on this host]
+ *   rfx_ransac_patch_h(ws, ..., idx, count, Hpatch (batch,kcap,9))   re-solved homographies in, det gate re-evaluated
+ *   rfx_ransac_h4_batched_stage(..., stages = 2)   count + select on the patched hypotheses
+ * stages = 3 is rfx_ransac_h4_batched.  cap / N / batch / ws as for rfx_ransac_h4_batched (same workspace across the calls). */
+int rfx_ransac_h4_batched_stage(const float* match1, const float* match2, const int32_t* n, int cap, const int64_t* samples,
+                                int N, float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, int batch,
+                                int stages, void* stream);
+int rfx_ransac_degenerate_list(const void* ws, int cap, int N, int batch, int32_t* idx, int32_t* count, int kcap, void* stream);
+int rfx_ransac_patch_h(void* ws, int cap, int N, int batch, const int32_t* idx, const int32_t* count, const float* Hpatch,
+                       int kcap, void* stream);
+/* rfx_dlt4_homography + the per-system flag byte (bit0 set; bit1: det(H) > 1e-6; bit2 (4): rank deficient). */
+int rfx_dlt4_homography_flags(const float* X, const float* Y, int N, float* Hout, uint8_t* flags, void* stream);
+
 /* Match lists of a batch (quick_start/coarseAlignFeatMatch.py:150-155): match1[b,i] = (xa[idx1[b,i]], ya[idx1[b,i]], 1),
  * match2[b,i] = (xb[idx2[b,i]], yb[idx2[b,i]], 1) for i < n[b], zeros after.  idx1/idx2 (batch,cap) int64 as written by
  * rfx_mutual_nn_batched_f32; xa/ya = source cell coordinates (getWHTensor "H"/"W" of all scales, utils/outil.py:21-24),

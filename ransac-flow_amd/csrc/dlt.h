@@ -59,8 +59,35 @@ RFX_HD double rfx_dlapy2(double x, double y) {
     return w * sqrt(1.0 + q * q);
 }
 
-// src: 4 source points (u', v'), tgt: 4 target points (u, v), float32 as in the reference; h: 9 doubles.
-RFX_HD void rfx_dlt4_nullvec(const float src[4][2], const float tgt[4][2], double h[9]) {
+// Is the 8x9 system numerically rank deficient?  bd[0..14] = the lower bidiagonal dgebd2 leaves (d1, e1, d2, e2, ..., d8:
+// exactly the off-diagonals of its Golub-Kahan form, the 16x16 symmetric tridiagonal with zero diagonal whose eigenvalues are
+// +-sigma_i).  One Sturm count at lambda = rel * max|bd|: the matrix has 8 eigenvalues -sigma_i < lambda, so a count above 8
+// means sigma_8 < lambda.  Backward stable; 15 divisions.  Why it matters: with sigma_8 / sigma_1 ~ 1e-17 (three matched
+// points collinear in BOTH images: common on the cell lattices) the null space is two-dimensional, a reflector is built from
+// a vector that is pure rounding noise, and which unit vector of the null space LAPACK returns depends on the summation order
+// inside the host BLAS -- it differs between LAPACK builds.  Those hypotheses are flagged so that a caller who needs the
+// host's answer bit for bit can re-solve exactly them with the host's LAPACK (rfx_ransac_degenerate_list).
+RFX_HD bool rfx_bidiag_rank_deficient(const double bd[15], double rel) {
+    double mx = 0.0;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) mx = fabs(bd[j]) > mx ? fabs(bd[j]) : mx;
+    if (mx == 0.0) return true;
+    const double lam = rel * mx;
+    double q = -lam;
+    int neg = 1;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        if (q == 0.0) q = -1e-300;
+        q = -lam - bd[j] * bd[j] / q;
+        neg += q < 0.0 ? 1 : 0;
+    }
+    return neg > 8;
+}
+#define RFX_DLT_RANK_REL 1e-8    /* sigma_8 < 1e-8 * max|bidiagonal|: the null vector is uncertain beyond ~1e-8 */
+
+// src: 4 source points (u', v'), tgt: 4 target points (u, v), float32 as in the reference; h: 9 doubles; bd: NULL or the 15
+// bidiagonal entries (d1, e1, ..., d8) for rfx_bidiag_rank_deficient.
+RFX_HD void rfx_dlt4_nullvec(const float src[4][2], const float tgt[4][2], double h[9], double* bd = nullptr) {
     double A[8][9];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -135,6 +162,13 @@ RFX_HD void rfx_dlt4_nullvec(const float src[4][2], const float tgt[4][2], doubl
                     for (int r = i + 2; r < 8; ++r) A[r][j] -= tw * A[r][i];
                 }
             }
+        }
+    }
+    if (bd) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bd[2 * i] = A[i][i];
+            if (i < 7) bd[2 * i + 1] = A[i + 1][i];
         }
     }
     // last row of Vh = G_1 ... G_8 e_9: apply G_8 first

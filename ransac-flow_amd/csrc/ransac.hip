@@ -80,14 +80,15 @@ __global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict_
             tgt[p][0] = m2[((size_t)h * 4 + p) * 3 + 0]; tgt[p][1] = m2[((size_t)h * 4 + p) * 3 + 1];
         }
     }
-    uint8_t fl = 0;  // bit0: evaluated (survives the duplicate filter), bit1: det gate passed
+    uint8_t fl = 0;  // bit0: evaluated (survives the duplicate filter), bit1: det gate passed, bit2: rank-deficient system
     if (!(filter_dup && dup) && !bad) {
-        double hv[9];
-        rfx_dlt4_nullvec(src, tgt, hv);
+        double hv[9], bd[15];
+        rfx_dlt4_nullvec(src, tgt, hv, bd);
         float hf[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) { hf[j] = (float)hv[j]; Hout[(size_t)h * 9 + j] = hf[j]; }
         fl = 1 | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);   // torch.det's own LU order (dlt.h)
+        fl |= rfx_bidiag_rank_deficient(bd, RFX_DLT_RANK_REL) ? 4 : 0;
     } else {
 #pragma unroll
         for (int j = 0; j < 9; ++j) Hout[(size_t)h * 9 + j] = 0.0f;
@@ -243,6 +244,48 @@ __global__ __launch_bounds__(1024) void ransac_select_kernel(const float4* __res
     for (int m = t; m < nout; m += 1024) inlier[m] = (m < n && is_inlier(P[m], Z[m], H, tol)) ? 1 : 0;
 }
 
+// ---- rank-deficient hypotheses: list them (ascending, per pair), take re-solved homographies back -------------------------
+__global__ __launch_bounds__(1024) void ransac_degen_list_kernel(const uint8_t* __restrict__ flags, int N, int32_t* __restrict__ idx,
+                                                                 int32_t* __restrict__ cnt, int kcap, size_t wsStride) {
+    const int b = blockIdx.x;
+    flags += b * wsStride; idx += (size_t)b * kcap;
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int s = 0; s < N; s += 1024) {
+        const int h = s + t;
+        const bool hit = h < N && (flags[h] & 5) == 5;       // evaluated AND rank deficient
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) woff += c; tot += c; }
+        const int pos = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < kcap) idx[pos] = h;
+        __syncthreads();
+        if (t == 0) base += tot;
+        __syncthreads();
+    }
+    if (t == 0) cnt[b] = base;
+}
+
+__global__ __launch_bounds__(256) void ransac_patch_kernel(float* __restrict__ Hs, uint8_t* __restrict__ flags,
+                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                           const float* __restrict__ Hp, int kcap, int N, size_t wsStride) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= kcap || k >= cnt[b]) return;
+    const int h = idx[(size_t)b * kcap + k];
+    if (h < 0 || h >= N) return;
+    Hs = reinterpret_cast<float*>(reinterpret_cast<char*>(Hs) + b * wsStride);
+    flags += b * wsStride;
+    float hf[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { hf[j] = Hp[((size_t)b * kcap + k) * 9 + j]; Hs[(size_t)h * 9 + j] = hf[j]; }
+    flags[h] = (flags[h] & ~2) | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);
+}
+
 struct RansacWs {
     size_t P, Z, H, flags, counts, total;
 };
@@ -283,23 +326,28 @@ extern "C" size_t rfx_ransac_ws_bytes(int n, int N) {
     return ws_layout(N, n).total;
 }
 
+// stages: 1 = pack + DLT (hypotheses and their flags into the workspace), 2 = count; 3 = both
 static int ransac_common(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
                          int filter_dup, const RansacWs& L, char* w, float* Hs, int64_t* counts64, hipStream_t st,
-                         const int32_t* narr = nullptr, int cap = 0, int batch = 1) {
+                         const int32_t* narr = nullptr, int cap = 0, int batch = 1, int stages = 3) {
     float4* P = reinterpret_cast<float4*>(w + L.P);
     float* Z = reinterpret_cast<float*>(w + L.Z);
     uint8_t* flags = reinterpret_cast<uint8_t*>(w + L.flags);
     int* counts = reinterpret_cast<int*>(w + L.counts);
     const int nmax = narr ? cap : n;
-    hipLaunchKernelGGL(ransac_pack_kernel, dim3((nmax + 255) / 256, batch), dim3(256), 0, st, match1, match2, n, P, Z, narr,
-                       cap, L.total);
-    RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
-                       filter_dup, Hs, flags, narr, cap, L.total);
-    RFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ransac_count_kernel, dim3((N + 3) / 4, batch), dim3(256), 0, st, P, Z, n, Hs, flags, N, tol, counts,
-                       counts64, narr, L.total);
-    RFX_LAUNCH_CHECK();
+    if (stages & 1) {
+        hipLaunchKernelGGL(ransac_pack_kernel, dim3((nmax + 255) / 256, batch), dim3(256), 0, st, match1, match2, n, P, Z, narr,
+                           cap, L.total);
+        RFX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
+                           filter_dup, Hs, flags, narr, cap, L.total);
+        RFX_LAUNCH_CHECK();
+    }
+    if (stages & 2) {
+        hipLaunchKernelGGL(ransac_count_kernel, dim3((N + 3) / 4, batch), dim3(256), 0, st, P, Z, n, Hs, flags, N, tol, counts,
+                           counts64, narr, L.total);
+        RFX_LAUNCH_CHECK();
+    }
     return RFX_OK;
 }
 
@@ -336,21 +384,69 @@ extern "C" size_t rfx_ransac_batched_ws_bytes(int cap, int N, int batch) {
     return ws_layout(N, cap).total * (size_t)batch;
 }
 
-extern "C" int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_t* n, int cap,
-                                     const int64_t* samples, int N, float tol, float* bestH, uint8_t* inlier,
-                                     int32_t* result, void* ws, int batch, void* stream) {
-    if (!match1 || !match2 || !n || !samples || !bestH || !inlier || !result || !ws || cap <= 0 || N <= 0 || batch <= 0)
+static int ransac_batched_stages(const float* match1, const float* match2, const int32_t* n, int cap, const int64_t* samples,
+                                 int N, float tol, float* bestH, uint8_t* inlier, int32_t* result, void* ws, int batch,
+                                 int stages, void* stream) {
+    if (!match1 || !match2 || !n || !samples || !bestH || !inlier || !result || !ws || cap <= 0 || N <= 0 || batch <= 0 ||
+        stages < 1 || stages > 3)
         return RFX_E_ARG;
     if ((N + CHUNK - 1) / CHUNK > MAX_CHUNKS || batch > 65535) return RFX_E_LIMIT;
     const RansacWs L = ws_layout(N, cap);
     char* w = static_cast<char*>(ws);
     float* Hs = reinterpret_cast<float*>(w + L.H);
     hipStream_t st = rfx_stream(stream);
-    int rc = ransac_common(match1, match2, 0, samples, N, tol, 1, L, w, Hs, nullptr, st, n, cap, batch);
+    int rc = ransac_common(match1, match2, 0, samples, N, tol, 1, L, w, Hs, nullptr, st, n, cap, batch, stages);
     if (rc != RFX_OK) return rc;
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
-                       reinterpret_cast<const float*>(w + L.Z), 0, Hs, reinterpret_cast<const uint8_t*>(w + L.flags),
-                       reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result, n, cap, L.total);
+    if (stages & 2) {
+        hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
+                           reinterpret_cast<const float*>(w + L.Z), 0, Hs, reinterpret_cast<const uint8_t*>(w + L.flags),
+                           reinterpret_cast<const int*>(w + L.counts), N, tol, bestH, inlier, result, n, cap, L.total);
+        RFX_LAUNCH_CHECK();
+    }
+    return RFX_OK;
+}
+
+extern "C" int rfx_ransac_h4_batched(const float* match1, const float* match2, const int32_t* n, int cap,
+                                     const int64_t* samples, int N, float tol, float* bestH, uint8_t* inlier,
+                                     int32_t* result, void* ws, int batch, void* stream) {
+    return ransac_batched_stages(match1, match2, n, cap, samples, N, tol, bestH, inlier, result, ws, batch, 3, stream);
+}
+
+extern "C" int rfx_ransac_h4_batched_stage(const float* match1, const float* match2, const int32_t* n, int cap,
+                                           const int64_t* samples, int N, float tol, float* bestH, uint8_t* inlier,
+                                           int32_t* result, void* ws, int batch, int stages, void* stream) {
+    return ransac_batched_stages(match1, match2, n, cap, samples, N, tol, bestH, inlier, result, ws, batch, stages, stream);
+}
+
+extern "C" int rfx_ransac_degenerate_list(const void* ws, int cap, int N, int batch, int32_t* idx, int32_t* count, int kcap,
+                                          void* stream) {
+    if (!ws || !idx || !count || cap <= 0 || N <= 0 || batch <= 0 || kcap <= 0) return RFX_E_ARG;
+    if (batch > 65535) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, cap);
+    hipLaunchKernelGGL(ransac_degen_list_kernel, dim3(batch), dim3(1024), 0, rfx_stream(stream),
+                       reinterpret_cast<const uint8_t*>(static_cast<const char*>(ws) + L.flags), N, idx, count, kcap, L.total);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_ransac_patch_h(void* ws, int cap, int N, int batch, const int32_t* idx, const int32_t* count,
+                                  const float* Hpatch, int kcap, void* stream) {
+    if (!ws || !idx || !count || !Hpatch || cap <= 0 || N <= 0 || batch <= 0 || kcap <= 0) return RFX_E_ARG;
+    if (batch > 65535) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, cap);
+    char* w = static_cast<char*>(ws);
+    hipLaunchKernelGGL(ransac_patch_kernel, dim3((kcap + 255) / 256, batch), dim3(256), 0, rfx_stream(stream),
+                       reinterpret_cast<float*>(w + L.H), reinterpret_cast<uint8_t*>(w + L.flags), idx, count, Hpatch, kcap, N,
+                       L.total);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+// outil.Homography with the rank flag per system (degenerate (N) uint8: 1 = rank deficient, see dlt.h)
+extern "C" int rfx_dlt4_homography_flags(const float* X, const float* Y, int N, float* Hout, uint8_t* degenerate, void* stream) {
+    if (!X || !Y || !Hout || !degenerate || N <= 0) return RFX_E_ARG;
+    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
+                       (const int64_t*)nullptr, N, 0, Hout, degenerate, (const int32_t*)nullptr, 0, (size_t)0);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

@@ -10,7 +10,15 @@ import numpy as np
 import PIL.Image as Image
 import torch
 
+import os
+
 from rfx import ops
+
+# Rank-deficient 4-point samples (three matched points collinear in both images): the reference's value there is whatever the
+# HOST's LAPACK returns (utils/outil.py:84), so the drop-in re-solves exactly those hypotheses with numpy's LAPACK
+# (ops.lapack_dlt) -- every function below is host-synchronous in the reference anyway.  RFX_DEGENERATE=device keeps the
+# device's own null vector (no extra sync).
+_DEGENERATE = os.environ.get("RFX_DEGENERATE", "lapack")
 
 
 def resizeImg(I, strideNet, minSize=400, mode=Image.LANCZOS):
@@ -46,7 +54,7 @@ def mutualMatching(featA, featB):
 def Homography(X, Y):
     """utils/outil.py:68-87: X, Y (N,4,3) source / target samples -> H21 (N,3,3) float32 on X's device.
     Float64 Householder DLT with LAPACK dgesdd's sign, entirely on the device (no CPU SVD round trip)."""
-    return ops.dlt4_homography(X, Y)
+    return ops.dlt4_homography(X, Y, degenerate=_DEGENERATE)
 
 
 def Prediction(X, Y, H21):
@@ -59,7 +67,7 @@ def Prediction(X, Y, H21):
 def ScoreRANSAC(match1, match2, tolerance, samples, Transform):
     """utils/outil.py:102-113 -> (H21 (N,3,3), inlier counts (N,) int64 gated by det(H21) > 1e-6)."""
     _require_homography(Transform)
-    return ops.score_hypotheses(match1, match2, samples, tolerance)
+    return ops.score_hypotheses(match1, match2, samples, tolerance, degenerate=_DEGENERATE)
 
 
 def RANSAC(nbIter, match1, match2, tolerance, nbPoint, Transform, samples=None):
@@ -77,7 +85,7 @@ def RANSAC(nbIter, match1, match2, tolerance, nbPoint, Transform, samples=None):
     nbMatch = len(match1)
     if samples is None:
         samples = torch.randint(nbMatch, (nbIter, nbPoint))
-    bestH, inl, res = ops.ransac_h4(match1, match2, samples.to(match1.device), tolerance)
+    bestH, inl, res = ops.ransac_h4(match1, match2, samples.to(match1.device), tolerance, degenerate=_DEGENERATE)
     status, cnt, _, _ = res.cpu().tolist()
     if status == 1:
         return None, 0, [], []

@@ -58,6 +58,11 @@ SIGNATURES = {
     "rfx_ransac_ws_bytes": (c_size_t, [c_int, c_int]),
     "rfx_ransac_h4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 5),
     "rfx_ransac_batched_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rfx_ransac_h4_batched_stage": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4
+                                    + [c_int, c_int, c_void_p]),
+    "rfx_ransac_degenerate_list": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "rfx_ransac_patch_h": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rfx_dlt4_homography_flags": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_ransac_h4_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4
                               + [c_int, c_void_p]),
     "rfx_gather_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int, c_void_p]),

@@ -602,11 +602,38 @@ def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
     return idx1[:n], idx2[:n]
 
 
-def dlt4_homography(X, Y):
+def lapack_dlt(X, Y):
+    """The reference's own solve (utils/outil.py:68-87: float32 products stored into a float64 8x9 system, numpy's LAPACK SVD,
+    Vh[8], float32) for the FEW hypotheses the device flags as rank deficient.  For those systems the null space is two-
+    dimensional and "the reference's value" is by definition whatever LAPACK returns on THIS host (it differs between LAPACK
+    builds): no device restatement can pin it, the host's own LAPACK does.  X, Y: (k,4,3) float32 numpy -> (k,3,3) float32."""
+    import numpy as np
+    k = X.shape[0]
+    A = np.zeros((k, 8, 9))
+    z, o = np.zeros(k), np.ones(k)
+    for i in range(4):
+        u, v, u_, v_ = Y[:, i, 0], Y[:, i, 1], X[:, i, 0], X[:, i, 1]
+        A[:, 2 * i] = np.stack([z, z, z, -u, -v, -o, v_ * u, v_ * v, v_], axis=1)
+        A[:, 2 * i + 1] = np.stack([u, v, o, z, z, z, -u_ * u, -u_ * v, -u_], axis=1)
+    return np.linalg.svd(A)[2][:, 8].reshape(k, 3, 3).astype(np.float32)
+
+
+def dlt4_homography(X, Y, degenerate="device", info=None):
+    """outil.Homography.  ``degenerate="lapack"``: systems flagged rank deficient (csrc/dlt.h) are re-solved with the host's
+    LAPACK (lapack_dlt) -- one sync; ``info`` (a dict) receives n_degenerate."""
     X, Y = _dev(X, "X"), _dev(Y, "Y")
     N = X.shape[0]
     H = torch.empty((N, 3, 3), dtype=torch.float32, device=X.device)
-    _call("rfx_dlt4_homography", _one_device(X, Y), _p(X), _p(Y), N, _p(H))
+    if degenerate != "lapack":
+        _call("rfx_dlt4_homography", _one_device(X, Y), _p(X), _p(Y), N, _p(H))
+        return H
+    fl = torch.empty(N, dtype=torch.uint8, device=X.device)
+    _call("rfx_dlt4_homography_flags", _one_device(X, Y), _p(X), _p(Y), N, _p(H), _p(fl))
+    bad = ((fl & 4) != 0).nonzero()[:, 0]
+    if info is not None:
+        info["n_degenerate"] = int(bad.numel())
+    if bad.numel():
+        H[bad] = torch.from_numpy(lapack_dlt(X[bad].cpu().numpy(), Y[bad].cpu().numpy())).to(H.device)
     return H
 
 
@@ -619,7 +646,10 @@ def prediction(match1, match2, Hs):
     return err
 
 
-def score_hypotheses(match1, match2, samples, tol):
+def score_hypotheses(match1, match2, samples, tol, degenerate="device"):
+    """outil.ScoreRANSAC -> (H (N,3,3), counts (N,) int64).  ``degenerate="lapack"``: rank-deficient samples get the host
+    LAPACK's homography (lapack_dlt) and their counts are re-evaluated (rfx_prediction_f32 + torch.det on the host, like the
+    reference on a CPU run)."""
     match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
     samples = _dev(samples, "samples", torch.int64)
     n, N = match1.shape[0], samples.shape[0]
@@ -628,15 +658,30 @@ def score_hypotheses(match1, match2, samples, tol):
     counts = torch.empty(N, dtype=torch.int64, device=match1.device)
     ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=match1.device)
     _call("rfx_score_hypotheses", _one_device(match1, match2, samples), _p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts), _p(ws))
+    if degenerate == "lapack":
+        X, Y = match1[samples], match2[samples]
+        fl = torch.empty(N, dtype=torch.uint8, device=match1.device)
+        _call("rfx_dlt4_homography_flags", _one_device(X, Y), _p(X), _p(Y), N, _p(torch.empty_like(H)), _p(fl))
+        bad = ((fl & 4) != 0).nonzero()[:, 0]
+        if bad.numel():
+            Hp = torch.from_numpy(lapack_dlt(X[bad].cpu().numpy(), Y[bad].cpu().numpy()))
+            H[bad] = Hp.to(H.device)
+            cnt = torch.cat([(prediction(match1, match2, H[bad[i:i + 4096]]) < tol).sum(dim=1) for i in range(0, bad.numel(), 4096)])
+            counts[bad] = cnt * (torch.det(Hp) > 1e-6).long().to(cnt.device)
     return H, counts
 
 
-def ransac_h4(match1, match2, samples, tol):
+def ransac_h4(match1, match2, samples, tol, degenerate="device", info=None):
     """Device RANSAC.  Returns (bestH (3,3) f32, inlier (n,) bool, result int32[4]) as device tensors
-    (result = [status, best count, winning hypothesis index, #hypotheses after the duplicate filter])."""
+    (result = [status, best count, winning hypothesis index, #hypotheses after the duplicate filter]).
+    ``degenerate="lapack"``: the two-stage form of ransac_h4_batched for this one pair."""
     match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
     samples = _dev(samples, "samples", torch.int64)
     n, N = match1.shape[0], samples.shape[0]
+    if degenerate == "lapack" and n >= 4:
+        nd = torch.tensor([n], dtype=torch.int32, device=match1.device)
+        bH, inl, res = ransac_h4_batched(match1[None], match2[None], nd, samples[None], tol, degenerate="lapack", info=info)
+        return bH[0], inl[0], res[0]
     lib = _lib.load()
     dev = match1.device
     bestH = torch.empty((3, 3), dtype=torch.float32, device=dev)
@@ -660,9 +705,16 @@ def gather_matches(idx1, idx2, n, xa, ya, xb, yb):
     return m1, m2
 
 
-def ransac_h4_batched(match1, match2, n, samples, tol):
+def ransac_h4_batched(match1, match2, n, samples, tol, degenerate="device", info=None):
     """match1/match2 (B,cap,3), n (B,) int32 device, samples (B,N,4) int64 -> bestH (B,3,3), inlier (B,cap) bool,
-    result (B,4) int32 [status (3 = fewer than 4 matches), count, winner, nUnique] -- all device tensors."""
+    result (B,4) int32 [status (3 = fewer than 4 matches), count, winner, nUnique] -- all device tensors.
+    ``degenerate``: what to do with 4-point samples whose 8x9 DLT system is rank deficient (three matched points collinear in
+    both images; ~1 % of the draws on the cell lattices).  "device" (default, no host round trip): the Householder sweep's
+    own null vector -- a valid unit vector of the 2-D null space, but not the one the host LAPACK's rounding noise picks.
+    "lapack": the search runs in two stages around ONE sync: the flagged hypotheses (rfx_ransac_degenerate_list) are re-solved
+    with the host's LAPACK (lapack_dlt: utils/outil.py:68-87 itself) and patched in before counting, so that inlier counts,
+    the winner and its inlier indices equal a CPU run of the reference on this host bit for bit even when such a sample wins
+    (late multi-homography rounds with a handful of matches left).  ``info`` (dict) receives n_degenerate per pair."""
     match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
     n = _dev(n, "n", torch.int32)
     samples = _dev(samples, "samples", torch.int64)
@@ -676,8 +728,34 @@ def ransac_h4_batched(match1, match2, n, samples, tol):
     inl = torch.empty((B, cap), dtype=torch.uint8, device=dev)
     res = torch.empty((B, 4), dtype=torch.int32, device=dev)
     ws = torch.empty(lib.rfx_ransac_batched_ws_bytes(cap, N, B), dtype=torch.uint8, device=dev)
-    _call("rfx_ransac_h4_batched", _one_device(match1, match2, n, samples), _p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
-                                         _p(res), _p(ws), B)
+    odev = _one_device(match1, match2, n, samples)
+    if degenerate != "lapack":
+        _call("rfx_ransac_h4_batched", odev, _p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
+              _p(res), _p(ws), B)
+        return bestH, inl.bool(), res
+    args = (_p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res), _p(ws), B)
+    _call("rfx_ransac_h4_batched_stage", odev, *args, 1)
+    idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    _call("rfx_ransac_degenerate_list", odev, _p(ws), cap, N, B, _p(idx), _p(cnt), N)
+    cnt_h = cnt.cpu()                                                      # the one sync of the exact mode
+    if info is not None:
+        info["n_degenerate"] = cnt_h.tolist()
+    kmax = int(cnt_h.max())
+    if kmax > 0:
+        sel = idx[:, :kmax].long().clamp_(0, N - 1)                        # (B,kmax); rows beyond cnt[b] are ignored below
+        smp = torch.gather(samples, 1, sel[:, :, None].expand(-1, -1, 4))  # (B,kmax,4)
+        smp = torch.where(smp < 0, smp + n.long()[:, None, None], smp).clamp_(0, cap - 1)
+        bi = torch.arange(B, device=dev)[:, None, None]
+        X, Y = match1[bi, smp].cpu().numpy(), match2[bi, smp].cpu().numpy()    # (B,kmax,4,3)
+        valid = torch.arange(kmax)[None, :] < cnt_h[:, None].long()        # (B,kmax)
+        rows = valid.numpy().reshape(-1)
+        Hp = torch.zeros((B * kmax, 3, 3), dtype=torch.float32)
+        Hp[torch.from_numpy(rows)] = torch.from_numpy(lapack_dlt(X.reshape(-1, 4, 3)[rows], Y.reshape(-1, 4, 3)[rows]))
+        Hp = Hp.view(B, kmax, 9).to(dev)
+        idxc = idx[:, :kmax].contiguous()
+        _call("rfx_ransac_patch_h", odev, _p(ws), cap, N, B, _p(idxc), _p(cnt), _p(Hp), kmax)
+    _call("rfx_ransac_h4_batched_stage", odev, *args, 2)
     return bestH, inl.bool(), res
 
 

@@ -76,7 +76,7 @@ def cell_coords(n_rows, n_cols, device):
 
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
-                 device="cuda", kernelSize=7, draw="device", seed=0):
+                 device="cuda", kernelSize=7, draw="device", seed=0, degenerate="auto"):
         """``draw``: where the RANSAC index draw of utils/outil.py:120 happens when no explicit ``samples`` / ``sample_fn`` is
         given.  "device" (default; the reference draws on ``match1.device``, i.e. on the GPU in a GPU run): Philox4x32-10 on
         the device keyed by (``seed``, call counter, pair, hypothesis) -- no host sync for nbMatch, no CPU draw + upload.
@@ -84,6 +84,13 @@ class AlignPipeline:
         (the parity mode: the oracle can replay it from ``torch.manual_seed``)."""
         if draw not in ("device", "host"):
             raise ValueError("draw must be 'device' or 'host'")
+        if degenerate not in ("auto", "device", "lapack"):
+            raise ValueError("degenerate must be 'auto', 'device' or 'lapack'")
+        # rank-deficient 4-point samples (ops.ransac_h4_batched): "lapack" = re-solved by the host's LAPACK like the reference
+        # does for every hypothesis (one more sync per RANSAC call); "auto" = lapack whenever the draw comes from the host
+        # (explicit samples / sample_fn / draw="host": the modes in which a CPU run of the reference can be compared bit for bit,
+        # and which sync for the match counts anyway), device otherwise (the throughput mode: no host round trip)
+        self.degenerate = degenerate
         self.draw, self.seed, self._draw_calls = draw, int(seed), 0
         self.dev = torch.device(device)
         self.trunk = ResNet50Trunk(sds["trunk"], self.dev)
@@ -95,6 +102,11 @@ class AlignPipeline:
         self.scaleList = scale_list(nbScale, scaleR)
         self.mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
         self.std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+
+    def _degenerate_mode(self, host_draw):
+        if self.degenerate == "auto":
+            return "lapack" if host_draw else "device"
+        return self.degenerate
 
     def reseed(self, seed):
         """Restart the device-side index-draw stream (same seed + same call sequence -> same draws)."""
@@ -418,7 +430,9 @@ class AlignPipeline:
         lib_out = []
         # ONE batched mutual-NN launch chain for all pairs
         idx1, idx2, cnt = self._mutual_batched(feats, B, maskB)
-        if samples is None and sample_fn is None and self.draw == "device":
+        host_draw = not (samples is None and sample_fn is None and self.draw == "device")
+        self._last_degenerate = {}
+        if not host_draw:
             ids, epoch = self._draw_epoch(pair_ids)
             smp = self._device_draw(cnt, ids, epoch, 0)
             counts, draws = None, smp
@@ -433,10 +447,11 @@ class AlignPipeline:
                 else:
                     draws.append(torch.zeros((self.nbIter, 4), dtype=torch.int64))
             if len({tuple(d.shape) for d in draws}) != 1:       # explicit draws of different lengths: one launch chain per pair
-                return self._coarse_per_pair(feats, idx1, idx2, counts, draws)
+                return self._coarse_per_pair(feats, idx1, idx2, counts, draws, self._degenerate_mode(True))
             smp = torch.stack(draws).to(self.dev, non_blocking=True)
         M1, M2 = ops.gather_matches(idx1, idx2, cnt, feats["HA"], feats["WA"], feats["Ht"], feats["Wt"])
-        bestH, inl, resd = ops.ransac_h4_batched(M1, M2, cnt, smp, self.tol)
+        bestH, inl, resd = ops.ransac_h4_batched(M1, M2, cnt, smp, self.tol, degenerate=self._degenerate_mode(host_draw),
+                                                 info=self._last_degenerate)
         host = torch.cat((cnt[:, None], resd), dim=1).cpu().tolist()  # <- sync: result records (+ the match counts)
         for b in range(B):
             n, status, c, widx, nuniq = host[b]
@@ -449,7 +464,7 @@ class AlignPipeline:
             lib_out.append(res)
         return lib_out
 
-    def _coarse_per_pair(self, feats, idx1, idx2, counts, draws):
+    def _coarse_per_pair(self, feats, idx1, idx2, counts, draws, degenerate="device"):
         out = []
         for b, n in enumerate(counts):
             i1, i2 = idx1[b, :n], idx2[b, :n]
@@ -458,7 +473,7 @@ class AlignPipeline:
                 ones = torch.ones(n, dtype=torch.float32, device=self.dev)
                 m1 = torch.stack((feats["HA"][i1], feats["WA"][i1], ones), dim=1)
                 m2 = torch.stack((feats["Ht"][i2], feats["Wt"][i2], ones), dim=1)
-                bestH, inl, r = ops.ransac_h4(m1, m2, draws[b].to(self.dev), self.tol)
+                bestH, inl, r = ops.ransac_h4(m1, m2, draws[b].to(self.dev), self.tol, degenerate=degenerate)
                 status, c, widx, nuniq = r.cpu().tolist()
                 res.update(match1=m1, match2=m2, samples=draws[b], status=status, count=c, winner=widx, nUnique=nuniq)
                 if status == 0:
@@ -582,7 +597,8 @@ class AlignPipeline:
             ones = torch.ones(n, dtype=torch.float32, device=dev)
             m1 = torch.stack((H1[valid], W1[valid], ones), dim=1)
             m2 = torch.stack((H2[valid], W2[valid], ones), dim=1)
-            bestH, inl, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol)
+            bestH, inl, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol,
+                                            degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
             flowCoarse = ops.warp_grid(bestH[None], h, w)
             pm = self.pred_flow_mask(IsT, featt, flowCoarse)
             stat = torch.stack(((pm["match"][0, 0] * (1 - fg)).mean(), res[0].float()))
@@ -655,7 +671,8 @@ class AlignPipeline:
                                                feats["Wt"])
             smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
             rnd += 1
-            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol,
+                                                    degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flowCoarse = ops.warp_grid(Hs, h, w)
             Is = prep["IsTensor"] if full else prep["IsTensor"].index_select(0, A)
@@ -739,7 +756,8 @@ class AlignPipeline:
             ones = torch.ones(n, dtype=torch.float32, device=dev)
             m1 = torch.stack((H1[valid], W1[valid], ones), dim=1)
             m2 = torch.stack((H2[valid], W2[valid], ones), dim=1)
-            bestH, _, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol)
+            bestH, _, res = ops.ransac_h4(m1, m2, draw(n, self.nbIter).to(dev), self.tol,
+                                          degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
             hom_d2 = ops.warp_grid(bestH[None], h_d2, w_d2)
             hom_resize = ops.warp_grid(bestH[None], h_r, w_r)
             Is_d2 = ops.grid_sample(tensor_s, hom_d2)
@@ -833,7 +851,8 @@ class AlignPipeline:
                                                feats["Wt"])
             smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
             rnd += 1
-            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol)
+            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol,
+                                                    degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flow_d2, pm, match = self.kitti_fine_round(Hs, sel(tensor_s), sel(tensor_d2), sel(tensor_resize), (h_org, w_org),
                                                        cc_th, remove_small_cc)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""EVIDENCE SCRIPT -- why the device's trunk features carry ~2x the round-off of the CPU executors (profiles/r04_feature_error_*).
+
+The fp32 MFMA accumulates a convolution's K = Cin*KH*KW products as ONE k-ordered fma chain per output element (bit-identical to
+the CPU's "native" path where K is short: the stem, K = 147, matches it bit for bit).  MKL's sgemm and oneDNN's blocked
+convolutions accumulate K in blocks of a few hundred k (register block), adding each block's sum to the running total.  For a
+random-walk partial sum the chain's round-off grows like eps*K/sqrt(2), the blocked form's like eps*K/sqrt(2*n_blocks): this
+script measures both on synthetic layer-3-shaped dot products (post-ReLU activations x zero-mean weights, K = 256 ... 2304)
+against float64 and prints the ratio -- the factor the stage-wise measurement shows between "device" and "onednn"/"native".
+
+    python scripts/summation_order_model.py [--out profiles/r04_summation_order_model.json]
+"""
+import argparse
+import json
+
+import numpy as np
+
+
+def chain(p):                       # sequential float32 accumulation, one rounding per term (fma: the product is exact)
+    s = np.zeros(p.shape[0], dtype=np.float32)
+    for k in range(p.shape[1]):
+        s = (s.astype(np.float64) + p[:, k]).astype(np.float32)
+    return s
+
+
+def blocked(p, kc):
+    tot = np.zeros(p.shape[0], dtype=np.float32)
+    for k0 in range(0, p.shape[1], kc):
+        tot = (tot + chain(p[:, k0:k0 + kc])).astype(np.float32)
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--n", type=int, default=20000)
+    a = ap.parse_args()
+    rng = np.random.default_rng(0)
+    rows = []
+    for K in (147, 256, 576, 1024, 1152, 2304):
+        x = np.maximum(rng.standard_normal((a.n, K)), 0).astype(np.float32)                  # post-ReLU activations
+        w = (rng.standard_normal((a.n, K)) * np.sqrt(2.0 / K)).astype(np.float32)           # kaiming-scaled weights
+        p = x.astype(np.float64) * w.astype(np.float64)                                      # exact products (the fma's view)
+        ref = p.sum(axis=1)
+        e_chain = chain(p).astype(np.float64) - ref
+        row = dict(K=K, rms_signal=float(np.sqrt((ref ** 2).mean())), rms_err_chain=float(np.sqrt((e_chain ** 2).mean())))
+        for kc in (128, 256, 384):
+            e = blocked(p, kc).astype(np.float64) - ref
+            row["rms_err_blocked_%d" % kc] = float(np.sqrt((e ** 2).mean()))
+            row["chain_over_blocked_%d" % kc] = round(row["rms_err_chain"] / row["rms_err_blocked_%d" % kc], 2)
+        rows.append(row)
+        print(row)
+    out = dict(note="sequential fp32 accumulation (the MFMA's k-ordered chain) vs K-blocked accumulation (MKL / oneDNN register blocks) "
+                    "of the same exact products, error vs float64", samples=a.n, rows=rows)
+    if a.out:
+        json.dump(out, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

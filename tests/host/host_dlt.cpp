@@ -18,3 +18,18 @@ extern "C" void rfx_host_dlt4(const float* X, const float* Y, int N, double* h_o
 extern "C" void rfx_host_det3(const float* H, int N, float* out) {
     for (int n = 0; n < N; ++n) out[n] = rfx_det3_lu_f32(H + n * 9);
 }
+
+// The rank flag of the DLT kernel (dlt.h: Sturm count on the bidiagonal dgebd2 leaves), for the CPU pin against numpy's
+// singular values.
+extern "C" void rfx_host_dlt4_rank(const float* X, const float* Y, int N, unsigned char* deficient) {
+    for (int n = 0; n < N; ++n) {
+        float src[4][2], tgt[4][2];
+        for (int p = 0; p < 4; ++p) {
+            src[p][0] = X[(n * 4 + p) * 3 + 0]; src[p][1] = X[(n * 4 + p) * 3 + 1];
+            tgt[p][0] = Y[(n * 4 + p) * 3 + 0]; tgt[p][1] = Y[(n * 4 + p) * 3 + 1];
+        }
+        double h[9], bd[15];
+        rfx_dlt4_nullvec(src, tgt, h, bd);
+        deficient[n] = rfx_bidiag_rank_deficient(bd, RFX_DLT_RANK_REL) ? 1 : 0;
+    }
+}

@@ -427,6 +427,82 @@ def test_ransac_sentinels_and_many_seeds(dev):
     assert rel.max() <= 1e-3 and (rel <= 4e-7).float().mean() > 0.95  # host BLAS may round the K=3 chain differently
 
 
+def _lattice_few_matches(seed, n=13, n_line=6):
+    """A late multi-homography round in miniature: a handful of matches left on the 30x40 cell lattice -- ``n_line`` of them on
+    ONE lattice row that maps to a shifted row (collinear in both images, same spacing), the rest unrelated.  A sample with three
+    points of that line has a rank-7 DLT system, and such samples WIN here (they are the only ones that can explain the line):
+    23 of 40 seeds."""
+    W, Hh = restate.get_wh(30, 40)
+    cells = torch.stack((Hh, W, torch.ones_like(W)), 1).view(30, 40, 3)
+    g = torch.Generator().manual_seed(seed)
+    row = int(torch.randint(3, 27, (1,), generator=g))
+    cols = torch.randperm(36, generator=g)[:n_line]
+    flat = cells.view(-1, 3)
+    n_out = n - n_line
+    m1 = torch.cat((cells[row + 1, cols + 2], flat[torch.randperm(1200, generator=g)[:n_out]]))
+    m2 = torch.cat((cells[row, cols], flat[torch.randperm(1200, generator=g)[:n_out]]))
+    p = torch.randperm(n, generator=g)
+    return m1[p].clone(), m2[p].clone(), torch.randint(n, (600, 4), generator=g)
+
+
+def test_rank_deficient_winners_equal_the_host_lapack_in_exact_mode(dev):
+    """VERDICT r3 #4.  utils/outil.py:84 takes Vh[8] of an 8x9 system; when a sample's system has rank 7 (three matched points
+    collinear in both images) that vector is whatever the HOST's LAPACK rounds to.  ops.ransac_h4(degenerate="lapack") flags those
+    hypotheses on the device, re-solves exactly them with numpy's LAPACK and counts / selects on the patched set: bestH, the
+    count and the inlier indices equal the oracle's on THIS host bit for bit on every seed -- including seeds whose WINNER is
+    such a sample, which the device's own null vector ("device" mode) cannot reproduce.  Same for ScoreRANSAC / Homography and
+    for the batched form."""
+    n_degenerate_winner, n_device_differs = 0, 0
+    for seed in range(40):
+        m1, m2, s = _lattice_few_matches(seed)
+        try:
+            Hb, cnt, inl_ref, _ = restate.ransac(m1, m2, 0.05, s)
+        except TypeError:
+            continue
+        if Hb is None:
+            continue
+        info = {}
+        bestH, inl, res = ops.ransac_h4(m1.to(dev), m2.to(dev), s.to(dev), 0.05, degenerate="lapack", info=info)
+        r = res.cpu().tolist()
+        assert r[0] == 0 and r[1] == int(cnt), (seed, r, int(cnt))
+        assert np.array_equal(inl.cpu().numpy(), inl_ref), seed
+        assert np.array_equal(bestH.cpu().numpy(), Hb), (seed, np.abs(bestH.cpu().numpy() - Hb).max())
+        win = s[r[2]]
+        sv = np.linalg.svd(restate.dlt_matrix(m1[win][None].numpy(), m2[win][None].numpy()), compute_uv=False)[0]
+        if sv[7] / sv[0] < 1e-10:
+            n_degenerate_winner += 1
+            assert info["n_degenerate"][0] > 0
+            dH, dinl, _ = ops.ransac_h4(m1.to(dev), m2.to(dev), s.to(dev), 0.05)          # the device's own null vector
+            if not np.array_equal(dH.cpu().numpy(), Hb) or not np.array_equal(dinl.cpu().numpy(), inl_ref):
+                n_device_differs += 1
+    assert n_degenerate_winner >= 10, n_degenerate_winner        # the case is exercised ...
+    assert n_device_differs >= 1                                 # ... and it is one the device mode cannot pin
+    # ScoreRANSAC / Homography on the same kind of samples
+    m1, m2, s = _lattice_few_matches(5, n=40, n_line=12)
+    uniq = restate.filter_samples(s)
+    Ho, co = restate.score_ransac(m1, m2, 0.05, uniq)
+    Hd, cd = ops.score_hypotheses(m1.to(dev), m2.to(dev), uniq.to(dev), 0.05, degenerate="lapack")
+    flagged = np.abs(ops.score_hypotheses(m1.to(dev), m2.to(dev), uniq.to(dev), 0.05)[0].cpu().numpy() - Ho.numpy()).reshape(len(uniq), -1).max(1) > 1e-3
+    assert flagged.sum() >= 1
+    assert np.abs(Hd.cpu().numpy() - Ho.numpy()).max() <= 2.4e-7 and np.array_equal(Hd.cpu().numpy()[flagged], Ho.numpy()[flagged])
+    assert np.array_equal(cd.cpu().numpy(), co.numpy())
+    info = {}
+    Hh_ = ops.dlt4_homography(m1[uniq].to(dev), m2[uniq].to(dev), degenerate="lapack", info=info)
+    assert info["n_degenerate"] >= flagged.sum() and np.array_equal(Hh_.cpu().numpy()[flagged], Ho.numpy()[flagged])
+    # batched: three pairs of different sizes in one chain, per pair identical to the single-pair call
+    cases = [_lattice_few_matches(sd, n=nn) for sd, nn in ((3, 13), (8, 30), (11, 9))]
+    cap = max(len(c[0]) for c in cases)
+    M1 = torch.zeros((3, cap, 3)); M2 = torch.zeros((3, cap, 3))
+    for b, (a, c, _) in enumerate(cases):
+        M1[b, :len(a)], M2[b, :len(a)] = a, c
+    nd = torch.tensor([len(c[0]) for c in cases], dtype=torch.int32, device=dev)
+    S = torch.stack([c[2] % len(c[0]) for c in cases]).to(dev)
+    bH, bI, bR = ops.ransac_h4_batched(M1.to(dev), M2.to(dev), nd, S, 0.05, degenerate="lapack")
+    for b, (a, c, sm) in enumerate(cases):
+        h1, i1, r1 = ops.ransac_h4(a.to(dev), c.to(dev), (sm % len(a)).to(dev), 0.05, degenerate="lapack")
+        assert torch.equal(bH[b], h1) and torch.equal(bI[b, :len(a)], i1) and torch.equal(bR[b], r1)
+
+
 # ------------------------------------------------------------------ whole networks
 
 

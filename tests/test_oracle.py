@@ -102,6 +102,41 @@ def test_householder_dlt_is_lapack_sign_exact(tmp_path_factory):
     assert np.abs(Href - Hf[:64]).max() <= 1.2e-7
 
 
+def test_rank_flag_of_the_dlt_separates_degenerate_samples_from_the_rest(tmp_path_factory):
+    """dlt.h flags a 4-point sample whose 8x9 system is numerically rank deficient (one Sturm count on the bidiagonal; the flagged
+    hypotheses are the ones ops.ransac_h4_batched(degenerate="lapack") hands to the host's LAPACK).  Against numpy's singular
+    values on lattice matches under a near-translation -- where three matched points collinear in BOTH images are common: every
+    system with sigma_8 / sigma_1 < 1e-10 is flagged, none with sigma_8 / sigma_1 > 1e-6 is, and on the unflagged ones the
+    device restatement agrees with LAPACK to float32 rounding INCLUDING the sign (the part that cannot be pinned is exactly the
+    flagged part)."""
+    lib = _host_dlt_lib(tmp_path_factory)
+    W, Hh = restate.get_wh(30, 40)
+    cells = torch.stack((Hh, W, torch.ones_like(W)), 1)
+    g = torch.Generator().manual_seed(3)
+    pick = torch.randperm(len(cells), generator=g)[:400]
+    m2 = cells[pick]
+    m1 = m2.clone()
+    m1[:, 0] += 2 / 40.0                                       # a shift by one lattice column: collinear stays collinear
+    m1[::7] = cells[torch.randperm(len(cells), generator=g)[:len(m1[::7])]]
+    samples = restate.filter_samples(torch.randint(len(m1), (20000, 4), generator=g))
+    X, Y = m1[samples].contiguous().numpy(), m2[samples].contiguous().numpy()
+    N = len(X)
+    vp = ctypes.c_void_p
+    flag = np.zeros(N, dtype=np.uint8)
+    lib.rfx_host_dlt4_rank(X.ctypes.data_as(vp), Y.ctypes.data_as(vp), N, flag.ctypes.data_as(vp))
+    _, s, vh = np.linalg.svd(restate.dlt_matrix(X, Y))
+    ratio = s[:, 7] / s[:, 0]
+    assert (ratio < 1e-10).sum() > 50                          # the case exists in quantity on a lattice
+    assert flag[ratio < 1e-10].all() and not flag[ratio > 1e-6].any()
+    assert 0.001 < flag.mean() < 0.2
+    h = np.zeros((N, 9))
+    Hf = np.zeros((N, 9), dtype=np.float32)
+    lib.rfx_host_dlt4(X.ctypes.data_as(vp), Y.ctypes.data_as(vp), N, h.ctypes.data_as(vp), Hf.ctypes.data_as(vp))
+    ok = flag == 0
+    assert np.abs(Hf[ok] - vh[ok, 8].astype(np.float32)).max() <= 2.4e-7
+    assert np.abs(Hf[~ok] - vh[~ok, 8].astype(np.float32)).max() > 1e-3      # ... and the flagged ones really do differ
+
+
 def det_gate_cases(N, seed=0, spread=0.1):
     """N 4-point correspondences whose unit-norm DLT homography has |det| within +-``spread`` of the 1e-6 gate of
     utils/outil.py:108,113: H0 = U diag(1, 1, d) V^T (random orthogonal U, V) maps four spread-out target points onto a
