@@ -170,10 +170,13 @@ def cpu_baseline(args):
                                       (", %.1f homographies per pair" % (sum(nh) / len(nh))) if nh else "", dt)}
 
 
-def parity_subprocess(cfg, dump_dir, seeds, H, W, budget):
-    """oracle/parity_sweep.py over the dumped GPU results (child process; bounded)."""
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "parity_sweep.py"), "--config", cfg, "--dump", dump_dir, "--height",
-           str(H), "--width", str(W), "--budget", str(budget), "--seeds"] + [str(s) for s in seeds]
+def parity_subprocess(cfg, dump_dir, seeds, H, W, budget, stability=False):
+    """oracle/parity_sweep.py over the dumped GPU results (child process; bounded).  ``stability``: the reference against ITSELF
+    under a second CPU execution setting (8 threads + oneDNN vs 1 thread without oneDNN) on the same seeds -- the flip rate two
+    executions of the reference show against each other, reported next to the device's."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "parity_sweep.py"), "--config", cfg, "--height",
+           str(H), "--width", str(W), "--budget", str(budget)] + (["--stability", "--threads", "8"] if stability else ["--dump", dump_dir])
+    cmd += ["--seeds"] + [str(s) for s in seeds]
     if os.environ.get("RFX_PARITY_RECORDS"):        # per-pair records for profiles/ (evidence scripts)
         cmd += ["--records", os.environ["RFX_PARITY_RECORDS"] + "_" + cfg + ".json"]
     env = dict(os.environ, OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0")     # many oracle workers side by side: no spin-waiting
@@ -210,6 +213,7 @@ def parse_args():
     ap.add_argument("--parity-pairs", type=int, default=None, help="pairs of the batch covered by the parity sweep (default: all)")
     ap.add_argument("--parity-budget", type=float, default=110.0, help="wall-clock bound of the headline's parity sweep, seconds")
     ap.add_argument("--qs-parity-budget", type=float, default=60.0, help="wall-clock bound of the quick_start leg's parity sweep")
+    ap.add_argument("--stability-budget", type=float, default=45.0, help="wall-clock bound of the reference-vs-reference sweep")
     ap.add_argument("--no-qs-leg", "--no-config3-leg", dest="no_qs_leg", action="store_true",
                     help="default run: skip the quick_start leg (extra.quick_start)")
     ap.add_argument("--host-prep", action="store_true",
@@ -657,6 +661,13 @@ def main():
                     parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
                     log("parity sweep (quick_start: oracle end to end), budget %.0f s" % args.qs_parity_budget)
                     extras["quick_start"]["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.qs_parity_budget)
+                    log("reference vs reference (quick_start: two CPU execution settings), budget %.0f s" % args.stability_budget)
+                    ovo = parity_subprocess("qs", None, seeds, args.height, args.width, args.stability_budget, stability=True)
+                    extras["quick_start"]["parity"]["oracle_vs_oracle"] = ovo
+                    if "pairs" in ovo and ovo["pairs"]:
+                        q = extras["quick_start"]["parity"]
+                        q["flipped_pairs_device_vs_reference_per_pair"] = round(q["pairs_with_flips"] / max(q["pairs"], 1), 3)
+                        q["flipped_pairs_reference_vs_reference_per_pair"] = round(ovo["pairs_with_flips"] / ovo["pairs"], 3)
     elif rank == 0 and not args.dry_run and args.config == "qs" and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         line["cpu_baseline"] = cpu_baseline_subprocess(args)

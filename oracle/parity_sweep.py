@@ -710,15 +710,36 @@ def sweep(cfg_name, dump_dir, seeds, H, W, workers=None, threads=8, budget_s=Non
     return summarise(cfg_name, records, len(jobs), time.perf_counter() - t0, H, W), records
 
 
-def stability_sweep(cfg_name, seeds, H, W, threads_a, threads_b, budget_s=None):
+def stability_sweep(cfg_name, seeds, H, W, threads_a, threads_b, budget_s=None, workers=None):
+    """Oracle vs oracle over ``seeds`` (worker processes like sweep(); pairs not reached within the budget are reported)."""
+    import multiprocessing as mp
     t0 = time.perf_counter()
-    _W["sds"] = state_dicts()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys = cores // 2 if cores >= 64 else cores
+    workers = workers or max(1, phys // max(threads_a, 1))
+    jobs = [(cfg_name, s, H, W, threads_a, threads_b) for s in seeds]
     records = []
-    for s in seeds:
-        if budget_s and time.perf_counter() - t0 > budget_s:
-            break
-        records.append(_stab_job((cfg_name, s, H, W, threads_a, threads_b)))
-    return summarise_stability(cfg_name, records, H, W, threads_a, threads_b), records
+    if workers == 1:
+        _W["sds"] = state_dicts()
+        for j in jobs:
+            if budget_s and time.perf_counter() - t0 > budget_s:
+                break
+            records.append(_stab_job(j))
+    else:
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(workers, initializer=_worker_init, initargs=(threads_a, None)) as pool:
+            it = pool.imap_unordered(_stab_job, jobs)
+            for _ in jobs:
+                left = None if not budget_s else max(1.0, budget_s - (time.perf_counter() - t0))
+                try:
+                    records.append(it.next(timeout=left))
+                except mp.TimeoutError:
+                    break
+            pool.terminate()
+    records.sort(key=lambda r: r["seed"])
+    s = summarise_stability(cfg_name, records, H, W, threads_a, threads_b)
+    s.update(pairs_requested=len(jobs), oracle_wall_s=round(time.perf_counter() - t0, 1))
+    return s, records
 
 
 def main():
@@ -748,7 +769,7 @@ def main():
     a.height = a.height or CONFIGS[a.config].get("H", 480)
     a.width = a.width or CONFIGS[a.config].get("W", 640)
     if a.stability:
-        summary, records = stability_sweep(a.config, a.seeds, a.height, a.width, a.threads, a.threads_b, a.budget)
+        summary, records = stability_sweep(a.config, a.seeds, a.height, a.width, a.threads, a.threads_b, a.budget, a.workers)
     else:
         if not a.dump:
             ap.error("--dump is required unless --stability")

@@ -414,6 +414,258 @@ __global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dma_k
 #undef RFX_STRIP
 }
 
+
+// ======================================================================================================================
+// Round 4: the DPP form.  The tuned kernel above reads a 12-float y window (three ds_read_b128) per (channel, tap row) step
+// for 28 FMAs; with 15 waves that is 240 b128 reads = 245 KB of LDS reads per 2-channel chunk and CU, ~1900 clocks at 128 B/clk
+// -- the "compute only" run of that kernel takes as long as its "DMA only" run (142 vs 129 us at N = 64), which is why the two
+// cannot hide behind each other.  The window's left and right quads are the OWN quads of the lanes next door, so here a lane
+// reads ONE quad per step (its own 4 pixels of y row r+i) and takes the other 8 floats from its neighbours inside the FMA:
+//     v_fmac_f32_dpp acc, y_own[e], x[d] row_shr:1      (window element e < 4: the left neighbour's quad)
+//     v_fmac_f32_dpp acc, y_own[e], x[d] row_shl:1      (e >= 8: the right neighbour's)
+// -- no extra instruction, the same channel-ordered fma chain (bit-identical results), a third of the LDS reads.
+// DPP shifts work inside rows of 16 lanes, so a tile row of NQ output quads (+ one halo quad on each side) is cut into segments
+// of at most 16 consecutive quads that overlap by two: the first and last lane of a segment only HOLD a quad for their
+// neighbour (their own sums are discarded), 14 of 16 lanes are productive (20 of 24 for an 80-column tile: segments of 16 + 8,
+// two 8-lane segments share a DPP row).  lane -> (tile row, quad) is pure integer arithmetic on the lane id (dpp_map).
+template <int TR_, int NCB_, int CK_, int NS_, int NG_, int OPT_ = 0>
+struct CfgD {
+    static constexpr int TR = TR_, NCB = NCB_, CK = CK_, NS = NS_, NG = NG_;
+    static constexpr bool BIDIR = OPT_ & 16;
+    static constexpr int NQ = 4 * NCB;                         // output quads per tile row
+    static constexpr int NSEGF = NQ / 14;                      // full 16-lane segments per row (14 productive lanes each)
+    static constexpr int REM = NQ - 14 * NSEGF;                // productive lanes of the partial segment (0: none)
+    static constexpr int LP = REM ? REM + 2 : 16;              // lanes of the partial segment
+    static constexpr int PPR = REM ? 16 / LP : 0;              // partial segments packed into one DPP row
+    static constexpr int RG = REM ? PPR : 1;                   // tile rows per packing group
+    static constexpr int DG = RG * NSEGF + (REM ? 1 : 0);      // DPP rows per packing group
+    static constexpr int DROWS = (TR + RG - 1) / RG * DG;      // DPP rows of a tile
+    static constexpr int WPG = (DROWS + 3) / 4;                // waves per tap-row group
+    static constexpr int NW = WPG * NG;
+    static constexpr int YR = TR + 6, YQ = NQ + 2, XQ = NQ;
+    static constexpr int Y_SLOTS = CK * YR * YQ, Y_PIECES = (Y_SLOTS + 63) / 64;
+    static constexpr int X_SLOTS = CK * TR * XQ, X_PIECES = (X_SLOTS + 63) / 64;
+    static constexpr int PPW = (Y_PIECES + X_PIECES + NW - 1) / NW;
+    static constexpr int N_PIECES = PPW * NW;
+    static constexpr int BUF_SLOTS = N_PIECES * 64;
+    static constexpr int row_begin(int g) { return NG == 2 ? (g == 0 ? 0 : g == 1 ? 4 : 7) : (g == 0 ? 0 : g == 1 ? 3 : g == 2 ? 5 : 7); }
+    static constexpr int WAVES_PER_SIMD = (NW + 3) / 4;
+    // wave -> tap group so that the waves the hardware deals to one SIMD (w, w+4, w+8, ..) mix heavy and light groups
+    static constexpr int wave_group(int w) { return (w % 4 + w / 4) % NG; }
+    static constexpr int wave_block(int w) { int r = 0; for (int v = 0; v < w; ++v) r += wave_group(v) == wave_group(w); return r; }
+    static_assert(NG == 2 || NG == 3, "2 or 3 tap-row groups");
+    static_assert(NW * 64 <= 1024, "workgroup too large");
+    static_assert((NS - 2) * PPW <= 15, "vmcnt immediate out of range");
+    static_assert((size_t)NS * BUF_SLOTS * 16 <= 160 * 1024, "LDS ring exceeds 160 KiB");
+};
+
+// (DPP row R of the tile, position p in it) -> tile row, quad (-1 / NQ = halo holders), productive?
+template <class G>
+__device__ __forceinline__ void dpp_map(int R, int p, int& row, int& quad, bool& prod) {
+    const int k = R / G::DG, m = R - k * G::DG;
+    if (m < G::RG * G::NSEGF) {
+        row = k * G::RG + m / G::NSEGF;
+        quad = (m % G::NSEGF) * 14 + p - 1;
+        prod = p >= 1 && p <= 14;
+    } else {
+        const int sub = p / G::LP, q = p - sub * G::LP;
+        row = k * G::RG + sub;
+        quad = G::NSEGF * 14 + q - 1;
+        prod = sub < G::PPR && q >= 1 && q <= G::REM;
+        if (sub >= G::PPR) { row = 0; quad = 0; }
+    }
+}
+
+template <int CTL>   // 0: own lane, 1: row_shr:1 (value of lane-1), 2: row_shl:1 (value of lane+1)
+__device__ __forceinline__ void fmac_dpp(float& acc, float y, float x) {
+    if constexpr (CTL == 0) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(y), "v"(x));
+    else if constexpr (CTL == 1) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(y), "v"(x));
+    else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(y), "v"(x));
+}
+
+// (channel, tap row) steps of one chunk; reads run one step ahead with counted waits as in corr7_steps
+template <class G, int I0, int I1, int ST>
+__device__ __forceinline__ void corr7_dpp_steps(f32x4 (&yq)[G::CK * (I1 - I0)], f32x4 (&xq)[G::CK], float (&acc)[4][(I1 - I0) * 7],
+                                                unsigned ya, unsigned xa) {
+    constexpr int NI = I1 - I0, NSTEP = G::CK * NI;
+    constexpr int YROW = G::YQ * 16, YCH = G::YR * G::YQ * 16, XCH = G::TR * G::XQ * 16;
+    if constexpr (ST == 0) {
+        lds_read128<0>(xq[0], xa);
+        lds_read128<I0 * YROW>(yq[0], ya);
+    }
+    constexpr int S2 = ST + 1;
+    if constexpr (S2 < NSTEP) {
+        if constexpr (S2 % NI == 0) lds_read128<(S2 / NI) * XCH>(xq[S2 / NI], xa);
+        lds_read128<(S2 / NI) * YCH + (I0 + S2 % NI) * YROW>(yq[S2], ya);
+    }
+    constexpr int NEWER = S2 < NSTEP ? 1 + (S2 % NI == 0 ? 1 : 0) : 0;
+    constexpr int ch = ST / NI, r = ST % NI;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(yq[ST]), "+v"(xq[ch]) : "n"(NEWER));
+    const f32x4 yv = yq[ST], xv = xq[ch];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int e = d + j + 1;                       // element of the 12-float window: 0-3 left, 4-7 own, 8-11 right quad
+            float& a = acc[d][r * 7 + j];
+            if (e < 4) fmac_dpp<1>(a, yv[e & 3], xv[d]);
+            else if (e < 8) fmac_dpp<0>(a, yv[e & 3], xv[d]);
+            else fmac_dpp<2>(a, yv[e & 3], xv[d]);
+        }
+    if constexpr (ST + 1 < NSTEP) corr7_dpp_steps<G, I0, I1, ST + 1>(yq, xq, acc, ya, xa);
+}
+
+template <class G, int I0, int I1>
+__device__ __forceinline__ void corr7_dpp_strip(f32x4* smem, const float* xn, const float* yn, const int* off, int wave, int amask,
+                                                int blk, int lane, int nchunks, size_t HW, float* __restrict__ out,
+                                                float* __restrict__ out21, int n, int row0, int H, int W, int trv) {
+    constexpr int NI = I1 - I0, NS = G::NS, CK = G::CK;
+    auto issue = [&](int chunk, int buf) {
+        const size_t cbase = (size_t)chunk * CK * HW;
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int pi = wave + G::NW * i;
+            const float* base = (pi < G::Y_PIECES ? yn : xn) + cbase;
+            if ((amask >> i) & 1)
+                if (off[i] >= 0)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + off[i]), (lptr_t)(smem + buf * G::BUF_SLOTS + pi * 64), 16, 0, 0);
+        }
+    };
+    const int npieces = __builtin_popcount((unsigned)amask);
+    float acc[4][NI * 7];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int q = 0; q < NI * 7; ++q) acc[d][q] = 0.f;
+    int tr, quad;
+    bool prod;
+    dpp_map<G>(blk * 4 + (lane >> 4), lane & 15, tr, quad, prod);
+    if (tr >= G::TR) { tr = 0; prod = false; }                  // DPP rows past the tile (DROWS not a multiple of 4)
+    const int yoff = tr * G::YQ + quad + 1;                      // own quad of y row tr (+ tap row, + channel added as immediates)
+    const int xoff = tr * G::XQ + (quad < 0 ? 0 : (quad >= G::NQ ? G::NQ - 1 : quad));
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nchunks) issue(p, p);
+    int buf = 0;
+    for (int s = 0; s < nchunks; ++s) {
+        const int younger = nchunks - 1 - s < NS - 2 ? nchunks - 1 - s : NS - 2;
+        wait_vm(younger * npieces);
+        __builtin_amdgcn_s_barrier();
+        if (s + NS - 1 < nchunks) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        const unsigned ya = lds_base + (unsigned)(buf * G::BUF_SLOTS + yoff) * 16u;
+        const unsigned xa = lds_base + (unsigned)(buf * G::BUF_SLOTS + G::Y_PIECES * 64 + xoff) * 16u;
+        f32x4 yq[CK * NI];
+        f32x4 xq[CK];
+        corr7_dpp_steps<G, I0, I1, 0>(yq, xq, acc, ya, xa);
+        buf = buf == NS - 1 ? 0 : buf + 1;
+    }
+    const int gr = row0 + tr, gc = quad * 4;
+    if (prod && tr < trv && gr < H && gc < W) {
+        float* o = out + (size_t)n * 49 * HW + (size_t)gr * W + gc;
+#pragma unroll
+        for (int q = 0; q < NI * 7; ++q) {
+            f32x4 v = {acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+            *reinterpret_cast<f32x4*>(o + (size_t)(I0 * 7 + q) * HW) = v;
+        }
+        if constexpr (G::BIDIR) {                               // see corr7_strip: the reverse volume from the same sums
+            float* o21 = out21 + (size_t)n * 49 * HW;
+#pragma unroll
+            for (int q = 0; q < NI * 7; ++q) {
+                const int i = I0 + q / 7, j = q % 7;
+                float* pl = o21 + (size_t)((6 - i) * 7 + (6 - j)) * HW;
+                const int dr = gr + i - 3;
+                if ((unsigned)dr < (unsigned)H) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int dc = gc + d + j - 3;
+                        if ((unsigned)dc < (unsigned)W) pl[(size_t)dr * W + dc] = acc[d][q];
+                    }
+                }
+                const int sr = gr - (i - 3);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int sc = gc + d - (j - 3);
+                    if ((unsigned)sr >= (unsigned)H || (unsigned)sc >= (unsigned)W) pl[(size_t)gr * W + gc + d] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__((G::NW * 64), (G::WAVES_PER_SIMD)) void corr7_dpp_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, float* __restrict__ out21, int N, int C,
+    int H, int W, int tilesR, int trv) {
+    constexpr int TR = G::TR, NG = G::NG;
+    __shared__ __attribute__((aligned(16))) f32x4 smem[G::NS * G::BUF_SLOTS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwg = N * tilesR;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: all tiles of one image on one XCD (halo re-reads hit that L2)
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int n = bid / tilesR;
+    const int row0 = (bid - n * tilesR) * trv;
+    const size_t HW = (size_t)H * W;
+    const float* xn = x + (size_t)n * C * HW;
+    const float* yn = y + (size_t)n * C * HW;
+    int off[G::PPW];
+    int amask = 0;
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) {
+        const int pi = wave + G::NW * i;
+        int o = -1;
+        if (pi < G::Y_PIECES) {
+            const int s = pi * 64 + lane;
+            if (s < G::Y_SLOTS) {
+                const int ch = s / (G::YR * G::YQ), rem = s - ch * (G::YR * G::YQ);
+                const int rr = rem / G::YQ, q = rem - rr * G::YQ;
+                const int gr = row0 + rr - 3, gc = -4 + 4 * q;
+                if (rr < trv + 6 && (unsigned)gr < (unsigned)H && (unsigned)gc < (unsigned)W) o = (int)(ch * HW) + gr * W + gc;
+            }
+        } else if (pi < G::Y_PIECES + G::X_PIECES) {
+            const int s = (pi - G::Y_PIECES) * 64 + lane;
+            if (s < G::X_SLOTS) {
+                const int ch = s / (TR * G::XQ), rem = s - ch * (TR * G::XQ);
+                const int rr = rem / G::XQ, q = rem - rr * G::XQ;
+                const int gr = row0 + rr, gc = 4 * q;
+                if (rr < trv && gr < H && gc < W) o = (int)(ch * HW) + gr * W + gc;
+            }
+        }
+        if (__ballot(o >= 0) != 0ull) amask |= 1 << i;
+        off[i] = o;
+    }
+    // zero the out-of-image / padding slots of every ring buffer ONCE: the DMA never writes them
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i)
+        if (off[i] < 0) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < G::NS; ++b) smem[b * G::BUF_SLOTS + (wave + G::NW * i) * 64 + lane] = z;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr unsigned long long gmap = []() { unsigned long long m = 0; for (int w = 0; w < G::NW; ++w) m |= (unsigned long long)G::wave_group(w) << (2 * w); return m; }();
+    constexpr unsigned long long bmap = []() { unsigned long long m = 0; for (int w = 0; w < G::NW; ++w) m |= (unsigned long long)G::wave_block(w) << (4 * w); return m; }();
+    const int grp = (int)((gmap >> (2 * wave)) & 3), blk = (int)((bmap >> (4 * wave)) & 15);
+    const int nch = C / G::CK;
+#define RFX_DSTRIP(g) corr7_dpp_strip<G, G::row_begin(g), G::row_begin(g + 1)>(smem, xn, yn, off, wave, amask, blk, lane, nch, HW, out, out21, n, row0, H, W, trv)
+    if (grp == 0) RFX_DSTRIP(0);
+    else if (grp == 1) RFX_DSTRIP(1);
+    if constexpr (NG > 2) { if (grp == 2) RFX_DSTRIP(2); }
+#undef RFX_DSTRIP
+}
+
+template <class G>
+static void launch_corr_dpp(const float* x, const float* y, float* out, int N, int C, int H, int W, hipStream_t st, float* out21 = nullptr) {
+    const int tilesR = (H + G::TR - 1) / G::TR;
+    const int trv = (H + tilesR - 1) / tilesR;                  // equal row tiles (60 = 4 x 15)
+    hipLaunchKernelGGL((corr7_dpp_kernel<G>), dim3((unsigned)(N * tilesR)), dim3(G::NW * 64), 0, st, x, y, out, out21, N, C, H, W,
+                       tilesR, trv);
+}
+
 // Small launches (the multi-homography rounds of the evaluation drivers run the correlation on the 8-16 pairs that are still
 // active: 48-200 workgroups of 16-row tiles on 256 CUs) are bound by the lifetime of ONE workgroup, not by bandwidth.
 // Experiment knob RFX_CORR_MIN_WGS = n: equal row tiles are made shorter than 16 rows until the grid reaches n workgroups or a
@@ -487,6 +739,7 @@ static int launch_variant(int v, const float* x, const float* y, float* out, flo
             case 5: launch_corr<CfgTunedB>(x, y, out, N, C, H, W, st, true, out21); break;
             case 7: launch_corr<CfgTuned3B>(x, y, out, N, C, H, W, st, true, out21); break;
             case 8: launch_corr<CfgTuned4B>(x, y, out, N, C, H, W, st, true, out21); break;
+            case 14: if (W > 80) return RFX_E_ARG; launch_corr_dpp<CfgD<16, 5, 2, 4, 2, 16>>(x, y, out, N, C, H, W, st, out21); break;
             default: return RFX_E_ARG;
         }
         return RFX_OK;
@@ -505,6 +758,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, flo
         case 11: launch_corr<Cfg<16, 5, 2, 5, 3, 1, 0, 0, 15 | 32>>(x, y, out, N, C, H, W, st, true); break;   // 10 with a ring of 5
         case 12: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 64>>(x, y, out, N, C, H, W, st, true); break;   // 5 + accumulator bank rotation
         case 13: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 0, 0, 15 | 32 | 64>>(x, y, out, N, C, H, W, st, true); break;   // 12 + DMA on the light waves
+        case 14: if (W > 80) return RFX_E_ARG; launch_corr_dpp<CfgD<16, 5, 2, 4, 2>>(x, y, out, N, C, H, W, st); break;   // DPP form, 80-column tiles, 2 tap groups
+        case 15: if (W > 80) return RFX_E_ARG; launch_corr_dpp<CfgD<16, 5, 2, 3, 2>>(x, y, out, N, C, H, W, st); break;   // 14 with a ring of 3
 #ifdef RFX_CORR_EXPERIMENTS   // `make exp NAME=correxp SRC=corr DEFS=-DRFX_CORR_EXPERIMENTS`: never in the product library
         case 21: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 1, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
         case 22: launch_corr<Cfg<16, 5, 2, 4, 3, 1, 2, 0, 15>>(x, y, out, N, C, H, W, st, true); break;
@@ -521,6 +776,8 @@ static int launch_variant(int v, const float* x, const float* y, float* out, flo
 // taken when the launch still gives most CUs a workgroup.  Otherwise 16-column tiles, as tall as the workgroup count allows
 // (>= 1024 workgroups).
 static int auto_variant(int N, int H, int W) {
+    static const int force = []() { const char* e = getenv("RFX_CORR_FORCE"); return e ? atoi(e) : 0; }();   // experiments
+    if (force == 14 && W > 32 && W <= 80) return 14;
     const long long tc = (W + TC - 1) / TC;
     const long long r16 = (H + 15) / 16;
     if (W > 32 && (long long)N * r16 * ((W + 79) / 80) >= 128) {

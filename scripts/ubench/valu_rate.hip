@@ -1,6 +1,8 @@
 // valu_rate.hip -- issue rate of the fp32 VALU forms the 7x7 correlation kernel can be written in (gfx950):
 //   0: v_fmac_f32 (scalar FMA)          1: v_pk_fma_f32 (aligned pairs)
 //   2: v_pk_fma_f32 with op_sel cross    3: v_pk_mov_b32      4: v_mov_b32
+//   5 / 6 / 7: v_fmac_f32_dpp row_shr:1 / row_shl:1 / wave_shr:1 (the y operand taken from the neighbouring lane: round 4, the
+//   correlation kernel's window quads exchanged between lanes instead of re-read from LDS)   8: 16 plain : 12 DPP, as in that loop
 // Each wave runs REP x 32 independent instructions per loop iteration; grid = 256 CUs x 4 SIMDs x WPS waves.
 // Prints instructions/cycle/SIMD at the measured clock-free rate (instr / s / 1024 SIMDs) and the implied TFLOP/s.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_rate.bin valu_rate.hip && ./valu_rate.bin
@@ -27,6 +29,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(a[i]) : "v"(x), "v"(y));
                 } else if (MODE == 3) {
                     asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "+v"(a[i]) : "v"(x), "v"(y));
+                } else if (MODE == 5) {
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].x) : "v"(x.x), "v"(y.x));
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].y) : "v"(x.y), "v"(y.y));
+                } else if (MODE == 6) {
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].x) : "v"(x.x), "v"(y.x));
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].y) : "v"(x.y), "v"(y.y));
+                } else if (MODE == 7) {
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].x) : "v"(x.x), "v"(y.x));
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].y) : "v"(x.y), "v"(y.y));
+                } else if (MODE == 8) {
+                    if (i % 7 < 4) {
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "v"(x.x), "v"(y.x));
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].y) : "v"(x.y), "v"(y.y));
+                    } else {
+                        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].x) : "v"(x.x), "v"(y.x));
+                        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a[i].y) : "v"(x.y), "v"(y.y));
+                    }
                 } else {
                     asm volatile("v_mov_b32 %0, %1" : "+v"(a[i].x) : "v"(x.x));
                     asm volatile("v_mov_b32 %0, %1" : "+v"(a[i].y) : "v"(x.y));
@@ -66,5 +85,9 @@ int main() {
     run<2>("v_pk_fma_f32 op_sel cross", 1, 4, d);
     run<3>("v_pk_mov_b32", 1, 0, d);
     run<4>("v_mov_b32", 2, 0, d);
+    run<5>("v_fmac_f32_dpp row_shr:1", 2, 2, d);
+    run<6>("v_fmac_f32_dpp row_shl:1", 2, 2, d);
+    run<7>("v_fmac_f32_dpp wave_shr:1", 2, 2, d);
+    run<8>("v_fmac_f32 16 plain : 12 dpp", 2, 2, d);
     return 0;
 }

@@ -14,7 +14,7 @@ import sys
 
 import pytest
 
-import parity_sweep
+import parity_sweep  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +46,54 @@ def test_end_to_end_parity_sweep_480x640(dev, cfg, tmp_path):
     # pairs whose lists differ: every differing match must be a float64 near-tie of the arg-max, their rate is bounded,
     # and the fine stage alone (device H through the oracle's fine stage) still meets the bound
     assert s["flips_all_near_ties"], s["max_tie_evidence"]
-    assert s["total_flipped_matches"] <= max(2, s["total_matches"] // 200)
+    # measured rate (round 4, 64 pairs, device vs the reference): 26 of 65 073 matches (qs), 55 of 38 867 (ev) -- 4.0e-4 / 1.4e-3;
+    # the bound is twice that (the old bound, 1/200, would have let a tripled flip rate pass).  Why the device flips more often
+    # than two CPU executions of the reference do against each other: profiles/r04_feature_error_*.json (DESIGN 4)
+    rate = 8.0e-4 if cfg == "qs" else 2.8e-3
+    assert s["total_flipped_matches"] <= max(3, int(rate * s["total_matches"])), (s["total_flipped_matches"], s["total_matches"])
     if s["pairs_with_flips"]:
         assert s["max_flow_delta_fine_stage_with_flips"] < 1e-3
+    assert s["downstream_exact_given_matches"] == "%d/%d" % (n, n)          # everything downstream of the arg-max is exact
+    assert s["oracle"].startswith("reference"), s["oracle"]                   # the checker is the reference itself (oracle/_ref)
+
+
+@pytest.mark.parametrize("cfg,seed", [("ev_loop", 5), ("c4", 1), ("c5", 2)])
+def test_full_size_multi_homography_loops_round_by_round_vs_the_reference(dev, cfg, seed, tmp_path):
+    """VERDICT r3 #3: BASELINE configs 3 / 4 / 5 AT FULL SIZE inside the driver-run suite -- 64-pair-shaped 480x640 (nA 13 065),
+    960x720 with 5 scales x2 and 50 000 hypotheses (nA 21 675 x nB 2 700; evaluation/evalHpatch/evaluation.py:211-243) and the
+    KITTI two-resolution loop at 1242x376 (nA 25 747 x nB 8 250; evaluation/evalKITTI/evaluation.py:270-336), one pair each.
+    The lock-step device driver leaves a per-round trace; the REFERENCE ITSELF (its getCoarse / outil.RANSAC on the device's
+    cached matches with the round's draw, its PredFlowMask -- for KITTI one pass of its ``while True`` statement -- its accept
+    rule) replays every round from the device's state, and also runs its own loop end to end.  Asserted per round: same
+    surviving-match count, RANSAC status, bit-exact inlier indices, H to float32 round-off, in-bounds flow within 1e-3, /8 flows,
+    the accept decision, the next mask up to threshold pixels; no rank-deficient-winner exemption (exact mode, VERDICT r3 #4)."""
+    c = parity_sweep.CONFIGS[cfg]
+    parity_sweep.dump_gpu_loop(cfg, [seed], dev, str(tmp_path), batch=1)
+    rec = str(tmp_path / "records.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "parity_sweep.py"), "--config", cfg, "--dump", str(tmp_path),
+                          "--seeds", str(seed), "--workers", "1", "--threads", "16", "--records", rec],
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    s = json.loads(out.stdout.strip().splitlines()[-1])
+    print(json.dumps({k: v for k, v in s.items() if k not in ("errors",)}))
+    assert not s["errors"] and s["pairs"] == 1 and s["oracle"].startswith("reference")
+    assert (s["nA"], s["nB"]) == {"ev_loop": (13065, 1200), "c4": (21675, 2700), "c5": (25747, 8250)}[cfg]
+    assert s["flips_all_near_ties"]
+    assert s["rounds"] >= 2 and s["rounds_count_equal"] == s["rounds"] and s["rounds_status_equal"]
+    assert s["rounds_compared"] >= 1
+    assert s["rounds_degenerate_winner"] == 0 or s["max_H_delta"] is not None
+    r = json.load(open(rec))["records"][0]
+    for q in r["round_records"]:
+        if "H_delta" not in q:
+            continue
+        assert q["inlier_bit_exact"], q
+        assert q["H_delta"] <= 2e-6, q                                    # incl. rounds won by a rank-deficient sample
+        assert q["flow12_delta"] < 1e-3 and q["flowDown8_delta"] < 1e-4, q
+        assert q["accept_equal"], q
+        if "flowD2_delta" in q:
+            assert q["flowD2_delta"] < 1e-4, q
+        if q.get("mask_diff_frac", 0) > 0:
+            assert q["mask_diff_frac"] < 1e-3 and (q.get("mask_diff_at_threshold", True)), q
+    if r["identical_list"]:
+        assert r["free_run"]["same_nbH"] and r["free_run"].get("max_H_delta", 0.0) <= 2e-6
+    assert c["H"] * c["W"] >= 480 * 640
