@@ -14,6 +14,7 @@
 // (masked) columns, which the v*v > 0 test drops exactly as the reference's product test does.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,82 @@ struct MnnArgs {
 
 __device__ __forceinline__ void take_min_idx(float& bv, int& bi, float ov, int oi) {
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+// Arg-max epilogue of a 128 x 128 score tile held in the accumulators of the 2 x 2 wavefronts (C/D layout: column = lcol,
+// row = (r&3) + 8*(r>>2) + 4*lrow): per-tile column and row maxima (value, first index) -> the workspace.  xval / xidx:
+// 2 x 128 floats / ints of LDS that no wavefront reads any more.
+__device__ __forceinline__ void mnn_tile_epilogue(f32x16 (&acc)[2][2], const MnnArgs& a, float* xval, int* xidx, int i0, int j0,
+                                                  int ta, int tb, float* rowPartVal, int* rowPartIdx, float* colPartVal,
+                                                  int* colPartIdx) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    // ---- column arg-max over this tile's rows (C/D: col = lcol, row = (r&3) + 8*(r>>2) + 4*lrow) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = i0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                const float v = acc[i][j][r];
+                if (gi < a.nA && v > bv) { bv = v; bi = gi; }  // rows visited in increasing order: first max kept
+            }
+        const float ov = __shfl_xor(bv, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        take_min_idx(bv, bi, ov, oi);
+        if (lrow == 0) {
+            xval[wm * 128 + (wn * 2 + j) * 32 + lcol] = bv;
+            xidx[wm * 128 + (wn * 2 + j) * 32 + lcol] = bi;
+        }
+    }
+    __syncthreads();
+    if (t < 128 && j0 + t < a.nB) {
+        float bv = xval[t];
+        int bi = xidx[t];
+        take_min_idx(bv, bi, xval[128 + t], xidx[128 + t]);
+        colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
+        colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
+    }
+    __syncthreads();
+
+    // ---- row arg-max over this tile's columns ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float bv = -INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gj = j0 + (wn * 2 + j) * 32 + lcol;
+                const float v = acc[i][j][r];
+                if (gj < a.nB && v > bv) { bv = v; bj = gj; }
+            }
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) {
+                const float ov = __shfl_xor(bv, m, 64);
+                const int oj = __shfl_xor(bj, m, 64);
+                take_min_idx(bv, bj, ov, oj);
+            }
+            if (lcol == 0) {
+                const int li = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                xval[wn * 128 + li] = bv;
+                xidx[wn * 128 + li] = bj;
+            }
+        }
+    __syncthreads();
+    if (t < 128 && i0 + t < a.nA) {
+        float bv = xval[t];
+        int bj = xidx[t];
+        take_min_idx(bv, bj, xval[128 + t], xidx[128 + t]);
+        rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
+        rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
+    }
 }
 
 // VEC: both feature matrices have a leading dimension that is a multiple of 4 and 16-byte aligned rows -- the staging then
@@ -195,74 +272,147 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
         __syncthreads();
         cur ^= 1;
     }
-    // all waves are past the last barrier: the staging buffers are free for the exchange below
-    float* xval = &As[0][0][0][0];                        // [2][128] values
-    int* xidx = reinterpret_cast<int*>(&Bs[0][0][0][0]);  // [2][128] indices
+    // all waves are past the last barrier: the staging buffers are free for the exchange
+    mnn_tile_epilogue(acc, a, &As[0][0][0][0], reinterpret_cast<int*>(&Bs[0][0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx,
+                      colPartVal, colPartIdx);
+}
 
-    // ---- column arg-max over this tile's rows (C/D: col = lcol, row = (r&3) + 8*(r>>2) + 4*lrow) ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gi = i0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                const float v = acc[i][j][r];
-                if (gi < a.nA && v > bv) { bv = v; bi = gi; }  // rows visited in increasing order: first max kept
-            }
-        const float ov = __shfl_xor(bv, 32, 64);
-        const int oi = __shfl_xor(bi, 32, 64);
-        take_min_idx(bv, bi, ov, oi);
-        if (lrow == 0) {
-            xval[wm * 128 + (wn * 2 + j) * 32 + lcol] = bv;
-            xidx[wm * 128 + (wn * 2 + j) * 32 + lcol] = bi;
-        }
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the k-major form of the tile kernel.  Both feature matrices are (C, cells) -- k-major, exactly like the two
+// operands of a 1x1 convolution -- and a lane of v_mfma_f32_32x32x2_f32 supplies ONE float per operand, so with k-major LDS
+// images As[k][cell], Bs[k][cell] a lane's operand is a single ds_read_b32 (32 consecutive lanes read 32 consecutive floats:
+// conflict-free by construction) and staging is a straight 16-byte copy without the 4x4 register transposes, the XOR swizzle
+// and the validity masks of mnn_tile_kernel above (4.3e9 LDS bank-conflict cycles per launch in round 3's counters): the scheme
+// of conv1x1.hip, one barrier per K step, every staging register stored and re-loaded in the shadow of the first two MFMA
+// chunks.  Cells past the end of a matrix read clamped (valid, finite) addresses: they only feed accumulator rows / columns
+// the arg-max skips.  The 0/1 column mask (quick_start/coarseAlignFeatMatch.py:143 multiplies the target features by it) is
+// applied to the finished accumulators: for a 0/1 mask the same values up to the sign of a zero, which no comparison sees.
+// Same k pairing and order as the kernel above: bit-identical scores.  Requires C % 32 == 0, C >= 64.
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
+    constexpr int NV = 4, NS = 16;                 // per operand, thread and K step: float4 (VEC) / floats (scalar)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int pair = blockIdx.y;
+    const float* Ab = a.A + (size_t)pair * a.strideA;
+    const float* Bb = a.B + (size_t)pair * a.strideB;
+    char* ws = a.ws + (size_t)pair * a.wsStride;
+    float* rowPartVal = reinterpret_cast<float*>(ws + a.oRowPartVal);
+    int* rowPartIdx = reinterpret_cast<int*>(ws + a.oRowPartIdx);
+    float* colPartVal = reinterpret_cast<float*>(ws + a.oColPartVal);
+    int* colPartIdx = reinterpret_cast<int*>(ws + a.oColPartIdx);
+    const int nwg = a.tilesA * a.tilesB;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap; column tile fastest so an XCD's L2 keeps one A panel hot
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    __syncthreads();
-    if (t < 128 && j0 + t < a.nB) {
-        float bv = xval[t];
-        int bi = xidx[t];
-        take_min_idx(bv, bi, xval[128 + t], xidx[128 + t]);
-        colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
-        colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
-    }
+    const int tb = bid % a.tilesB, ta = bid / a.tilesB;
+    const int i0 = ta * BM, j0 = tb * BN;
+    // staging roles: VEC: row t>>5 (+8 per round), cells 4*(t&31)..+3; scalar: row t>>7 (+2 per round), cell t&127
+    const int srow = VEC ? t >> 5 : t >> 7, scol = VEC ? (t & 31) * 4 : t & 127;
+    int ca = i0 + scol, cb = j0 + scol;
+    if (VEC) { if (ca + 4 > a.ldA) ca = a.ldA - 4; if (cb + 4 > a.ldB) cb = a.ldB - 4; }
+    else     { if (ca >= a.nA) ca = a.nA - 1;     if (cb >= a.nB) cb = a.nB - 1; }
+    const float* asrc = Ab + (size_t)srow * a.ldA + ca;
+    const float* bsrc = Bb + (size_t)srow * a.ldB + cb;
+    f32x4 va[VEC ? NV : 1], vb[VEC ? NV : 1];
+    float ra[VEC ? 1 : NS], rb[VEC ? 1 : NS];
+    auto load_a = [&](int k0, int j) {
+        if (VEC) va[j] = *reinterpret_cast<const f32x4*>(asrc + (size_t)(k0 + 8 * j) * a.ldA);
+        else     ra[j] = asrc[(size_t)(k0 + 2 * j) * a.ldA];
+    };
+    auto load_b = [&](int k0, int j) {
+        if (VEC) vb[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * a.ldB);
+        else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * a.ldB];
+    };
+    auto store_a = [&](int buf, int j) {
+        if (VEC) *reinterpret_cast<f32x4*>(&As[buf][srow + 8 * j][scol]) = va[j];
+        else     As[buf][srow + 2 * j][scol] = ra[j];
+    };
+    auto store_b = [&](int buf, int j) {
+        if (VEC) *reinterpret_cast<f32x4*>(&Bs[buf][srow + 8 * j][scol]) = vb[j];
+        else     Bs[buf][srow + 2 * j][scol] = rb[j];
+    };
+    constexpr int NL = VEC ? NV : NS;
+    const int nk = a.C / BK;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { load_a(0, j); load_b(0, j); }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { store_a(0, j); store_b(0, j); }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { load_a(BK, j); load_b(BK, j); }
     __syncthreads();
 
-    // ---- row arg-max over this tile's columns ----
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float bv = -INFINITY;
-            int bj = 0x7fffffff;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int gj = j0 + (wn * 2 + j) * 32 + lcol;
-                const float v = acc[i][j][r];
-                if (gj < a.nB && v > bv) { bv = v; bj = gj; }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const float* arow = &As[0][lrow][wm * 64 + lcol];
+    const float* brow = &Bs[0][lrow][wn * 64 + lcol];
+    for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1;
+        const float* ap = arow + cur * (BK * BM);
+        const float* bp = brow + cur * (BK * BN);
+        const int k2 = (s + 2 < nk ? s + 2 : nk - 1) * BK;      // past the end: re-load the last step (never consumed)
+        float af[2][4][2], bf[2][4][2];
+        auto read_chunk = [&](int c, int slot) {
 #pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) {
-                const float ov = __shfl_xor(bv, m, 64);
-                const int oj = __shfl_xor(bj, m, 64);
-                take_min_idx(bv, bj, ov, oj);
+            for (int e = 0; e < 4; ++e) {
+                const int kk = c * 4 + e;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[slot][e][i] = ap[2 * kk * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[slot][e][j] = bp[2 * kk * BN + j * 32];
             }
-            if (lcol == 0) {
-                const int li = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                xval[wn * 128 + li] = bv;
-                xidx[wn * 128 + li] = bj;
+        };
+        read_chunk(0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c + 1 < 4) read_chunk(c + 1, (c + 1) & 1);
+            // the registers hold K step s+1: stored into the other buffer and re-loaded with step s+2 right behind the store
+            if (c == 0) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) store_a(cur ^ 1, j);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) load_a(k2, j);
+            } else if (c == 1) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) store_b(cur ^ 1, j);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) load_b(k2, j);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    __syncthreads();
-    if (t < 128 && i0 + t < a.nA) {
-        float bv = xval[t];
-        int bj = xidx[t];
-        take_min_idx(bv, bj, xval[128 + t], xidx[128 + t]);
-        rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
-        rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
+        __syncthreads();
     }
+    if (a.maskB) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gj = j0 + (wn * 2 + j) * 32 + lcol;
+            const float mk = gj < a.nB ? a.maskB[(size_t)pair * a.strideMask + gj] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= mk;
+        }
+    }
+    mnn_tile_epilogue(acc, a, &As[0][0][0], reinterpret_cast<int*>(&Bs[0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx, colPartVal,
+                      colPartIdx);
 }
 
 __global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a) {
@@ -374,7 +524,13 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
     const bool vec = a.ldA % 4 == 0 && a.ldB % 4 == 0 && a.strideA % 4 == 0 && a.strideB % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(mnn_tile_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
+    const int form = fe ? atoi(fe) : 0;
+    const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);
+    if (kmajor) {
+        if (vec) hipLaunchKernelGGL(mnn_tile_kmajor_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(mnn_tile_kmajor_kernel<false>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    } else if (vec) hipLaunchKernelGGL(mnn_tile_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(mnn_tile_kernel<false>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(mnn_reduce_kernel, dim3((a.nA + a.nB + 255) / 256, batch), dim3(256), 0, st, a);

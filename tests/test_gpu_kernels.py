@@ -331,6 +331,33 @@ def test_mutual_nn_golden_and_random(dev):
         _mnn_check(dev, A, B, mask)
 
 
+def test_mutual_nn_kmajor_form_equals_the_transposed_image_form(dev, monkeypatch):
+    """Round 4: mnn_tile_kmajor_kernel (k-major LDS images, straight 16-byte staging, mask applied to the finished
+    accumulators) accumulates every score in the same k order and pairing as mnn_tile_kernel -> identical match lists on
+    ragged sizes, with and without a 0/1 column mask, with 16-byte rows (vector staging) and without (scalar staging), and
+    on a padded leading dimension whose padding columns hold NaNs (they may only pollute rows / columns the arg-max skips)."""
+    gen = torch.Generator().manual_seed(11)
+    for (C, nA, nB, ld_pad) in ((1024, 2107, 300, 0), (256, 533, 1201, 0), (1024, 13065, 1200, 3), (64, 130, 129, 0), (96, 1000, 260, 4)):
+        A = F.normalize(torch.relu(torch.randn(C, nA, generator=gen)), dim=0)
+        pick = torch.randint(nA, (nB,), generator=gen)
+        B = F.normalize(torch.relu(A[:, pick] + 0.3 * torch.randn(C, nB, generator=gen)), dim=0)
+        mask = (torch.rand(nB, generator=gen) > 0.3).float().to(dev)
+        Ad, Bd = A.to(dev), B.to(dev)
+        kw = {}
+        if ld_pad:                                                 # (C, ld) storage with ld = nA + pad, padding = NaN
+            ldA = nA + ld_pad
+            Ap = torch.full((C, ldA), float("nan"), device=dev)
+            Ap[:, :nA] = Ad
+            Ad, kw = Ap, dict(ldA=ldA, nA=nA)
+        res = {}
+        for form in ("0", "1"):
+            monkeypatch.setenv("RFX_MNN_FORM", form)
+            res[form] = [ops.mutual_nn(Ad, Bd, m, **kw) for m in (None, mask)]
+        for (a1, a2), (b1, b2) in zip(res["0"], res["1"]):
+            assert torch.equal(a1, b1) and torch.equal(a2, b2), (C, nA, nB, ld_pad)
+        assert len(res["0"][0][0]) > 10
+
+
 # ------------------------------------------------------------------ RANSAC
 
 
