@@ -100,6 +100,9 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
  * conv1x1_kmajor_kernel<TM, VEC> (Cin % 32 == 0; TM = 2 - bits 0-1, VEC = bit 4).  Bit 5 set = the geometry is served by
  * rfx_conv3x3_f32 below (the host mirrors call it then); rfx_conv2d_f32 itself always runs the implicit-GEMM kernel. */
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
+/* (round 4) bit 13 = the direct 3x3 / STRIDE 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0, TM = 2 - bit 0), served by
+ * rfx_conv3x3_s2_f32 below: ResNet-50 layer2.0 / layer3.0 conv2 (model/resnet50.py:75) and the first convolution of
+ * FeatureExtractor layer2 / layer3 (model/model.py:86-95). */
 
 /* 3x3 / stride 1 / pad 1 convolution, Cin >= 8 (a Cin that is not a multiple of 8 -- the 49-channel correlation volume in
  * front of the heads -- takes ceil(Cin/8) K steps, the packed weights carrying zero rows for the missing channels) (ResNet Bottleneck conv2 at stride 1, model/resnet50.py:75; the
@@ -110,6 +113,10 @@ int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, i
  *     mt < roundup(Cout,128)/128, s < ceil(Cin/8), h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout and for c >= Cin; 16-byte aligned. */
 int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
                     float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
+/* The same for stride 2 (pad 1, Cin % 8 == 0): out (N, Cout, (H-1)/2+1, (W-1)/2+1); wP as above.  Bit-identical to
+ * rfx_conv2d_f32 on the same geometry. */
+int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
+                       float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 
 /* Bottleneck tail (model/resnet50.py:71-79, forward :93-103: conv2 3x3 -> bn2 -> relu -> conv3 1x1 -> bn3 -> += residual
  * -> relu) as ONE kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual).  The workgroup that computed a

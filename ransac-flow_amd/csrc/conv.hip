@@ -374,6 +374,8 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
                               int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
 int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused);                                       // conv3x3.hip
+int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
+                          float* out, int N, int Cin, int H, int W, int Cout, int act, int tm, hipStream_t st);   // conv3x3.hip
 bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols);                          // conv3x3.hip
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
@@ -413,6 +415,15 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
         return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (!big && !rag && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) |
                (rag ? 4096 : 0);
     }
+    // bit 13 = the direct 3x3 / stride 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0; TM = 2 - bit 0); never inside a
+    // grouped launch (it has no grouped form: a recorded group keeps the implicit-GEMM kernel)
+    static const int s2_env = getenv("RFX_CONV_S2") ? atoi(getenv("RFX_CONV_S2")) : 1;
+    if (allow_direct && direct_env && s2_env && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Cin % 8 == 0 && Cin >= 8 &&
+        !rfx_group_recording()) {
+        const long long tiles = (long long)N * ((Hout + 7) / 8) * ((Wout + 15) / 16);
+        const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
+        return 8192 | (big ? 0 : 1);
+    }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
@@ -443,6 +454,18 @@ extern "C" int rfx_conv3x3_f32(const float* in, const float* wP, const float* sc
     const int tm = (kid & 32) ? ((kid & 3) ? 1 : 2) : (Cout > 64 ? 2 : 1);   // RFX_CONV_DIRECT=0 only changes the host's choice
     return rfx_conv3x3_direct_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, (Cout + 127) / 128 * 128, act,
                                      tm, pc, rfx_stream(stream));
+}
+
+// The direct stride-2 kernel with the packed weights of rfx_conv3x3_f32 (bit 13 of rfx_conv2d_kernel_id says when it applies).
+extern "C" int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float* scale, const float* shift,
+                                  const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int act,
+                                  void* stream) {
+    if (!in || !wP || !out || N <= 0 || Cin < 8 || Cin % 8 != 0 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 2, 1, Ho, Wo, true);
+    const int tm = (kid & 8192) ? ((kid & 1) ? 1 : 2) : (Cout > 64 ? 2 : 1);
+    return rfx_conv3x3_s2_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, act, tm, rfx_stream(stream));
 }
 
 extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,

@@ -399,6 +399,179 @@ static int c3_group_launch(const void* blob, const unsigned* gx, int n, hipStrea
     return rfx_group_launch_impl<C3Args>(conv3x3_direct_group_kernel<TM, PTC, FUSE>, 256, blob, gx, n, st);
 }
 
+
+// ======================================================================================================================
+// Round 4: the direct form for 3x3 / STRIDE 2 / pad 1 (ResNet-50 layer2.0 / layer3.0 conv2, model/resnet50.py:75; the first
+// convolution of FeatureExtractor layer2 / layer3, model/model.py:86-95) -- 10 % of the config-3 step on the implicit-GEMM
+// kernel at 95 TFLOP/s.  Same scheme as above: a workgroup owns an 8 x 16 patch of OUTPUT pixels of one image and stages the
+// raw 17 x 33 input patch of 8 channels per K step; the stride-2 taps of 16 consecutive output pixels would hit every second
+// LDS word (2-way bank conflicts), so a patch row is stored de-interleaved, [even columns 0..16 | odd columns at +20], 40 floats
+// per row: tap (kh, kw) of output pixel (r, x) is the word (2r + kh) * 40 + (kw & 1) * 20 + x + (kw >> 1) -- consecutive
+// pixels read consecutive words, and the two patch rows of a 32-lane half lie 80 words = 16 banks apart.  Weights: the same
+// packed images wP as the stride-1 kernel (rfx_api.h), same k order as conv.hip -> bit-identical results.  Images are tiled
+// one by one (the stacked-batch trick above needs stride 1).  Cin % 8 == 0.
+namespace s2 {
+constexpr int PT_R = 8, PT_C = 16, PRI = 2 * PT_R + 1, PCI = 2 * PT_C + 1, PH = 20, BS2 = 40, RH = 2;
+constexpr int NEL = CH * PRI * PCI;                  // 4488 input elements per K step
+constexpr int NB = (NEL + 255) / 256;                // 18 per thread (the last round is partial)
+}  // namespace s2
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
+    using namespace s2;
+    constexpr int TN = 2, BM = 64 * TM;
+    constexpr int AS_F = 2 * BM * KK, BS_F = CH * PRI * BS2;
+    __shared__ __attribute__((aligned(16))) float smem[AS_F + BS_F];
+    float (*As)[BM][KK] = reinterpret_cast<float (*)[BM][KK]>(smem);
+    float* bflat = smem + AS_F;                       // [CH][PRI][BS2]
+    __shared__ float s_scale[BM], s_shift[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+    const int tilesP = a.tilesH * a.tilesW;           // patches per image
+    const int nwg = a.tilesM * tilesP * a.N;
+    int bid = (int)blockIdx.x;
+    {   // XCD-aware bijective remap, m-tile fastest
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int m0 = (bid % a.tilesM) * BM;
+    int pt = bid / a.tilesM;
+    const int n = pt / tilesP;
+    pt -= n * tilesP;
+    const int oh0 = (pt / a.tilesW) * PT_R, ow0 = (pt % a.tilesW) * PT_C;
+    const size_t HW = (size_t)a.H * a.W, HWo = (size_t)Ho * Wo;
+    const float* inn = a.in + (size_t)n * a.Cin * HW;
+
+    if (t < BM) {
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
+    // ---- staging roles: weights exactly as in conv3x3_direct_body
+    constexpr int A_F4 = 2 * BM * KK / 4, NA = (A_F4 + 255) / 256;
+    constexpr int PLANE_B = 128 * KK * 4;
+    unsigned aoff[NA];
+    int alds[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int L = t + 256 * j;
+        if (L >= A_F4) L -= A_F4;
+        alds[j] = L;
+        aoff[j] = TM == 2 ? (unsigned)(L * 16) : (unsigned)((L / (A_F4 / 2)) * PLANE_B + (L % (A_F4 / 2)) * 16);
+    }
+    const size_t step_b = (size_t)2 * PLANE_B;
+    const int nsteps = a.Cin / CH;
+    const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * nsteps * step_b +
+                        (TM == 1 ? ((m0 >> 6) & 1) * (PLANE_B / 2) : 0);
+    // input patch: element idx = t + 256 u of [CH][PRI][PCI]
+    unsigned boffB[NB];
+    unsigned bokm = 0, realm = 0;
+    int blds[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int idx = t + 256 * u;
+        const bool real = idx < NEL;
+        const int ii = real ? idx : 0;
+        const int cl = ii / (PRI * PCI), rem = ii - cl * (PRI * PCI);
+        const int pr = rem / PCI, px = rem - pr * PCI;
+        const int gy = 2 * oh0 - 1 + pr, gx = 2 * ow0 - 1 + px;
+        const bool ok = real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        bokm |= ok ? (1u << u) : 0u;
+        realm |= real ? (1u << u) : 0u;
+        boffB[u] = ok ? ((unsigned)cl * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : 0u;
+        blds[u] = (cl * PRI + pr) * BS2 + (px & 1) * PH + (px >> 1);
+    }
+    f32x4 ra[NA];
+    float rb[NB];
+    constexpr int NLD = NB + NA;
+    constexpr int LPC = 3;
+    static_assert(LPC * 9 >= NLD, "all loads of a step are issued inside its 9 chunks");
+    auto load_one = [&](int id, const char* wstep, const char* base) {
+        if (id < NB) rb[id] = *reinterpret_cast<const float*>(base + boffB[id]);          // masked at store time
+        else if (id < NLD) ra[id - NB] = *reinterpret_cast<const f32x4*>(wstep + aoff[id - NB]);
+    };
+    auto store_lds = [&]() {
+        f32x4* a4 = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a4[alds[j]] = ra[j];
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (u + 1 < NB || ((realm >> u) & 1u)) bflat[blds[u]] = ((bokm >> u) & 1u) ? rb[u] : 0.0f;
+    };
+    // ---- per-lane B addresses of the 36 k-pairs of a step
+    const int pixb = (2 * (wn * TN * RH + lcol / PT_C)) * BS2 + lcol % PT_C;            // sub-tile j adds 2*RH rows of the patch
+    int baddr[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const int k = 2 * kk + lrow;
+        const int cl = k / 9, t9 = k - cl * 9;
+        const int kh = t9 / 3, kw = t9 - kh * 3;
+        baddr[kk] = pixb + cl * (PRI * BS2) + kh * BS2 + (kw & 1) * PH + (kw >> 1);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    {
+        const char* base = reinterpret_cast<const char*>(inn);
+#pragma unroll
+        for (int id = 0; id < NLD; ++id) load_one(id, wtile, base);
+    }
+    store_lds();
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int sn = s + 1 < nsteps ? s + 1 : s;
+        const char* wstep = wtile + (size_t)sn * step_b;
+        const char* base = reinterpret_cast<const char*>(inn + (size_t)sn * CH * HW);
+        f32x4 af[2][TM];
+        float bv[2][4 * TN];
+        auto read_chunk = [&](int q, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[slot][i] = *reinterpret_cast<const f32x4*>(&As[lrow][(wm * TM + i) * 32 + lcol][q * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[baddr[q * 4 + e] + j * 2 * RH * BS2];
+        };
+        read_chunk(0, 0);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < 9) read_chunk(q + 1, cur ^ 1);
+#pragma unroll
+            for (int i = 0; i < LPC; ++i) load_one(q * LPC + i, wstep, base);            // tile s+1, in the MFMA shadow
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][TN * e + j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        store_lds();
+        __syncthreads();
+    }
+    size_t pix_off[TN];
+    bool pix_ok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int oh = oh0 + (wn * TN + j) * RH + lcol / PT_C, ow = ow0 + lcol % PT_C;
+        pix_ok[j] = oh < Ho && ow < Wo;
+        pix_off[j] = pix_ok[j] ? (size_t)n * a.Cout * HWo + (size_t)oh * Wo + ow : 0;
+    }
+    conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HWo, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+}
+
 }  // namespace
 
 // 256-pixel (16 x 16) patches for a layer whose output channels fit ONE 64-channel tile: only for launches that still fill the
@@ -484,6 +657,30 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
     if (patch_cols == 16) return rfx_conv3x3_wide_patch(N, H, W, Cout, 16) ? launch_direct<1, 16, false, 4>(a, st) : launch_direct<1, 16>(a, st);
     if (patch_cols == 8) return launch_direct<1, 8>(a, st);
     return launch_direct<1, 4>(a, st);
+}
+
+// 3x3 / stride 2 / pad 1, Cin % 8 == 0: the direct stride-2 kernel above.  tm = 2 -> 128 output channels per workgroup, 1 -> 64.
+int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
+                          float* out, int N, int Cin, int H, int W, int Cout, int act, int tm, hipStream_t st) {
+    C3Args a;
+    a.in = in; a.wT = wP; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = (Cout + 127) / 128 * 128;
+    a.wT3 = a.scale3 = a.shift3 = nullptr; a.Cexp = a.Mpad3 = a.act3 = 0; a.stagger = 0;
+#ifdef RFX_TRACE
+    a.trace = nullptr;
+#endif
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int BM = 64 * tm;
+    a.tilesM = (Cout + BM - 1) / BM;
+    a.tilesH = (Ho + s2::PT_R - 1) / s2::PT_R;
+    a.tilesW = (Wo + s2::PT_C - 1) / s2::PT_C;
+    const long long nwg = (long long)a.tilesM * a.tilesH * a.tilesW * N;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    if ((long long)Cin * H * W * 4 > 0xffffffffLL) return RFX_E_LIMIT;                    // 32-bit byte offsets inside one image
+    if (tm == 2) hipLaunchKernelGGL((conv3x3_s2_kernel<2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_s2_kernel<1>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
 }
 
 // Bottleneck tail in one kernel: out = act3(bn3(conv1x1(act2(bn2(conv3x3(in))))) + residual)  (model/resnet50.py:71-79,93-103).

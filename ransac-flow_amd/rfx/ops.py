@@ -154,7 +154,7 @@ class ConvPlan:
         self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
         self._wq = None
         self.wP = None
-        if self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.Cin >= 8:
+        if self.KH == 3 and self.KW == 3 and pad == 1 and self.Cin >= 8 and (stride == 1 or (stride == 2 and self.Cin % 8 == 0)):
             # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]; a Cin that is not a multiple of 8
             # (the 49-channel correlation volume) gets zero rows for the missing channels of its last K step
             Kp = (self.Cin + 7) // 8 * 72
@@ -202,10 +202,13 @@ class ConvPlan:
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
         lib = _lib.load()
-        direct = self.wP is not None and (lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, 3, 3, 1, 1, Ho, Wo) & 32) != 0
+        kid0 = lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo) if self.wP is not None else 0
         e0 = Profiler.begin(x)
-        if direct:
+        if kid0 & 32:
             _call("rfx_conv3x3_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
+                  _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
+        elif kid0 & 8192:
+            _call("rfx_conv3x3_s2_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
                   _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
         else:
             _call("rfx_conv2d_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale),

@@ -169,6 +169,36 @@ def test_direct_3x3_equals_implicit_gemm_bit_for_bit(dev, shape):
     assert torch.equal(direct, generic)
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 60, 80, 128), (16, 128, 120, 160, 256), (3, 8, 5, 3, 130), (2, 16, 1, 1, 8), (5, 24, 33, 47, 40),
+                                   (4, 64, 34, 66, 64), (9, 8, 2, 70, 32), (2, 256, 31, 53, 256), (70, 16, 17, 18, 192), (1, 8, 16, 32, 64)])
+def test_direct_3x3_stride2_equals_implicit_gemm_bit_for_bit(dev, shape):
+    """Round 4: rfx_conv3x3_s2_f32 (direct 3x3 / stride 2 / pad 1 kernel, input patch de-interleaved by column parity in LDS)
+    == rfx_conv2d_f32 on the same layer, bit for bit -- odd and even map sizes, maps smaller than a patch, ragged channel tiles,
+    both tile heights -- and the ConvPlan routes stride-2 layers to it."""
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(Cin * 5 + Cout + H)
+    x = torch.randn(N, Cin, H, W, generator=g).to(dev)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bnd = dict(weight=1 + 0.3 * torch.randn(Cout, generator=g), bias=0.2 * torch.randn(Cout, generator=g),
+               running_mean=0.2 * torch.randn(Cout, generator=g), running_var=0.5 + torch.rand(Cout, generator=g))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    r = torch.randn(N, Cout, Ho, Wo, generator=g).to(dev)
+    plan = ops.ConvPlan(w, bnd, 2, 1, ops.ACT_RELU, dev)
+    assert plan.wP is not None
+    from rfx import _lib
+    assert _lib.load().rfx_conv2d_kernel_id(N, Cin, Cout, 3, 3, 2, 1, Ho, Wo) & 8192
+    direct = plan(x, residual=r)
+    generic = torch.empty_like(direct)
+    ops._call("rfx_conv2d_f32", x.device, ops._p(x), ops._p(plan.wT), ops._p(plan.ktab), ops._p(plan.scale), ops._p(plan.shift),
+              ops._p(r), ops._p(generic), N, Cin, H, W, Cout, 3, 3, 2, 1, ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert direct.shape == (N, Cout, Ho, Wo)
+    assert torch.equal(direct, generic)
+    ref = F.relu(F.batch_norm(F.conv2d(x.cpu(), w, stride=2, padding=1), bnd["running_mean"], bnd["running_var"], bnd["weight"],
+                              bnd["bias"], False, 0.0, 1e-5) + r.cpu())
+    assert relerr(direct, ref) < 2e-5
+
+
 def test_pools_norm_head_resize(dev):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 5, 19, 26, generator=g)
