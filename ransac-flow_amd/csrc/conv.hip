@@ -420,9 +420,14 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     static const int s2_env = getenv("RFX_CONV_S2") ? atoi(getenv("RFX_CONV_S2")) : 1;
     if (allow_direct && direct_env && s2_env && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Cin % 8 == 0 && Cin >= 8 &&
         !rfx_group_recording()) {
-        const long long tiles = (long long)N * ((Hout + 7) / 8) * ((Wout + 15) / 16);
-        const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
-        return 8192 | (big ? 0 : 1);
+        // its 8 x 16 output patches tile every image on their own (no stacked-batch trick at stride 2): on maps that pad badly
+        // the implicit-GEMM kernel, which tiles the flattened pixel axis, wins.  Measured break-even (scripts/ubench/
+        // conv_s2_bench.py, profiles/r04_conv_s2_ab.json): +8..16 % at 100 % / 94 % useful pixels, +-0 at 88 %, -12 % at 74 %.
+        const long long th = (Hout + 7) / 8, tw = (Wout + 15) / 16;
+        if ((long long)Hout * Wout * 100 >= 90 * th * 8 * tw * 16) {
+            const bool big = Cout > 64 && (long long)N * th * tw * ((Cout + 127) / 128) >= 512;
+            return 8192 | (big ? 0 : 1);
+        }
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
@@ -464,7 +469,8 @@ extern "C" int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float*
     if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 2, 1, Ho, Wo, true);
-    const int tm = (kid & 8192) ? ((kid & 1) ? 1 : 2) : (Cout > 64 ? 2 : 1);
+    int tm = (kid & 8192) ? ((kid & 1) ? 1 : 2) : (Cout > 64 ? 2 : 1);
+    if (const char* e = getenv("RFX_S2_TM")) tm = atoi(e) == 1 ? 1 : (atoi(e) == 2 ? 2 : tm);      // experiments
     return rfx_conv3x3_s2_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, act, tm, rfx_stream(stream));
 }
 

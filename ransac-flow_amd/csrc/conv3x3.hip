@@ -466,40 +466,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
     const int nsteps = a.Cin / CH;
     const char* wtile = reinterpret_cast<const char*>(a.wT) + (size_t)(m0 / 128) * nsteps * step_b +
                         (TM == 1 ? ((m0 >> 6) & 1) * (PLANE_B / 2) : 0);
-    // input patch: element idx = t + 256 u of [CH][PRI][PCI]
-    unsigned boffB[NB];
-    unsigned bokm = 0, realm = 0;
-    int blds[NB];
+    // input patch = 136 rows (R = channel * 17 + patch row) x 33 columns per K step.  Thread t stages column px = t & 31 of
+    // the rows R = (t >> 5) + 8 u, u = 0..16 (8 x 17 = 136 exactly) and, for t < 136, column 32 of row t -- 18 loads, and NO
+    // per-element address tables: the LDS word of (R, px) is R * BS2 + f(px), affine in u (an immediate of the store), and the
+    // global offset is base + u * 8 W + cl(u) * (HW - 17 W) with cl(u) = c0(u) + [rg >= th(u)], c0 / th compile-time constants
+    // (the tables cost 36 registers and made the 128-channel instance spill).
+    const int rg = t >> 5, px = t & 31;
+    const int gx = 2 * ow0 - 1 + px, gy0 = 2 * oh0 - 1;
+    const bool xok = (unsigned)gx < (unsigned)a.W;
+    const unsigned D4 = (unsigned)(HW - (size_t)PRI * a.W) * 4u;            // channel step minus 17 rows, bytes
+    const unsigned W4 = (unsigned)a.W * 4u;
+    // base of row R = rg (channel 0, patch row rg): may point outside the image (masked by bokm); keep it inside the tensor
+    const unsigned base_b = (unsigned)((gy0 + rg) * a.W + gx) * 4u;
+    unsigned bokm = 0, clsel = 0;
+    constexpr int NBR = 17;
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const int idx = t + 256 * u;
-        const bool real = idx < NEL;
-        const int ii = real ? idx : 0;
-        const int cl = ii / (PRI * PCI), rem = ii - cl * (PRI * PCI);
-        const int pr = rem / PCI, px = rem - pr * PCI;
-        const int gy = 2 * oh0 - 1 + pr, gx = 2 * ow0 - 1 + px;
-        const bool ok = real && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        bokm |= ok ? (1u << u) : 0u;
-        realm |= real ? (1u << u) : 0u;
-        boffB[u] = ok ? ((unsigned)cl * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : 0u;
-        blds[u] = (cl * PRI + pr) * BS2 + (px & 1) * PH + (px >> 1);
+    for (int u = 0; u < NBR; ++u) {
+        const int R = rg + 8 * u, cl = R / PRI, pr = R - cl * PRI;
+        const int gy = gy0 + pr;
+        bokm |= (xok && (unsigned)gy < (unsigned)a.H) ? (1u << u) : 0u;
+        clsel |= (cl != (8 * u) / PRI) ? (1u << u) : 0u;                      // cl(u) = c0(u) + 1 for this thread's rg
     }
+    const int blds0 = rg * BS2 + (px & 1) * PH + (px >> 1);                  // + u * 8 * BS2
+    // column 32 (t < 136): row R = t
+    const bool has33 = t < CH * PRI;
+    const int cl33 = (has33 ? t : 0) / PRI, pr33 = (has33 ? t : 0) - cl33 * PRI;
+    const int gx33 = 2 * ow0 - 1 + 32, gy33 = gy0 + pr33;
+    const bool ok33 = has33 && (unsigned)gx33 < (unsigned)a.W && (unsigned)gy33 < (unsigned)a.H;
+    const unsigned boff33 = ok33 ? ((unsigned)cl33 * (unsigned)HW + (unsigned)(gy33 * a.W + gx33)) * 4u : 0u;
+    const int blds33 = (has33 ? t : 0) * BS2 + 16;                           // even column 32 -> slot 16
     f32x4 ra[NA];
     float rb[NB];
     constexpr int NLD = NB + NA;
     constexpr int LPC = 3;
+    static_assert(NB == NBR + 1, "17 regular rows + the 33rd column");
     static_assert(LPC * 9 >= NLD, "all loads of a step are issued inside its 9 chunks");
     auto load_one = [&](int id, const char* wstep, const char* base) {
-        if (id < NB) rb[id] = *reinterpret_cast<const float*>(base + boffB[id]);          // masked at store time
-        else if (id < NLD) ra[id - NB] = *reinterpret_cast<const f32x4*>(wstep + aoff[id - NB]);
+        if (id < NBR) {
+            const bool ok = (bokm >> id) & 1u;
+            // byte offset relative to the channel group's plane 0 (mod 2^32: a valid element's offset is non-negative and below
+            // 4 GB, checked at launch); invalid elements read offset 0 (masked at store time).  The empty asm keeps the compiler
+            // from hoisting the 17 step-invariant offsets out of the K loop into registers -- the point of having no tables.
+            unsigned bo = base_b;
+            asm volatile("" : "+v"(bo));
+            const unsigned off = bo + (unsigned)id * 8u * W4 + (unsigned)((8 * id) / PRI) * D4 + (((clsel >> id) & 1u) ? D4 : 0u);
+            rb[id] = *reinterpret_cast<const float*>(base + (ok ? off : 0u));
+        } else if (id == NBR) {
+            rb[id] = *reinterpret_cast<const float*>(base + boff33);
+        } else if (id < NLD) {
+            ra[id - NB] = *reinterpret_cast<const f32x4*>(wstep + aoff[id - NB]);
+        }
     };
     auto store_lds = [&]() {
         f32x4* a4 = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
         for (int j = 0; j < NA; ++j) a4[alds[j]] = ra[j];
 #pragma unroll
-        for (int u = 0; u < NB; ++u)
-            if (u + 1 < NB || ((realm >> u) & 1u)) bflat[blds[u]] = ((bokm >> u) & 1u) ? rb[u] : 0.0f;
+        for (int u = 0; u < NBR; ++u) bflat[blds0 + u * 8 * BS2] = ((bokm >> u) & 1u) ? rb[u] : 0.0f;
+        if (has33) bflat[blds33] = ok33 ? rb[NBR] : 0.0f;
     };
     // ---- per-lane B addresses of the 36 k-pairs of a step
     const int pixb = (2 * (wn * TN * RH + lcol / PT_C)) * BS2 + lcol % PT_C;            // sub-tile j adds 2*RH rows of the patch

@@ -47,6 +47,7 @@ def main():
         rows.append(row)
         print(json.dumps(row), flush=True)
     if len(sys.argv) > 1:
+        os.makedirs(os.path.dirname(os.path.abspath(sys.argv[1])), exist_ok=True)
         json.dump(rows, open(sys.argv[1], "w"), indent=1)
 
 

@@ -185,9 +185,11 @@ def test_direct_3x3_stride2_equals_implicit_gemm_bit_for_bit(dev, shape):
     r = torch.randn(N, Cout, Ho, Wo, generator=g).to(dev)
     plan = ops.ConvPlan(w, bnd, 2, 1, ops.ACT_RELU, dev)
     assert plan.wP is not None
-    from rfx import _lib
-    assert _lib.load().rfx_conv2d_kernel_id(N, Cin, Cout, 3, 3, 2, 1, Ho, Wo) & 8192
-    direct = plan(x, residual=r)
+    # the kernel itself, whatever the dispatcher would pick for this shape (it leaves badly padding maps to the implicit GEMM)
+    direct = torch.empty((N, Cout, Ho, Wo), device=dev)
+    ops._call("rfx_conv3x3_s2_f32", x.device, ops._p(x), ops._p(plan.wP), ops._p(plan.scale), ops._p(plan.shift), ops._p(r), ops._p(direct),
+              N, Cin, H, W, Cout, ops.ACT_RELU)
+    assert torch.equal(plan(x, residual=r), direct)                          # ConvPlan: either kernel, same bits
     generic = torch.empty_like(direct)
     ops._call("rfx_conv2d_f32", x.device, ops._p(x), ops._p(plan.wT), ops._p(plan.ktab), ops._p(plan.scale), ops._p(plan.shift),
               ops._p(r), ops._p(generic), N, Cin, H, W, Cout, 3, 3, 2, 1, ops.ACT_RELU)

@@ -482,7 +482,11 @@ def test_conv_dispatch_table_is_stable():
     assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 32 | 4096                   # Cin % 8 != 0 -> the direct kernel's ragged instance
     assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 32 | 1 | 4096                # ... a single image: 64-channel tiles fill the chip
     assert kid(64, 3, 64, 3, 1, 1, 480, 640) & 32 == 0                      # Cin < 8 (the stems' own kernels aside): implicit GEMM
-    assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 0                          # strided 3x3 -> implicit GEMM, 128x128 tile
+    assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 8192                       # 3x3 / stride 2 / pad 1, Cin % 8 == 0 -> direct stride-2 kernel <2>
+    assert kid(64, 64, 64, 3, 2, 1, 120, 160) == 8192 | 1                   # ... 64-channel tiles for Cout <= 64
+    assert kid(64, 128, 128, 3, 2, 1, 50, 66) & 8192 == 0                   # 50x66 pads to 56x80 (74 % useful): implicit GEMM
+    assert kid(64, 12, 128, 3, 2, 1, 60, 80) & 8192 == 0                    # Cin % 8 != 0 -> implicit GEMM
+    assert kid(64, 128, 128, 3, 2, 0, 59, 79) & 8192 == 0                   # pad != 1 -> implicit GEMM
     # 1x1: 16-byte pixel loads only for stride 1 and H*W % 4 == 0
     # ... on the k-major kernel of conv1x1.hip (bit 10) when Cin % 32 == 0 and the tile is not the 64x64 one
     assert kid(64, 64, 256, 1, 1, 0, 120, 160) == 1024 | 4 | 16
