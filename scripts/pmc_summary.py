@@ -7,7 +7,8 @@ Every directory holds ONE pass (--pmc <group> --kernel-trace: counters are colle
 FETCH_SIZE / WRITE_SIZE arrive in KB; bytes = x 1024.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports
 exactly half of the bytes of wide coalesced streaming reads (16 B / lane, global_load and buffer_load..lds alike) -> the
 `fetch_bytes_corrected` column doubles it for the kernels whose loads are 16-byte (listed in WIDE); dword readers and WRITE_SIZE
-stay raw ("uncalibrated").  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)."""
+stay raw ("uncalibrated").  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): rocprofv3 sums
+GRBM_GUI_ACTIVE over the 8 XCDs (checked against the kernel duration x 2.4 GHz)."""
 import argparse
 import collections
 import csv
@@ -64,14 +65,15 @@ def main():
             o["fetch_bytes_per_launch_corrected"] = o["fetch_size_bytes_per_launch_raw"] * (2.0 if wide else 1.0)
             o["fetch_correction"] = "x2 (16-byte/lane loads, gfx950 FETCH_SIZE counts them at half)" if wide else "none (dword loads: uncalibrated)"
         if "SQ_VALU_MFMA_BUSY_CYCLES_per_launch" in o and o.get("GRBM_GUI_ACTIVE_per_launch"):
-            o["mfma_busy"] = o["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (o["GRBM_GUI_ACTIVE_per_launch"] * 1024.0)
+            o["mfma_busy"] = o["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / (o["GRBM_GUI_ACTIVE_per_launch"] / 8.0 * 1024.0)
         if "SQ_LDS_BANK_CONFLICT_per_launch" in o and o.get("SQ_ACTIVE_INST_ANY_per_launch"):
             o["lds_conflict_over_active_inst"] = o["SQ_LDS_BANK_CONFLICT_per_launch"] / o["SQ_ACTIVE_INST_ANY_per_launch"]
         if dur[k][0]:
             o["launches"] = dur[k][0]
             o["avg_us"] = dur[k][1] / dur[k][0] / 1e3
         out[k] = o
-    top = dict(sorted(out.items(), key=lambda kv: -(kv[1].get("avg_us", 0) * kv[1].get("launches", 0)))[:a.top])
+    ranked = sorted(out.items(), key=lambda kv: -(kv[1].get("avg_us", 0) * kv[1].get("launches", 0)))
+    top = dict(ranked[:a.top] + [kv for kv in ranked[a.top:] if any(w in kv[0] for w in ("corr7", "mnn_", "ransac_", "stem"))])
     json.dump(dict(note=__doc__.split("\n\n")[1], command=a.cmd, passes=[os.path.basename(d.rstrip("/")) for d in a.dirs], kernels=top),
               open(a.out, "w"), indent=1)
     for k, o in list(top.items())[:10]:
