@@ -379,7 +379,7 @@ int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, 
 bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols);                          // conv3x3.hip
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
-                              hipStream_t st, int stride, int Hin, int Win, int Wo);    // conv1x1.hip
+                              hipStream_t st);                                          // conv1x1.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -432,8 +432,8 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
-    if (kmajor_env && one && (stride == 1 || stride == 2) && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4)
-        return 1024 | 4 | variant | ((stride == 1 && ((long long)Hout * Wout) % 4 == 0) ? 16 : 0);   // conv1x1.hip (stride 2: scalar pixel loads)
+    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4)
+        return 1024 | 4 | variant | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0);   // conv1x1.hip
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env > 0);  // off by default: since the branch-free epilogue the single-role kernel is as fast
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
@@ -500,8 +500,8 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     int kid = conv_kernel_id(N, Cin, Cout, KH, KW, stride, pad, a.Hout, a.Wout, false);
     if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
     if (kid & 1024)
-        return rfx_conv1x1_kmajor_launch(in, wT, scale, shift, residual, out, N, Cin, a.Hout * a.Wout, Cout, a.Mpad, act,
-                                         (kid & 3) ? 1 : 2, (kid & 16) != 0, st, stride, Hin, Win, a.Wout);
+        return rfx_conv1x1_kmajor_launch(in, wT, scale, shift, residual, out, N, Cin, Hin * Win, Cout, a.Mpad, act,
+                                         (kid & 3) ? 1 : 2, (kid & 16) != 0, st);
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;
     const bool vecb = (kid & 16) != 0;

@@ -31,9 +31,7 @@ namespace {
 
 struct C1Args {
     const float* in; const float* wT; const float* scale; const float* shift; const float* res; float* out;
-    int Cin, HW, Cout, act, Mpad;   // HW = OUTPUT plane size
-    int HWin, Win, Wo, stride;      // input plane size / width, output width, stride (1, or 2: the projection shortcuts of
-                                    // ResNet-50 layer2.0 / layer3.0, model/resnet50.py:139-143 -- scalar pixel loads only)
+    int Cin, HW, Cout, act, Mpad;
     long long P;   // N*HW
     int tilesM, tilesP;
     unsigned stagger;   // common.h: rfx_stagger
@@ -81,19 +79,15 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
         long long p = n0 + bcol;
         if (p >= a.P) p = a.P - (VEC ? 4 : 1);                               // columns past the end: any valid address
         const long long n = p / a.HW;
-        const int rem = (int)(p - n * a.HW);
-        // stride s: output pixel (oh, ow) reads input pixel (s*oh, s*ow) of an HWin plane (1x1, pad 0)
-        const size_t pin = a.stride == 1 ? (size_t)rem : (size_t)(rem / a.Wo) * a.stride * a.Win + (size_t)(rem % a.Wo) * a.stride;
-        bsrc = a.in + (size_t)n * a.Cin * a.HWin + pin + (size_t)brow * a.HWin;   // + (k0 + row) * HWin
+        bsrc = a.in + (size_t)n * a.Cin * HW + (size_t)(p - n * a.HW) + (size_t)brow * HW;   // + (k0 + row) * HW
     };
     f32x4 ra[NA];
     f32x4 rv[VEC ? NBV : 1];
     float rb[VEC ? 1 : NBS];
     auto load_a = [&](const float* wsrc, int k0, int j) { ra[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(k0 + A_RS * j) * a.Mpad); };
-    const size_t HWi = (size_t)a.HWin;
     auto load_b = [&](const float* bsrc, int k0, int j) {
-        if (VEC) rv[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * HWi);
-        else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * HWi];
+        if (VEC) rv[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * HW);
+        else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * HW];
     };
     auto store_a = [&](int buf, int j) { *reinterpret_cast<f32x4*>(&As[buf][ar + A_RS * j][ac * 4]) = ra[j]; };
     auto store_b = [&](int buf, int j) {
@@ -280,17 +274,15 @@ int launch_1x1(C1Args& a, hipStream_t st) {
 
 }  // namespace
 
-// Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 1x1, pad 0, stride 1 (or 2 with scalar loads),
+// Internal entry used by rfx_conv2d_f32 (conv.hip).  Preconditions checked by the caller: 1x1, stride 1, pad 0,
 // Cin % 32 == 0, Cin >= 64, N*HW >= 4; tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; vec: HW % 4 == 0 and `in` 16-byte
 // aligned (16-byte pixel loads).
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
-                              hipStream_t st, int stride, int Hin, int Win, int Wo) {
+                              hipStream_t st) {
     C1Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.Cin = Cin; a.HW = HW; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
-    a.stride = stride; a.HWin = stride == 1 ? HW : Hin * Win; a.Win = Win; a.Wo = Wo;
-    if (stride != 1) vec = false;
     a.P = (long long)N * HW;
     if (tm == 2) return vec ? launch_1x1<2, true>(a, st) : launch_1x1<2, false>(a, st);
     return vec ? launch_1x1<1, true>(a, st) : launch_1x1<1, false>(a, st);

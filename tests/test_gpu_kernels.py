@@ -109,9 +109,6 @@ CONV_CASES = [
     (8, 96, 34, 45, 72, 1, 1, 0, True, False, 1),     # k-major 1x1 <1, false>: three K steps, ragged channel tile
     (9, 32, 30, 40, 64, 1, 1, 0, False, True, 0),     # k-major 1x1 <1, true>: ONE K step, ragged pixel tile
     (66, 128, 16, 20, 130, 1, 1, 0, True, True, 1),   # k-major 1x1 <2, true>: ragged channel + pixel tiles
-    (16, 256, 60, 80, 512, 1, 2, 0, True, False, 0),  # k-major 1x1 <2, false> at stride 2 (ResNet projection shortcut)
-    (5, 64, 33, 47, 96, 1, 2, 0, True, True, 1),      # ... odd map, ragged tiles, residual at the OUTPUT resolution
-    (3, 128, 1, 7, 64, 1, 2, 0, False, False, 0),     # ... one-row map
 ]
 
 
