@@ -465,7 +465,24 @@ def kernel_name(kid):
     return "conv2d_mfma_kernel<%s, %s, %s, %s>" % ({0: "2, 2", 1: "1, 2", 2: "1, 1"}[kid & 3], tf(kid & 4), tf(kid & 8), tf(kid & 16))
 
 
-def rooflines(prof, elapsed, rank):
+def pmc_traffic(kernel, cfg):
+    """HBM-side bytes per launch of ``kernel`` from the committed PMC summary of the SAME bench command (separate rocprofv3 --pmc
+    passes: FETCH_SIZE and WRITE_SIZE cannot share a pass and rocprofv3 cannot wrap the process that is being timed), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 16-byte/lane reads at half: doubled; WRITE_SIZE raw).  None when
+    the summary or the kernel is missing."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_summary_config%s.json" % cfg)
+    try:
+        ks = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    norm = lambda t: t.replace(" ", "")
+    for name, o in ks.items():
+        if norm(name).startswith(norm(kernel)) and "fetch_bytes_per_launch_corrected" in o and "write_size_bytes_per_launch_raw" in o:
+            return o["fetch_bytes_per_launch_corrected"] + o["write_size_bytes_per_launch_raw"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def rooflines(prof, elapsed, rank, cfg="3"):
     by = {}
     for (v, f, e0, e1, _, nb) in prof.conv:
         g = by.setdefault(v, [0, 0.0, 0.0, 0.0])
@@ -493,6 +510,13 @@ def rooflines(prof, elapsed, rank):
             "time_share": round(t / elapsed, 3), "all_conv_tflops": round(tot_f / tot_t / 1e12, 2), "conv_time_share": round(tot_t / elapsed, 3),
             "conv_kernels": {("%d" % k): {"launches": g[0], "tflops": round(g[1] / g[2] / 1e12, 1), "time_share": round(g[2] / elapsed, 3)}
                              for k, g in sorted(by.items())}}
+    tr, src = pmc_traffic(roof["kernel"], cfg)
+    if tr is not None:
+        roof["traffic"] = round(tr)
+        roof["traffic_unit"] = "bytes per launch"
+        roof["traffic_note"] = ("FETCH_SIZE (x2: gfx950 counts 16-byte/lane reads at half) + WRITE_SIZE of this kernel, averaged per launch over "
+                                "separate rocprofv3 --pmc passes of this bench command (%s): static evidence, not this process; "
+                                "algorithmic bytes per launch (input + output + weights once) = %d" % (src, round(b / n)))
     corr = None
     if prof.corr:
         cb = sum(x[0] for x in prof.corr) / len(prof.corr)
@@ -501,6 +525,10 @@ def rooflines(prof, elapsed, rank):
                 "frac": round(cb / cd / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": cb, "launches": len(prof.corr),
                 "avg_launch_us": round(cd * 1e6, 2),
                 "traffic_note": "PMC per-launch traffic of this kernel: profiles/ (static, separate --pmc passes)"}
+        trc, srcc = pmc_traffic("corr7_dma_kernel", "qs" if cfg == "qs" else cfg)
+        if trc is not None and cfg == "qs":
+            corr["traffic"] = round(trc)
+            corr["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE per launch, separate --pmc passes of this command (%s)" % srcc
     if getattr(prof, "corr_bidir", None):
         # both directions of a pair in ONE launch (evaluation semantics): `achieved` is priced on the bytes that launch must
         # move at minimum -- (2C + 2*49)*4 per pixel: x and y read once, two volumes written -- NOT on twice SURVEY 8d's
@@ -621,7 +649,7 @@ def main():
             nbh = out[:, col["nbh"]]
             line["config"]["homographies_per_pair_last_step"] = {"mean": round(float(nbh.mean()), 2), "min": int(nbh.min()), "max": int(nbh.max())}
             line["config"]["homographies_per_s"] = round(float(nbh.sum()) * args.steps / elapsed, 1)
-        roof, corr = rooflines(prof, profiled_elapsed, rank)
+        roof, corr = rooflines(prof, profiled_elapsed, rank, args.config)
         if unprofiled is not None:
             roof["note"] = ("value / ms_per_step: HIP-graph trunk, no profiler (%.2f ms per pair); this roofline: a second pass of %d steps "
                             "with the per-launch events (eager launches, %.2f ms per pair)" % (unprofiled / args.steps * 1e3, args.steps,
@@ -640,11 +668,11 @@ def main():
             stepq, metaq, extraq = build_workload(aq, dev, rank, world)
             torch.manual_seed(123)
             eq, outq, profq = timed_loop(stepq, aq, None, sync, ops.Profiler)
-            rq, cq = rooflines(profq, eq, rank)
+            rq, cq = rooflines(profq, eq, rank, "qs")
             extras["quick_start"] = {"value": round(B * aq.steps / eq, 3), "unit": "pairs/s", "ms_per_step": round(eq / aq.steps * 1e3, 2),
                                      "steps": aq.steps, "warmup": aq.warmup, "workload": metaq["workload"],
                                      "aligned_ok_last_step": int((outq[:, 9] == 0).sum().item()),
-                                     "roofline": {k: rq[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops", "conv_time_share")},
+                                     "roofline": {k: rq[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops", "conv_time_share", "traffic")},
                                      "roofline_corr": cq}
             log("quick_start leg done: %.1f pairs/s" % extras["quick_start"]["value"])
         # ---- CPU legs: bounded oracle baseline, then the parity sweeps over pairs of the timed batches ----
