@@ -192,6 +192,19 @@ def _install_stubs():
     sys.modules["scipy.misc"] = sm
     scipy.misc = sm
     sys.modules.setdefault("segEval", types.ModuleType("segEval"))
+    # evaluation/evalKITTI/evaluation.py:24 imports skimage.measure (label: 8-connectivity in 2-D) -- not installed: scipy's labelling
+    if "skimage" not in sys.modules:
+        try:
+            import skimage  # noqa: F401
+        except ImportError:
+            from scipy import ndimage
+            sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.measure")
+            skm.label = lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0]
+            sk.measure = skm
+            sys.modules["skimage"], sys.modules["skimage.measure"] = sk, skm
+    if not hasattr(torch.cuda, "_rfx_long_stub"):
+        torch.cuda.LongTensor = torch.LongTensor          # evaluation/evalKITTI/evaluation.py:217 (indexRoll, unused afterwards)
+        torch.cuda._rfx_long_stub = True
 
 
 def load():

@@ -198,9 +198,17 @@ namespace r50 {
 constexpr int TH = 4, TW = 16;
 constexpr int CR = 2 * TH + 1, CC = 2 * TW + 1;    // 9 x 33 conv outputs
 constexpr int PR = 2 * CR + 5, PCW = 2 * CC + 5;   // 23 x 71 input patch
-constexpr int PHALF = 36, PST = 2 * PHALF;         // de-interleaved row: 36 even + 36 odd columns
-constexpr int CST = CC + 1;                        // 34
-constexpr int NPX = CR * CC, NSUB = (NPX + 31) / 32;   // 297 -> 10 sub-tiles
+constexpr int PHALF = 36, PST = 2 * PHALF + 2;     // de-interleaved row: 36 even + 36 odd columns (+2: the 9 lanes of the column
+                                                   // sub-tile below sit 2*PST = 148 words apart = 20 banks: all distinct but one pair)
+// conv-output tile in LDS, rows de-interleaved by column parity as well ([17 even | 17 odd at +17], row stride 40): the
+// pooling pass reads columns 2*ow + j of 16 consecutive pooled outputs as CONSECUTIVE words, and the four pooled rows of a
+// wavefront lie 2*CST = 80 words = 16 banks apart -> every bank is hit exactly twice by the 64 lanes (the minimum).
+constexpr int CHALF = 17, CST = 40;
+// MFMA sub-tiles are ROW-ALIGNED (round 4): sub-tile s < 9 = conv row s, columns 0..31 (32 consecutive LDS words per tap: no
+// bank conflict); sub-tile 9 = column 32 of the nine rows (9 live lanes).  The old numbering p = s*32 + lcol over the 9 x 33
+// map made most sub-tiles straddle two rows that land 2*PST = 16 banks apart on overlapping banks: 2-way conflicts on the B
+// reads -- 19 % of the kernel's instructions in round 3's counters (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_ANY).
+constexpr int NSUB = CR + 1;                       // 9 x 33 outputs -> 9 row sub-tiles + 1 column sub-tile
 constexpr int KKS = 74;                            // 148 / 2
 constexpr int MCH = 32;
 __host__ __device__ constexpr int koff(int k) {    // patch offset of tap k = c*49 + kh*7 + kw
@@ -215,7 +223,7 @@ struct Stem7Args {
 
 __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, const unsigned bx) {
     constexpr int TH = r50::TH, TW = r50::TW, CR = r50::CR, CC = r50::CC, PR = r50::PR, PCW = r50::PCW, PHALF = r50::PHALF,
-                  PST = r50::PST, CST = r50::CST, NPX = r50::NPX, NSUB = r50::NSUB, KKS = r50::KKS, MCH = r50::MCH;
+                  PST = r50::PST, CST = r50::CST, CHALF = r50::CHALF, NSUB = r50::NSUB, KKS = r50::KKS, MCH = r50::MCH;
     using r50::koff;
     __shared__ float P[3][PR][PST];
     __shared__ float C[MCH][CR][CST];
@@ -278,10 +286,8 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
     // ---- conv on the MFMA, BN + ReLU -> LDS
     const float* pf = &P[0][0][0];
     for (int s = wave; s < NSUB; s += 4) {
-        const int p = s * 32 + lcol;
-        const bool pv = p < NPX;
-        const int pc = pv ? p : 0;
-        const int py = pc / CC, px = pc - py * CC;
+        const bool pv = s < CR || lcol < CR;
+        const int py = s < CR ? s : (lcol < CR ? lcol : 0), px = s < CR ? lcol : CC - 1;
         const int pbase = 2 * py * PST + px;
         f32x16 acc;
 #pragma unroll
@@ -298,7 +304,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             for (int r = 0; r < 16; ++r) {
                 float v = fmaf(acc[r], sc[r], sh[r]);
                 v = v > 0.0f ? v : 0.0f;
-                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][px] = v;
+                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][(px & 1) * CHALF + (px >> 1)] = v;
             }
         }
     }
@@ -318,7 +324,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             for (int j = 0; j < 3; ++j) {
                 const int gx = cx0 + 2 * owl + j;
                 const bool ok = (unsigned)gy < (unsigned)a.Hc && (unsigned)gx < (unsigned)a.Wc;
-                const float v = C[ch][2 * ohl + i][2 * owl + j];
+                const float v = C[ch][2 * ohl + i][(j & 1) * CHALF + owl + (j >> 1)];     // column 2*owl + j
                 m = ok ? umaxf(m, v) : m;
             }
         }

@@ -113,6 +113,16 @@ def install_misc_shims():
         sys.modules["scipy.misc"] = sm
         scipy.misc = sm
     sys.modules.setdefault("segEval", types.ModuleType("segEval"))
+    try:
+        import skimage.measure  # noqa: F401
+    except ImportError:
+        # evaluation/evalKITTI/evaluation.py:24,85-100: measure.label(binary, background=0) = 8-connected components in 2-D
+        import numpy as np
+        from scipy import ndimage
+        sk, skm = types.ModuleType("skimage"), types.ModuleType("skimage.measure")
+        skm.label = lambda m, background=0: ndimage.label(m, structure=np.ones((3, 3), dtype=np.int32))[0]
+        sk.measure = skm
+        sys.modules["skimage"], sys.modules["skimage.measure"] = sk, skm
 
 
 def patch_functional():

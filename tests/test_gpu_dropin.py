@@ -245,7 +245,7 @@ def _reference_tree():
     return ref_loader
 
 
-def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16):
+def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16, tail=()):
     """One unchanged reference script, same command line twice: on the MI355X drop-ins (dropin/run_reference_script.py) and as
     the reference itself on this box's host cores (oracle/run_ref_script.py); the k-th RANSAC call of both runs draws from the
     CPU generator seeded with seed + k.  Returns the two output prefixes."""
@@ -256,7 +256,7 @@ def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16):
     outs = {}
     for side in ("gpu", "cpu"):
         out = str(tmp_path / ("out_" + side)) + ("/" if out_flag == "--outdir" else "")
-        if out_flag == "--outdir":
+        if out_flag == "--outdir" and not os.path.isdir(out):
             os.makedirs(out)
         env = dict(os.environ, MPLBACKEND="Agg", RFX_TRUNK_WEIGHTS=str(trunk), RFX_REFERENCE_ROOT=rl.REF_ROOT)
         if side == "gpu":
@@ -265,7 +265,7 @@ def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16):
         else:
             env["RFX_CPU_THREADS"] = str(cpu_threads)
             cmd = [sys.executable, os.path.join(ROOT, "oracle", "run_ref_script.py"), rel_script, "--rfx-ransac-seed", str(seed)]
-        r = subprocess.run(cmd + args + [out_flag, out], capture_output=True, text=True, timeout=900, env=env)
+        r = subprocess.run(cmd + args + [out_flag, out] + list(tail), capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, "%s run of %s failed:\n%s" % (side, rel_script, r.stderr[-3000:])
         outs[side] = out
     return outs["gpu"], outs["cpu"]
@@ -334,3 +334,43 @@ def test_unchanged_evalhpatch_script_on_a_synthetic_stream_vs_the_reference_cpu_
     # a scene whose cached match list differs by a float32 near-tie draws other samples (nMatch enters torch.randint) and may
     # stop at another homography count: tests/test_gpu_parity_sweep.py counts and bounds those; here at most one scene may
     assert same_nb >= 4 and exact >= 4, (same_nb, exact)
+
+
+def test_unchanged_evalkitti_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):
+    """evaluation/evalKITTI/evaluation.py:164-345 ITSELF, unmodified -- the two-resolution driver with its own get_info /
+    PredFlowMask / remove_small_cc (skimage's label through a scipy stand-in) -- over a synthetic KITTI-shaped stream (3 pairs of
+    96x312 images named like the dataset, %06d_10.png / _11.png): device drop-ins vs the reference on the host CPU.  Compares
+    what the script saves per pair (:338-345): the homography count (in the file names), Homograpy_*, Finetune_D2_* (the
+    half-resolution /8 flow), Finetune_* (/8 flow) and Finetune_Mask_* (matchability)."""
+    sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+           "netMatch": weights.net_matchability_sd(3, last_std=3.0)}
+    ck = tmp_path / "ck.pth"
+    torch.save(sds, str(ck))
+    os.makedirs(str(tmp_path / "img"))
+    n_pairs = 3
+    for i in range(n_pairs):
+        Is, It = synth.make_pair(96, 312, seed=12 + i, homography=True, amp=0.03)
+        Is.save(str(tmp_path / "img" / ("%06d_11.png" % i)))
+        It.save(str(tmp_path / "img" / ("%06d_10.png" % i)))
+    args = ["--coarseIter", "300", "--nbScale", "3", "--coarseSize", "160", "--fineSize", "128", "--cc_th", "0.002", "--maskRegionTh", "0.01",
+            "--imageNet", "--resumePth", str(ck), "--endIndex", str(n_pairs)]
+    tail = ["Kitti", "--testImg", str(tmp_path / "img") + "/"]
+    os.makedirs(str(tmp_path / "out_gpu"))
+    os.makedirs(str(tmp_path / "out_cpu"))
+    g, c = _run_both("evaluation/evalKITTI/evaluation.py", args, tmp_path, 31, "--outDir", tail=tail)
+    exact = 0
+    for i in range(n_pairs):
+        fg, fc = (sorted(f for f in os.listdir(d) if f.split("_")[-2] == str(i) or f.startswith("BG_%d_" % i)) for d in (g, c))
+        assert len(fg) == 5 and len(fc) == 5, (fg, fc)                           # BG_, Finetune_, Finetune_D2_, Finetune_Mask_, Homograpy_
+        if fg != fc:
+            print("pair %d: %s vs %s" % (i, fg, fc))
+            continue
+        ok = True
+        for f in fg:
+            a, b = np.load(os.path.join(g, f)), np.load(os.path.join(c, f))
+            d = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if a.dtype != bool else float((a != b).mean())
+            tol = 1e-5 if f.startswith("Homograpy") else (1e-3 if not f.startswith("BG") else 0.0)
+            print("pair %d %-22s max |d| %.2e" % (i, f, d))
+            ok = ok and d <= tol
+        exact += 1 if ok else 0
+    assert exact >= n_pairs - 1, exact
