@@ -339,7 +339,8 @@ def test_unchanged_evalhpatch_script_on_a_synthetic_stream_vs_the_reference_cpu_
 def test_unchanged_evalkitti_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):
     """evaluation/evalKITTI/evaluation.py:164-345 ITSELF, unmodified -- the two-resolution driver with its own get_info /
     PredFlowMask / remove_small_cc (skimage's label through a scipy stand-in) -- over a synthetic KITTI-shaped stream (3 pairs of
-    96x312 images named like the dataset, %06d_10.png / _11.png): device drop-ins vs the reference on the host CPU.  Compares
+    188x620 images named like the dataset, %06d_10.png / _11.png; large enough that no round ends in the reference's own
+    TypeError on a handful of matches, utils/outil.py:162): device drop-ins vs the reference on the host CPU.  Compares
     what the script saves per pair (:338-345): the homography count (in the file names), Homograpy_*, Finetune_D2_* (the
     half-resolution /8 flow), Finetune_* (/8 flow) and Finetune_Mask_* (matchability)."""
     sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
@@ -349,10 +350,10 @@ def test_unchanged_evalkitti_script_on_a_synthetic_stream_vs_the_reference_cpu_r
     os.makedirs(str(tmp_path / "img"))
     n_pairs = 3
     for i in range(n_pairs):
-        Is, It = synth.make_pair(96, 312, seed=12 + i, homography=True, amp=0.03)
+        Is, It = synth.make_pair(188, 620, seed=12 + i, homography=True, amp=0.03)
         Is.save(str(tmp_path / "img" / ("%06d_11.png" % i)))
         It.save(str(tmp_path / "img" / ("%06d_10.png" % i)))
-    args = ["--coarseIter", "300", "--nbScale", "3", "--coarseSize", "160", "--fineSize", "128", "--cc_th", "0.002", "--maskRegionTh", "0.01",
+    args = ["--coarseIter", "2000", "--nbScale", "3", "--coarseSize", "320", "--fineSize", "256", "--cc_th", "0.002", "--maskRegionTh", "0.01",
             "--imageNet", "--resumePth", str(ck), "--endIndex", str(n_pairs)]
     tail = ["Kitti", "--testImg", str(tmp_path / "img") + "/"]
     os.makedirs(str(tmp_path / "out_gpu"))
