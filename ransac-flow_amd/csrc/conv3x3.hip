@@ -81,9 +81,19 @@ extern "C" long long* rfx_debug_trace_ptr();
 // intermediate never touches HBM, the expansion's launch, prologue and B-operand staging disappear, and its residual /
 // output traffic overlaps the MFMA-bound 3x3 main loops of the neighbouring workgroups.  k order and pairing of the
 // expansion are those of conv.hip: bit-identical to the two separate kernels.
-template <int TM, int PTC, bool FUSE, int TN = 2, bool RAG = false>
+// KCH > 0 (round 4): CHUNKED ACCUMULATION.  The fp32 MFMA adds a layer's K = 9 Cin products to ONE accumulator in k order; for
+// K = 2304 / 4608 (ResNet-50 layer3 conv2, model/resnet50.py:75; NetFlowCoarse / NetMatchability conv2, model/model.py:172) that
+// single chain carries 2.3x the round-off of the CPU reference's K-blocked sums (MKL / oneDNN register blocks of a few hundred
+// k; profiles/r04_feature_error_*.json, r04_summation_order_model.json) -- the reason the device's arg-max near-ties flip more
+// often than the reference's flip against itself.  With KCH the accumulators are added to a second set every KCH K steps
+// (KCH * 72 k) and restarted from zero: total = ((c1 + c2) + c3) + ..., the same blocked sum.  The 64 extra registers come from
+// the per-lane B-address table: baddr[kk] = pixb + (lrow ? c1[kk] : c0[kk]) with compile-time c0 / c1, i.e. ONE v_mad per
+// k-pair (lrow * (c1 - c0) + pixb) and c0 as the immediate offset of the ds_read -- 36 VALU per K step instead of 36 registers.
+// Dispatch: plain (non-fused) 128-channel instances on layers with K >= 2048 (rfx_conv3x3_chunked).
+template <int TM, int PTC, bool FUSE, int TN = 2, bool RAG = false, int KCH = 0>
 __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsigned bx) {
     using G = Patch<PTC, TN>;
+    static_assert(KCH == 0 || (!FUSE && !RAG && TN == 2), "chunked accumulation: plain instances only");
     static_assert(TN == 2 || (TN == 4 && TM == 1 && PTC == 16), "the 256-pixel patch is built for 64-channel tiles, 16 x 16");
     constexpr int NPX = 64 * TN;                     // output pixels of the workgroup
     constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
@@ -195,14 +205,18 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 
     // ---- per-lane B addresses of the 36 k-pairs of a step (identical for every step) ----
     const int pixb = (wn * TN * RH + lcol / PT_C) * BS + lcol % PT_C;   // sub-tile j adds RH rows = RH*BS
-    int baddr[KK];
+    // patch offset of tap k = c*9 + kh*3 + kw (compile-time for a constant k)
+    auto koff = [](int k) constexpr { return (k / 9) * (PR * BS) + ((k % 9) / 3) * BS + (k % 9) % 3; };
+    int baddr[KCH ? 1 : KK];
+    if constexpr (KCH == 0) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        const int k = 2 * kk + lrow;
-        const int cl = k / 9, t9 = k - cl * 9;
-        const int kh = t9 / 3, kw = t9 - kh * 3;
-        baddr[kk] = pixb + cl * (PR * BS) + kh * BS + kw;
+        for (int kk = 0; kk < KK; ++kk) baddr[kk] = pixb + (lrow ? koff(2 * kk + 1) : koff(2 * kk));
     }
+    int pixb_cur = pixb;               // KCH: laundered once per K step so that the 36 step-invariant indices are NOT hoisted
+    auto b_index = [&](int kk) {       // KCH: recomputed per use (one v_mad); else the table
+        if constexpr (KCH == 0) return baddr[kk];
+        else return pixb_cur + koff(2 * kk) + lrow * (koff(2 * kk + 1) - koff(2 * kk));
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -212,6 +226,15 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    f32x16 tot[KCH ? TM : 1][KCH ? TN : 1];
+    if constexpr (KCH > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
+    }
     load_global(0, ragged && nsteps == 1);
     store_lds(ragged && nsteps == 1);
     __syncthreads();
@@ -225,6 +248,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
         f32x4 af[2][TM];
         float bv[2][4 * TN];
+        if constexpr (KCH > 0) { pixb_cur = pixb; asm volatile("" : "+v"(pixb_cur)); }
         auto read_chunk = [&](int q, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -232,7 +256,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[baddr[q * 4 + e] + j * RH * BS];
+                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[b_index(q * 4 + e) + j * RH * BS];
             }
         };
         read_chunk(0, 0);
@@ -253,6 +277,16 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][TN * e + j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (KCH > 0) {
+            if ((s + 1) % KCH == 0 || s + 1 == nsteps) {      // wave-uniform: close the chunk
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
+            }
         }
         if (RFX_C3_DBG != 4) __syncthreads();   // everyone is done reading the tile
         if (RFX_C3_DBG != 1 && RFX_C3_DBG != 3 && RFX_C3_DBG != 4)
@@ -293,7 +327,10 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
         for (int j = 0; j < TN; ++j) pixel_of(wn * TN + j, pix_off[j], pix_ok[j]);
         const bool full = m0 + BM <= a.Cout;
-        conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+        if constexpr (KCH > 0)
+            conv_epilogue<TM, TN, (TM > 1)>(tot, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
+        else
+            conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, full);
     } else {
         // ---- mid tile -> LDS: T2[channel][pixel], pixel = MFMA column numbering (wn*2 + j)*32 + lcol
         float* T2 = smem;   // every wavefront is past the last barrier of the main loop: As / Bs are free
@@ -381,22 +418,22 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 }
 
 // (three workgroups per CU for the 64-channel fused tail -- 168 VGPRs, 4 spilled -- measured -2.4 %: profiles/r03_fused_tail_3wgs.jsonl)
-template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false>
+template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false, int KCH = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Args a) {
-    conv3x3_direct_body<TM, PTC, FUSE, TN, RAG>(a, blockIdx.x);
+    conv3x3_direct_body<TM, PTC, FUSE, TN, RAG, KCH>(a, blockIdx.x);
 }
 
 // grouped form (group.h): blockIdx.y = problem, the same body on that problem's argument block
-template <int TM, int PTC, bool FUSE = false>
+template <int TM, int PTC, bool FUSE = false, int KCH = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_direct_group_kernel(RfxGroupArgs<C3Args> g) {
     const unsigned y = blockIdx.y;
     if (blockIdx.x >= g.gx[y]) return;
-    conv3x3_direct_body<TM, PTC, FUSE>(g.p[y], blockIdx.x);
+    conv3x3_direct_body<TM, PTC, FUSE, 2, false, KCH>(g.p[y], blockIdx.x);
 }
 
-template <int TM, int PTC, bool FUSE>
+template <int TM, int PTC, bool FUSE, int KCH = 0>
 static int c3_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
-    return rfx_group_launch_impl<C3Args>(conv3x3_direct_group_kernel<TM, PTC, FUSE>, 256, blob, gx, n, st);
+    return rfx_group_launch_impl<C3Args>(conv3x3_direct_group_kernel<TM, PTC, FUSE, KCH>, 256, blob, gx, n, st);
 }
 
 
@@ -598,6 +635,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
 
 }  // namespace
 
+// Chunked accumulation (KCH above) for the layers whose single fma chain is longest: K = 9 Cin >= 2048.  RFX_C3_CHUNK=0 turns it off
+// (A/B runs: the chain form is what rfx_conv2d_f32's implicit-GEMM kernel computes).
+bool rfx_conv3x3_chunked(int Cin) {
+    static const int en = getenv("RFX_C3_CHUNK") ? atoi(getenv("RFX_C3_CHUNK")) : 1;
+    return en && Cin % CH == 0 && Cin * 9 >= 2048;
+}
+
 // 256-pixel (16 x 16) patches for a layer whose output channels fit ONE 64-channel tile: only for launches that still fill the
 // chip two generations deep with the larger patch, never inside a grouped launch (latency-bound: more, smaller workgroups win).
 bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols) {
@@ -627,7 +671,7 @@ int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused) {
     return best;
 }
 
-template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false>
+template <int TM, int PTC, bool FUSE = false, int TN = 2, bool RAG = false, int KCH = 0>
 static int launch_direct(C3Args& a, hipStream_t st) {
     using G = Patch<PTC, TN>;
     const long long rows = (long long)a.N * (a.H + 1);
@@ -642,9 +686,9 @@ static int launch_direct(C3Args& a, hipStream_t st) {
                                          : rfx_stagger_env("RFX_C3_STAGGER", "RFX_C3_STAGGER_MODE");
     a.stagger = (rfx_group_recording() || nwg < 1024) ? 0u : stagger;
     if constexpr (TN == 2 && !RAG) {
-        if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE>, &a, sizeof(a), (unsigned)nwg);
+        if (rfx_group_recording()) return rfx_group_record(&c3_group_launch<TM, PTC, FUSE, KCH>, &a, sizeof(a), (unsigned)nwg);
     }
-    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE, TN, RAG>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_direct_kernel<TM, PTC, FUSE, TN, RAG, KCH>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -674,9 +718,19 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
         return launch_direct<1, 4, false, 2, true>(a, st);
     }
     if (tm == 2) {
+        if (rfx_conv3x3_chunked(Cin)) {      // K >= 2048: chunks of 4 K steps (288 k)
+            if (patch_cols == 16) return launch_direct<2, 16, false, 2, false, 4>(a, st);
+            if (patch_cols == 8) return launch_direct<2, 8, false, 2, false, 4>(a, st);
+            return launch_direct<2, 4, false, 2, false, 4>(a, st);
+        }
         if (patch_cols == 16) return launch_direct<2, 16>(a, st);
         if (patch_cols == 8) return launch_direct<2, 8>(a, st);
         return launch_direct<2, 4>(a, st);
+    }
+    if (rfx_conv3x3_chunked(Cin)) {          // a single image / tiny batch runs the long-K layers on 64-channel tiles: same chunks
+        if (patch_cols == 16) return launch_direct<1, 16, false, 2, false, 4>(a, st);
+        if (patch_cols == 8) return launch_direct<1, 8, false, 2, false, 4>(a, st);
+        return launch_direct<1, 4, false, 2, false, 4>(a, st);
     }
     if (patch_cols == 16) return rfx_conv3x3_wide_patch(N, H, W, Cout, 16) ? launch_direct<1, 16, false, 4>(a, st) : launch_direct<1, 16>(a, st);
     if (patch_cols == 8) return launch_direct<1, 8>(a, st);

@@ -201,6 +201,42 @@ def test_direct_3x3_stride2_equals_implicit_gemm_bit_for_bit(dev, shape):
     assert relerr(direct, ref) < 2e-5
 
 
+def test_chunked_accumulation_of_the_long_k_layers(dev):
+    """Round 4: the direct 3x3 kernel closes a chunk every 4 K steps (288 k) on layers with K = 9 Cin >= 2048 and adds the chunk
+    sums to a running total -- the K-blocked sum of the CPU reference's GEMM / oneDNN kernels instead of ONE fma chain over 2304 /
+    4608 products (DESIGN 4).  (1) the 64- and the 128-channel-tile instances (picked by launch size) agree bit for bit;
+    (2) against float64 the chunked result carries clearly less round-off than the chain form, which rfx_conv2d_f32's
+    implicit-GEMM kernel computes for the same layer; (3) layers below the threshold are untouched (bit-identical to the chain)."""
+    g = torch.Generator().manual_seed(3)
+    for Cin, Cout in ((256, 256), (512, 256)):
+        x = torch.relu(torch.randn(48, Cin, 30, 40, generator=g)).to(dev)                  # post-ReLU activations, as in the trunk
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+        plan = ops.ConvPlan(w, None, 1, 1, ops.ACT_NONE, dev)
+        big = plan(x)                                                                      # 48 images: 128-channel tiles
+        small = plan(x[:2].contiguous())                                                   # 2 images: 64-channel tiles
+        from rfx import _lib
+        lib = _lib.load()
+        assert lib.rfx_conv2d_kernel_id(48, Cin, Cout, 3, 3, 1, 1, 30, 40) & 3 == 0 and lib.rfx_conv2d_kernel_id(2, Cin, Cout, 3, 3, 1, 1, 30, 40) & 3 == 1
+        assert torch.equal(big[:2], small)
+        chain = torch.empty_like(small)
+        ops._call("rfx_conv2d_f32", dev, ops._p(x[:2].contiguous()), ops._p(plan.wT), ops._p(plan.ktab), ops._p(None), ops._p(None), ops._p(None),
+                  ops._p(chain), 2, Cin, 30, 40, Cout, 3, 3, 1, 1, ops.ACT_NONE)
+        ref = F.conv2d(x[:2].cpu().double(), w.double(), padding=1)
+        e_chunk = float(((small.cpu().double() - ref) ** 2).mean().sqrt())
+        e_chain = float(((chain.cpu().double() - ref) ** 2).mean().sqrt())
+        print("K = %d: rms error vs float64: chunked %.3e, chain %.3e (ratio %.2f)" % (9 * Cin, e_chunk, e_chain, e_chain / e_chunk))
+        assert e_chunk < 0.7 * e_chain
+        assert not torch.equal(small, chain)
+    # K = 1152 < 2048: the chain form, bit-identical to the implicit GEMM (also covered by test_direct_3x3_equals_implicit_gemm_bit_for_bit)
+    x = torch.randn(2, 128, 30, 40, generator=g).to(dev)
+    w = torch.randn(128, 128, 3, 3, generator=g) / (128 * 9) ** 0.5
+    plan = ops.ConvPlan(w, None, 1, 1, ops.ACT_NONE, dev)
+    chain = torch.empty((2, 128, 30, 40), device=dev)
+    ops._call("rfx_conv2d_f32", dev, ops._p(x), ops._p(plan.wT), ops._p(plan.ktab), ops._p(None), ops._p(None), ops._p(None), ops._p(chain),
+              2, 128, 30, 40, 128, 3, 3, 1, 1, ops.ACT_NONE)
+    assert torch.equal(plan(x), chain)
+
+
 def test_pools_norm_head_resize(dev):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 5, 19, 26, generator=g)
