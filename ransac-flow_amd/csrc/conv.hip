@@ -379,7 +379,8 @@ int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, 
 bool rfx_conv3x3_wide_patch(int N, int H, int W, int Cout, int patch_cols);                          // conv3x3.hip
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
-                              hipStream_t st);                                          // conv1x1.hip
+                              hipStream_t st, bool chunked);                            // conv1x1.hip
+bool rfx_conv3x3_chunked(int Cin);                                                                   // conv3x3.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -412,8 +413,10 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
         const long long tiles = (((long long)N * (Hout + 1) + pr - 1) / pr) * ((Wout + pc - 1) / pc);
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
         const bool rag = Cin % 8 != 0;
-        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (!big && !rag && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) |
-               (rag ? 4096 : 0);
+        // bit 14 = chunked accumulation (K >= 2048: conv3x3_direct_kernel<TM, PT_C, false, 2, false, 4>; never on the 256-pixel patches)
+        const bool chk = !rag && rfx_conv3x3_chunked(Cin);
+        return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) |
+               (!big && !rag && !chk && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) | (rag ? 4096 : 0) | (chk ? 16384 : 0);
     }
     // bit 13 = the direct 3x3 / stride 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0; TM = 2 - bit 0); never inside a
     // grouped launch (it has no grouped form: a recorded group keeps the implicit-GEMM kernel)
@@ -432,8 +435,12 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
-    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4)
-        return 1024 | 4 | variant | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0);   // conv1x1.hip
+    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4) {
+        // bit 14 = chunked accumulation (K >= 1024: conv1x1_kmajor_kernel<1, VEC, 8>, 64-channel tiles); RFX_C1_CHUNK=0: off
+        static const int c1chunk = getenv("RFX_C1_CHUNK") ? atoi(getenv("RFX_C1_CHUNK")) : 1;
+        const bool chk = c1chunk && Cin >= 1024;
+        return 1024 | 4 | (chk ? 1 : variant) | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0) | (chk ? 16384 : 0);   // conv1x1.hip
+    }
     const int env = conv_ws_env();
     const bool ws = variant == 2 ? false : (env > 0);  // off by default: since the branch-free epilogue the single-role kernel is as fast
     static const int vec_env = getenv("RFX_CONV_VECB") ? atoi(getenv("RFX_CONV_VECB")) : 1;
@@ -501,7 +508,7 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
     if (reinterpret_cast<uintptr_t>(in) & 15) kid &= ~16;  // VECB needs 16-B aligned planes
     if (kid & 1024)
         return rfx_conv1x1_kmajor_launch(in, wT, scale, shift, residual, out, N, Cin, Hin * Win, Cout, a.Mpad, act,
-                                         (kid & 3) ? 1 : 2, (kid & 16) != 0, st);
+                                         (kid & 3) ? 1 : 2, (kid & 16) != 0, st, (kid & 16384) != 0);
     const int variant = kid & 3;
     const bool ws = (kid & 8) != 0;
     const bool vecb = (kid & 16) != 0;

@@ -43,8 +43,12 @@ struct C1Args {
 // workgroup (load step 0, wait, store, load step 1, barrier: ~2 us of a 25 us lifetime when K = 256) overlaps the MFMAs and
 // the epilogue of the tile before.  A tile's folded-BN vectors live in a double-buffered LDS pair (a fast wavefront may be
 // one tile ahead of a slow one's epilogue).
-template <int TM, bool VEC>
+// KCH > 0 (round 4): chunked accumulation as in conv3x3.hip -- every KCH K steps (KCH * 32 k) the accumulators are added to a
+// second set and restarted: the K-blocked sum of the CPU reference's GEMM instead of one fma chain over K = 1024 products (ResNet-50
+// layer3 conv1, model/resnet50.py:71).  64-channel tiles only (TM = 1: 174 + 32 registers; the 128-channel instance has none to spare).
+template <int TM, bool VEC, int KCH = 0>
 __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsigned bx, const unsigned gsz) {
+    static_assert(KCH == 0 || TM == 1, "chunked accumulation: 64-channel tiles");
     constexpr int BM = 64 * TM, BN = 128, BK = 32;
     constexpr int A_C4 = BM / 4;                 // float4 per A row: 32 / 16
     constexpr int A_RS = 256 / A_C4;             // rows covered by one round of the 256 threads: 8 / 16
@@ -137,12 +141,16 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
         tile_sources(m0n, n0n, wsrc_n, bsrc_n);
 
         f32x16 acc[TM][2];
+        f32x16 tot[KCH ? TM : 1][KCH ? 2 : 1];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[i][j][r] = 0.0f;
+                    if constexpr (KCH > 0) tot[i][j][r] = 0.0f;
+                }
 
         for (int s = 0; s < nk; ++s, ++g) {
             const int cur = g & 1;
@@ -201,6 +209,16 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (KCH > 0) {
+                if ((s + 1) % KCH == 0 || s + 1 == nk) {      // wave-uniform: close the chunk
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
+                }
+            }
             if (RFX_C1_DBG != 4) __syncthreads();   // step s+1 is complete in the other buffer; everyone is done reading this one
         }
         put_scale((it + 1) & 1, m0n);             // the next tile's BN vectors (read after >= nk barriers)
@@ -225,6 +243,10 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
                 const long long n = pp / a.HW;
                 pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pp - n * a.HW);
             }
+            if constexpr (KCH > 0)
+                conv_epilogue<TM, 2, false>(tot, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off,
+                                            pix_ok, m0 + BM <= a.Cout);
+            else
             conv_epilogue<TM, 2, false>(acc, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off,
                                         pix_ok, m0 + BM <= a.Cout);
         }
@@ -232,25 +254,25 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
     }
 }
 
-template <int TM, bool VEC>
+template <int TM, bool VEC, int KCH = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_kernel(C1Args a) {
-    conv1x1_kmajor_body<TM, VEC>(a, blockIdx.x, gridDim.x);
+    conv1x1_kmajor_body<TM, VEC, KCH>(a, blockIdx.x, gridDim.x);
 }
 
 // grouped form (group.h): blockIdx.y = problem; a problem's persistent workgroups stride by that problem's own grid
-template <int TM, bool VEC>
+template <int TM, bool VEC, int KCH = 0>
 __global__ __launch_bounds__(256, 2) void conv1x1_kmajor_group_kernel(RfxGroupArgs<C1Args> g) {
     const unsigned y = blockIdx.y;
     if (blockIdx.x >= g.gx[y]) return;
-    conv1x1_kmajor_body<TM, VEC>(g.p[y], blockIdx.x, g.gx[y]);
+    conv1x1_kmajor_body<TM, VEC, KCH>(g.p[y], blockIdx.x, g.gx[y]);
 }
 
-template <int TM, bool VEC>
+template <int TM, bool VEC, int KCH = 0>
 static int c1_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
-    return rfx_group_launch_impl<C1Args>(conv1x1_kmajor_group_kernel<TM, VEC>, 256, blob, gx, n, st);
+    return rfx_group_launch_impl<C1Args>(conv1x1_kmajor_group_kernel<TM, VEC, KCH>, 256, blob, gx, n, st);
 }
 
-template <int TM, bool VEC>
+template <int TM, bool VEC, int KCH = 0>
 int launch_1x1(C1Args& a, hipStream_t st) {
     a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
     a.tilesP = (int)((a.P + 127) / 128);
@@ -266,8 +288,8 @@ int launch_1x1(C1Args& a, hipStream_t st) {
     const unsigned grid = (unsigned)(nwg < slots ? (nwg + 7) / 8 * 8 : slots);
     static const unsigned stagger = rfx_stagger_env("RFX_C1_STAGGER", "RFX_C1_STAGGER_MODE");
     a.stagger = (rfx_group_recording() || (int)grid < slots) ? 0u : stagger;      // only when every CU holds its two workgroups
-    if (rfx_group_recording()) return rfx_group_record(&c1_group_launch<TM, VEC>, &a, sizeof(a), grid);
-    hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC>), dim3(grid), dim3(256), 0, st, a);
+    if (rfx_group_recording()) return rfx_group_record(&c1_group_launch<TM, VEC, KCH>, &a, sizeof(a), grid);
+    hipLaunchKernelGGL((conv1x1_kmajor_kernel<TM, VEC, KCH>), dim3(grid), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }
@@ -279,11 +301,12 @@ int launch_1x1(C1Args& a, hipStream_t st) {
 // aligned (16-byte pixel loads).
 int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* scale, const float* shift, const float* residual,
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
-                              hipStream_t st) {
+                              hipStream_t st, bool chunked) {
     C1Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.Cin = Cin; a.HW = HW; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
     a.P = (long long)N * HW;
+    if (chunked) return vec ? launch_1x1<1, true, 8>(a, st) : launch_1x1<1, false, 8>(a, st);     // K >= 1024: chunks of 8 steps (256 k)
     if (tm == 2) return vec ? launch_1x1<2, true>(a, st) : launch_1x1<2, false>(a, st);
     return vec ? launch_1x1<1, true>(a, st) : launch_1x1<1, false>(a, st);
 }

@@ -227,6 +227,20 @@ def test_chunked_accumulation_of_the_long_k_layers(dev):
         print("K = %d: rms error vs float64: chunked %.3e, chain %.3e (ratio %.2f)" % (9 * Cin, e_chunk, e_chain, e_chain / e_chunk))
         assert e_chunk < 0.7 * e_chain
         assert not torch.equal(small, chain)
+    # the k-major 1x1 kernel at K = 1024 (layer3 conv1): chunks of 8 steps (256 k) on 64-channel tiles -- round-off on the level of
+    # the CPU's own float32 convolution (one chain over 1024 products carries ~2x that: scripts/summation_order_model.py)
+    x = torch.relu(torch.randn(2, 1024, 30, 40, generator=g)).to(dev)
+    w = torch.randn(256, 1024, 1, 1, generator=g) * (2.0 / 1024) ** 0.5
+    plan = ops.ConvPlan(w, None, 1, 0, ops.ACT_NONE, dev)
+    assert lib.rfx_conv2d_kernel_id(2, 1024, 256, 1, 1, 1, 0, 30, 40) & 16384
+    got = plan(x)
+    ref = F.conv2d(x.cpu().double(), w.double())
+    e_chunk = float(((got.cpu().double() - ref) ** 2).mean().sqrt())
+    print("1x1 K = 1024: rms error vs float64: chunked %.3e" % e_chunk)
+    x32 = x.cpu()
+    e_cpu = float(((F.conv2d(x32, w) - ref) ** 2).mean().sqrt())
+    print("              the CPU's own float32 conv: %.3e" % e_cpu)
+    assert e_chunk < 2.0 * e_cpu
     # K = 1152 < 2048: the chain form, bit-identical to the implicit GEMM (also covered by test_direct_3x3_equals_implicit_gemm_bit_for_bit)
     x = torch.randn(2, 128, 30, 40, generator=g).to(dev)
     w = torch.randn(128, 128, 3, 3, generator=g) / (128 * 9) ** 0.5

@@ -470,15 +470,17 @@ def test_conv_dispatch_table_is_stable():
     """Host-side dispatch of rfx_conv2d_f32 (no GPU needed): which kernel instance a layer geometry gets.  Bits: 0-1 tile
     variant, 2 = 1x1 specialisation, 3 = wave-specialised form (off by default), 4 = 16-byte pixel loads, 5 = direct 3x3
     kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4), 10 = k-major 1x1 kernel, 11 = 256-pixel patches of the
-    direct kernel (one 64-channel tile, large launch), 12 = its instance with a ragged last K step (Cin % 8 != 0)."""
+    direct kernel (one 64-channel tile, large launch), 12 = its instance with a ragged last K step (Cin % 8 != 0), 13 = direct
+    3x3 / stride 2 kernel, 14 = chunked accumulation (direct 3x3 with K = 9 Cin >= 2048; k-major 1x1 with K >= 1024, 64-channel tiles)."""
     lib = _lib.load()
     kid = lambda N, Cin, Cout, k, s, p, Ho, Wo: lib.rfx_conv2d_kernel_id(N, Cin, Cout, k, k, s, p, Ho, Wo)
     # direct 3x3 / stride 1: big layers -> 128-channel tiles, 8x16 patches
     assert kid(128, 128, 128, 3, 1, 1, 120, 160) == 32
     assert kid(128, 64, 64, 3, 1, 1, 240, 320) == 33 | 2048                # Cout = 64 -> 64-channel tiles, 256-pixel patches
     assert kid(2, 64, 64, 3, 1, 1, 240, 320) == 33                         # ... only on launches of >= 1024 such patches
-    assert kid(64, 256, 256, 3, 1, 1, 30, 40) == 32 | 64                    # 30x40 pads least with 16x8 patches
-    assert kid(64, 256, 256, 3, 1, 1, 25, 33) == 32 | 128                   # 25x33 -> 32x4 patches
+    assert kid(64, 256, 256, 3, 1, 1, 30, 40) == 32 | 64 | 16384            # 30x40 pads least with 16x8 patches; K = 2304: chunked sums
+    assert kid(64, 256, 256, 3, 1, 1, 25, 33) == 32 | 128 | 16384           # 25x33 -> 32x4 patches
+    assert kid(64, 224, 256, 3, 1, 1, 30, 40) == 32 | 64                    # K = 2016 < 2048: one chain
     assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 32 | 4096                   # Cin % 8 != 0 -> the direct kernel's ragged instance
     assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 32 | 1 | 4096                # ... a single image: 64-channel tiles fill the chip
     assert kid(64, 3, 64, 3, 1, 1, 480, 640) & 32 == 0                      # Cin < 8 (the stems' own kernels aside): implicit GEMM
@@ -493,6 +495,8 @@ def test_conv_dispatch_table_is_stable():
     assert kid(64, 256, 1024, 1, 1, 0, 34, 45) == 1024 | 4                  # 1530 pixels per plane: scalar pixel loads
     assert kid(64, 256, 512, 1, 2, 0, 60, 80) == 4                          # strided 1x1 -> generic kernel
     assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 1024 | 4 | 16 | 1         # Cout = 64 -> 64-wide channel tile
+    assert kid(64, 1024, 256, 1, 1, 0, 30, 40) == 1024 | 4 | 16 | 1 | 16384  # K = 1024 (layer3 conv1): chunked sums, 64-channel tiles
+    assert kid(64, 512, 128, 1, 1, 0, 60, 80) == 1024 | 4 | 16              # K = 512: one chain
     assert kid(64, 48, 256, 1, 1, 0, 120, 160) == 4 | 16                    # Cin % 32 != 0 -> generic kernel
     # tiny problems fall back to the 64x64 tile
     assert kid(1, 128, 49, 1, 1, 0, 12, 16) & 3 == 2
