@@ -435,10 +435,11 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
     const bool one = (KH == 1 && KW == 1 && pad == 0);
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
-    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && variant != 2 && (long long)N * Hout * Wout >= 4) {
-        // bit 14 = chunked accumulation (K >= 1024: conv1x1_kmajor_kernel<1, VEC, 8>, 64-channel tiles); RFX_C1_CHUNK=0: off
-        static const int c1chunk = getenv("RFX_C1_CHUNK") ? atoi(getenv("RFX_C1_CHUNK")) : 1;
-        const bool chk = c1chunk && Cin >= 1024;
+    // bit 14 = chunked accumulation (K >= 1024: conv1x1_kmajor_kernel<1, VEC, 8>, 64-channel tiles, at EVERY launch size -- a result
+    // must not depend on how many pairs share the launch); RFX_C1_CHUNK=0: off
+    static const int c1chunk = getenv("RFX_C1_CHUNK") ? atoi(getenv("RFX_C1_CHUNK")) : 1;
+    const bool chk = c1chunk && Cin >= 1024;
+    if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && (variant != 2 || chk) && (long long)N * Hout * Wout >= 4) {
         return 1024 | 4 | (chk ? 1 : variant) | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0) | (chk ? 16384 : 0);   // conv1x1.hip
     }
     const int env = conv_ws_env();

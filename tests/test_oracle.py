@@ -496,6 +496,7 @@ def test_conv_dispatch_table_is_stable():
     assert kid(64, 256, 512, 1, 2, 0, 60, 80) == 4                          # strided 1x1 -> generic kernel
     assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 1024 | 4 | 16 | 1         # Cout = 64 -> 64-wide channel tile
     assert kid(64, 1024, 256, 1, 1, 0, 30, 40) == 1024 | 4 | 16 | 1 | 16384  # K = 1024 (layer3 conv1): chunked sums, 64-channel tiles
+    assert kid(1, 1024, 256, 1, 1, 0, 15, 20) == 1024 | 4 | 16 | 1 | 16384  # ... at every launch size (results do not depend on the batch)
     assert kid(64, 512, 128, 1, 1, 0, 60, 80) == 1024 | 4 | 16              # K = 512: one chain
     assert kid(64, 48, 256, 1, 1, 0, 120, 160) == 4 | 16                    # Cin % 32 != 0 -> generic kernel
     # tiny problems fall back to the 64x64 tile
