@@ -24,6 +24,7 @@ struct MnnArgs {
     const float* A; const float* B; const float* maskB;
     int ldA, ldB, nA, nB, C;
     int tilesA, tilesB;
+    int kch;                                   // chunked accumulation: K steps (of 32 k) per chunk; 0 = one fma chain over C
     long long strideA, strideB, strideMask;   // element strides between the pairs of a batch (blockIdx.y)
     size_t wsStride;                           // byte stride of the per-pair workspace
     size_t oRowPartVal, oRowPartIdx, oColPartVal, oColPartIdx, oRowVal, oRowIdx, oColIdx;  // offsets inside it
@@ -33,6 +34,20 @@ struct MnnArgs {
 
 __device__ __forceinline__ void take_min_idx(float& bv, int& bi, float ov, int oi) {
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+// Chunked accumulation (round 4).  A score is a sum of C = 1024 non-negative products; as ONE fma chain its round-off is 2.8x that of
+// the CPU reference's sgemm (utils/outil.py:34, torch.mm: K-blocked register tiles whose partial sums are added), and it is THIS
+// error -- 8e-8 rms against 3e-8 from the trunk features -- that decides which float64 near-tie of the arg-max flips
+// (scripts/summation_order_model.py).  Every a.kch K steps (8 x 32 = 256 k) the accumulators are added to a running total
+// and restarted; with a.kch == 0 the single close after the last step leaves the chain sum unchanged.
+__device__ __forceinline__ void mnn_close_chunk(f32x16 (&tot)[2][2], f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
 }
 
 // Arg-max epilogue of a 128 x 128 score tile held in the accumulators of the 2 x 2 wavefronts (C/D layout: column = lcol,
@@ -224,13 +239,13 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = tot[i][j][r] = 0.0f;
 
     const int nk = (a.C + BK - 1) / BK;
     load_global(0);
@@ -268,12 +283,13 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][q][e], bf[j][q][e], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);   // ... and their consumers behind them
+        if (kt + 1 == nk || (a.kch && (kt + 1) % a.kch == 0)) mnn_close_chunk(tot, acc);
         if (kt + 1 < nk) store_lds(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
         cur ^= 1;
     }
     // all waves are past the last barrier: the staging buffers are free for the exchange
-    mnn_tile_epilogue(acc, a, &As[0][0][0][0], reinterpret_cast<int*>(&Bs[0][0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx,
+    mnn_tile_epilogue(tot, a, &As[0][0][0][0], reinterpret_cast<int*>(&Bs[0][0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx,
                       colPartVal, colPartIdx);
 }
 
@@ -347,13 +363,13 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
     for (int j = 0; j < NL; ++j) { load_a(BK, j); load_b(BK, j); }
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = tot[i][j][r] = 0.0f;
     const float* arow = &As[0][lrow][wm * 64 + lcol];
     const float* brow = &Bs[0][lrow][wn * 64 + lcol];
     for (int s = 0; s < nk; ++s) {
@@ -398,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][e][i], bf[c & 1][e][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (s + 1 == nk || (a.kch && (s + 1) % a.kch == 0)) mnn_close_chunk(tot, acc);
         __syncthreads();
     }
     if (a.maskB) {
@@ -408,10 +425,10 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] *= mk;
+                for (int r = 0; r < 16; ++r) tot[i][j][r] *= mk;
         }
     }
-    mnn_tile_epilogue(acc, a, &As[0][0][0], reinterpret_cast<int*>(&Bs[0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx, colPartVal,
+    mnn_tile_epilogue(tot, a, &As[0][0][0], reinterpret_cast<int*>(&Bs[0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx, colPartVal,
                       colPartIdx);
 }
 
@@ -524,6 +541,8 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
     const bool vec = a.ldA % 4 == 0 && a.ldB % 4 == 0 && a.strideA % 4 == 0 && a.strideB % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
+    const char* ce = getenv("RFX_MNN_CHUNK");                 // K steps per chunk (default 8 = 256 k); 0 = one chain (tests, A/B runs)
+    a.kch = ce ? (atoi(ce) > 0 ? atoi(ce) : 0) : 8;
     const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
     const int form = fe ? atoi(fe) : 0;
     const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);

@@ -440,6 +440,47 @@ def test_mutual_nn_kmajor_form_equals_the_transposed_image_form(dev, monkeypatch
         assert len(res["0"][0][0]) > 10
 
 
+def test_mutual_nn_scores_are_accumulated_in_chunks_of_256_products(dev, monkeypatch):
+    """Round 4: a score (utils/outil.py:34, featA.t() @ featB) is a sum of C = 1024 NON-NEGATIVE products (post-ReLU, L2-normalised
+    features).  One fma chain over them carries 2.8x the round-off of the CPU reference's K-blocked sgemm -- and that error, larger
+    than what the trunk features contribute, is what decides a float64 near-tie of the arg-max.  Both tile kernels close a chunk
+    every 8 K steps (256 k) and add it to a running total (RFX_MNN_CHUNK=0: the chain).  Read back: the per-row maxima the tile
+    kernel leaves in the workspace (csrc/mutual_nn.hip::layout), compared with the float64 maxima."""
+    gen = torch.Generator().manual_seed(5)
+    C, nA, nB = 1024, 3000, 1100
+    A = F.normalize(torch.relu(torch.randn(C, nA, generator=gen)), dim=0)
+    B = F.normalize(torch.relu(A[:, torch.randint(nA, (nB,), generator=gen)] + 0.5 * torch.randn(C, nB, generator=gen)), dim=0)
+    S64 = A.double().t() @ B.double()
+    ref = S64.max(dim=1).values
+    cpu = (A.t() @ B).max(dim=1).values.double()                  # the reference's own float32 product
+    from rfx import _lib
+    lib = _lib.load()
+    al = lambda x: (x + 255) & ~255
+    tA, tB = (nA + 127) // 128, (nB + 127) // 128
+    o_rowval = 2 * al(tB * nA * 4) + 2 * al(tA * nB * 4)
+    Ad, Bd = A.to(dev), B.to(dev)
+    err, lists = {}, {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("RFX_MNN_FORM", form)
+        for chunk in ("8", "0"):
+            monkeypatch.setenv("RFX_MNN_CHUNK", chunk)
+            ws = torch.zeros(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=dev)
+            i1 = torch.empty(nB, dtype=torch.int64, device=dev); i2 = torch.empty_like(i1)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            ops._call("rfx_mutual_nn_f32", dev, ops._p(Ad), nA, nA, ops._p(Bd), nB, nB, C, ops._p(None), ops._p(i1), ops._p(i2), ops._p(cnt),
+                      ops._p(ws))
+            rowval = ws[o_rowval:o_rowval + 4 * nA].view(torch.float32).cpu().double()
+            err[form, chunk] = float(((rowval - ref) ** 2).mean().sqrt())
+            n = int(cnt.item())
+            lists[form, chunk] = (i1[:n].cpu(), i2[:n].cpu())
+    e_cpu = float(((cpu - ref) ** 2).mean().sqrt())
+    print("row-maximum round-off vs float64: chunked %.3e, chain %.3e, the CPU's torch.mm %.3e" % (err["0", "8"], err["0", "0"], e_cpu))
+    assert err["0", "8"] == err["1", "8"] and err["0", "0"] == err["1", "0"]            # both kernel forms: the same sums
+    assert torch.equal(lists["0", "8"][0], lists["1", "8"][0]) and torch.equal(lists["0", "8"][1], lists["1", "8"][1])
+    assert err["0", "8"] < 0.6 * err["0", "0"]
+    assert err["0", "8"] < 1.5 * e_cpu
+
+
 # ------------------------------------------------------------------ RANSAC
 
 
