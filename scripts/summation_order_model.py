@@ -8,6 +8,10 @@ random-walk partial sum the chain's round-off grows like eps*K/sqrt(2), the bloc
 script measures both on synthetic layer-3-shaped dot products (post-ReLU activations x zero-mean weights, K = 256 ... 2304)
 against float64 and prints the ratio -- the factor the stage-wise measurement shows between "device" and "onednn"/"native".
 
+Second part (round 4, after the trunk was chunked and the flip counts did NOT follow): the same comparison for the mutual-NN score
+itself, a sum of 1024 non-negative products -- the chain's round-off there (8e-8) is 2.8x the CPU product's and twice what the
+trunk-feature error induces in a score, i.e. the score accumulation, not the trunk, decided most of the excess flips.
+
     python scripts/summation_order_model.py [--out profiles/r04_summation_order_model.json]
 """
 import argparse
@@ -50,7 +54,39 @@ def main():
             row["chain_over_blocked_%d" % kc] = round(row["rms_err_chain"] / row["rms_err_blocked_%d" % kc], 2)
         rows.append(row)
         print(row)
-    out = dict(note="sequential fp32 accumulation (the MFMA's k-ordered chain) vs K-blocked accumulation (MKL / oneDNN register blocks) "
+    # ---- the mutual-NN scores (utils/outil.py:34): sums of C = 1024 NON-NEGATIVE products of L2-normalised post-ReLU features.
+    # The partial sum of a chain grows monotonically towards the score, so every later rounding is relative to a value of the
+    # order of the score itself; with blocks of 256 each block sum is ~1/4 of it.  Compared: the chain, blocks of 32 ... 512,
+    # and the CPU's own float32 product (torch.mm -- what the reference executes); also the score error that a trunk-feature
+    # error of the measured size (profiles/r04_feature_error_*: 2.0e-8 ... 4.2e-8 per element) induces, for scale.
+    import torch
+    torch.manual_seed(0)
+    C, nA, nB = 1024, 1500, 600
+    A = torch.relu(torch.randn(C, nA)); A = A / A.norm(dim=0, keepdim=True)
+    B = torch.relu(A[:, torch.randint(nA, (nB,))] + 0.5 * torch.randn(C, nB)); B = B / B.norm(dim=0, keepdim=True)
+    ref = (A.double().t() @ B.double()).numpy()
+    mm = (A.t() @ B).numpy().astype(np.float64)
+    a64, b64 = A.numpy().astype(np.float64), B.numpy().astype(np.float64)
+
+    def scores(kc):
+        tot = np.zeros((nA, nB), np.float32); acc = np.zeros((nA, nB), np.float32)
+        for k in range(C):
+            acc = (acc.astype(np.float64) + np.outer(a64[k], b64[k])).astype(np.float32)
+            if kc and ((k + 1) % kc == 0 or k + 1 == C):
+                tot = (tot.astype(np.float64) + acc).astype(np.float32); acc[:] = 0
+        return (tot if kc else acc).astype(np.float64)
+    rms = lambda x, y: float(np.sqrt(((x - y) ** 2).mean()))
+    sc = dict(C=C, nA=nA, nB=nB, mean_score=float(ref.mean()), rms_err_torch_mm=rms(mm, ref))
+    for kc in (0, 512, 256, 128, 32):
+        x = scores(kc)
+        sc["rms_err_%s" % ("chain" if kc == 0 else "blocked_%d" % kc)] = rms(x, ref)
+        sc["rms_distance_to_torch_mm_%s" % ("chain" if kc == 0 else "blocked_%d" % kc)] = rms(x, mm)
+    for d in (2.0e-8, 2.8e-8, 4.2e-8):        # per-element feature error -> score error (both operands perturbed independently)
+        dA = torch.randn(C, nA, dtype=torch.float64) * d; dB = torch.randn(C, nB, dtype=torch.float64) * d
+        pert = ((A.double() + dA).t() @ (B.double() + dB)).numpy()
+        sc["rms_score_error_from_feature_error_%.1e" % d] = rms(pert, ref)
+    print(sc)
+    out = dict(scores=sc, note="sequential fp32 accumulation (the MFMA's k-ordered chain) vs K-blocked accumulation (MKL / oneDNN register blocks) "
                     "of the same exact products, error vs float64", samples=a.n, rows=rows)
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)
