@@ -102,7 +102,14 @@ int rfx_conv2d_tile_variant(int N, int Cout, int Hout, int Wout);
 int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout);
 /* (round 4) bit 13 = the direct 3x3 / STRIDE 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0, TM = 2 - bit 0), served by
  * rfx_conv3x3_s2_f32 below: ResNet-50 layer2.0 / layer3.0 conv2 (model/resnet50.py:75) and the first convolution of
- * FeatureExtractor layer2 / layer3 (model/model.py:86-95). */
+ * FeatureExtractor layer2 / layer3 (model/model.py:86-95).
+ * bit 14 = chunked accumulation: on layers whose K is long -- 3x3 / stride 1 with K = 9 Cin >= 2048 (conv3x3_direct_kernel<TM, PT_C,
+ * false, 2, false, 4>, a chunk = 4 K steps = 288 products) and 1x1 / stride 1 with K >= 1024 (conv1x1_kmajor_kernel<1, VEC, 8>, a chunk
+ * = 256 products, 64-channel tiles at every launch size) -- the accumulators are added to a running total at the end of every chunk and
+ * restarted, the K-blocked sum of the reference's CPU kernels (MKL sgemm / oneDNN) instead of ONE fma chain over K: 2.7-3.8x less
+ * round-off against float64 at K = 2304 / 4608.  On those 3x3 layers rfx_conv2d_f32 (its implicit-GEMM kernel: a chain) and
+ * rfx_conv3x3_f32 therefore differ in the last bits -- everywhere else they are bit-identical; the 1x1 layers with K >= 1024 run chunked
+ * through rfx_conv2d_f32 itself.  RFX_C3_CHUNK=0 / RFX_C1_CHUNK=0: chains (A/B runs). */
 
 /* 3x3 / stride 1 / pad 1 convolution, Cin >= 8 (a Cin that is not a multiple of 8 -- the 49-channel correlation volume in
  * front of the heads -- takes ceil(Cin/8) K steps, the packed weights carrying zero rows for the missing channels) (ResNet Bottleneck conv2 at stride 1, model/resnet50.py:75; the
@@ -297,7 +304,10 @@ int rfx_remove_small_cc_f32(const float* in, float* out, int N, int H, int W, fl
  * featA: (C, nA) and featB: (C, nB), column = one cell ("K-major": element (k,i) at k*ld+i).
  * maskB (optional, nB floats, 0/1) multiplies featB's columns (quick_start/coarseAlignFeatMatch.py:143).
  * Outputs: idx1/idx2 (int64, capacity min(nA,nB)) in ascending idx1 order, count (int32[1]).
- * The nA x nB score matrix is never written to memory.
+ * The nA x nB score matrix is never written to memory.  A score -- a sum of C non-negative products -- is accumulated in chunks of
+ * 256 products that are added to a running total (round 4; RFX_MNN_CHUNK=0: one fma chain): the chain's round-off over C = 1024 is
+ * 2.8x that of the reference's torch.mm and flipped float64 near-ties of the arg-max 1.5-2.3x as often as the reference flips them
+ * against itself; chunked, the rates are equal.
  * ws: rfx_mutual_nn_ws_bytes(nA, nB) bytes.
  * ------------------------------------------------------------------------------------------ */
 size_t rfx_mutual_nn_ws_bytes(int nA, int nB);
