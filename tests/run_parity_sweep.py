@@ -4,7 +4,7 @@
 written to gpurun_out/parity_sweep_<cfg>_64.json for profiles/.  The pytest version (tests/test_gpu_parity_sweep.py) runs a
 subset by default; this is the same code on every seed.
 
-    python tests/run_parity_sweep.py ev [n_pairs]
+    python tests/run_parity_sweep.py ev [n_pairs [first_seed]]
 """
 import json
 import os
@@ -22,10 +22,11 @@ def main():
     import parity_sweep
     cfg = sys.argv[1] if len(sys.argv) > 1 else "ev"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    seeds = list(range(n))
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # further seeds: more pairs for the flip statistics
+    seeds = list(range(first, first + n))
     d = tempfile.mkdtemp(prefix="rfx_parity_")
     parity_sweep.dump_gpu_pairs(cfg, seeds, 480, 640, torch.device("cuda:0"), d)
-    rec = os.path.join(ROOT, "gpurun_out", "parity_sweep_%s_%d.json" % (cfg, n))
+    rec = os.path.join(ROOT, "gpurun_out", "parity_sweep_%s_%d%s.json" % (cfg, n, "_from%d" % first if first else ""))
     os.makedirs(os.path.dirname(rec), exist_ok=True)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "parity_sweep.py"), "--config", cfg, "--dump", d, "--seeds"]
                          + [str(s) for s in seeds] + ["--records", rec], capture_output=True, text=True)
