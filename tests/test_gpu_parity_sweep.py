@@ -46,11 +46,11 @@ def test_end_to_end_parity_sweep_480x640(dev, cfg, tmp_path):
     # pairs whose lists differ: every differing match must be a float64 near-tie of the arg-max, their rate is bounded,
     # and the fine stage alone (device H through the oracle's fine stage) still meets the bound
     assert s["flips_all_near_ties"], s["max_tie_evidence"]
-    # measured rate (round 4, 64 pairs, device vs the reference, scores and long-K layers accumulated in chunks): 17 of 65 073
-    # matches (qs), 26 of 38 867 (ev) -- 2.6e-4 / 6.7e-4, the rate at which two CPU executions of the reference flip against each
-    # other on the same box (17 and 24).  The bound is twice that (+ 3 sigma of a Poisson count: the sweep here covers
-    # 12 / 6 pairs, and the host CPU -- hence the reference's own rounding -- differs between boxes).  Round 3's chain sums
-    # flipped 4.0e-4 / 1.4e-3 of the matches.
+    # measured rate (round 4, device vs the reference, scores and long-K layers accumulated in chunks): 17 of 65 073 matches (qs) and
+    # 26 of 38 867 (ev) on the 64 bench pairs -- 2.6e-4 / 6.7e-4 (2.0e-4 / 6.7e-4 over 128 / 160 pairs), 1.0-1.3x the rate at which two
+    # CPU executions of the reference flip against each other on the same box.  The bound is twice that (+ 3 sigma of a
+    # Poisson count: the sweep here covers 12 / 6 pairs, and the host CPU -- hence the reference's own rounding -- differs between
+    # boxes).  Round 3's chain sums flipped 4.0e-4 / 1.4e-3 of the matches.
     rate = 5.2e-4 if cfg == "qs" else 1.34e-3
     lam = rate * s["total_matches"]
     assert s["total_flipped_matches"] <= max(3, int(lam + 3 * lam ** 0.5)), (s["total_flipped_matches"], s["total_matches"])
