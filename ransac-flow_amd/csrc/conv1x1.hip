@@ -141,7 +141,7 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
         tile_sources(m0n, n0n, wsrc_n, bsrc_n);
 
         f32x16 acc[TM][2];
-        f32x16 tot[KCH ? TM : 1][KCH ? 2 : 1];
+        f32x16 tot[TM][2];                                    // only live in the KCH > 0 instances
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -243,12 +243,8 @@ __device__ __forceinline__ void conv1x1_kmajor_body(const C1Args& a, const unsig
                 const long long n = pp / a.HW;
                 pix_off[j] = (size_t)n * a.Cout * HW + (size_t)(pp - n * a.HW);
             }
-            if constexpr (KCH > 0)
-                conv_epilogue<TM, 2, false>(tot, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off,
-                                            pix_ok, m0 + BM <= a.Cout);
-            else
-            conv_epilogue<TM, 2, false>(acc, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off,
-                                        pix_ok, m0 + BM <= a.Cout);
+            conv_epilogue<TM, 2, false>(KCH > 0 ? tot : acc, s_scale[it & 1], s_shift[it & 1], a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow,
+                                        pix_off, pix_ok, m0 + BM <= a.Cout);
         }
         m0 = m0n; n0 = n0n; wsrc = wsrc_n; bsrc = bsrc_n;
     }
