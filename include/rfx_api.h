@@ -42,7 +42,7 @@ const char* rfx_version(void);
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
  * round kernels, two-direction correlation, grouped launches; round 4: rfx_draw_samples_i64 keyed by pair id).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 6
+#define RFX_ABI_VERSION 7
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -311,6 +311,13 @@ int rfx_remove_small_cc_f32(const float* in, float* out, int N, int H, int W, fl
  * ws: rfx_mutual_nn_ws_bytes(nA, nB) bytes.
  * ------------------------------------------------------------------------------------------ */
 size_t rfx_mutual_nn_ws_bytes(int nA, int nB);
+/* (ABI 7) K steps of 32 products per accumulation chunk of a score (process-wide; returns the previous value; 0 = one chain; the
+ * environment variable RFX_MNN_CHUNK overrides it).  The reference's score is torch.mm on the HOST (utils/outil.py:34): MKL's sgemm
+ * sums k as an fma chain inside blocks of KC products and adds the block sums to C -- KC = 192 on the GPU box's EPYC host, 384 on a
+ * Xeon (scripts/mm_blocking_probe.py).  With k_steps = KC / 32 the device's scores equal the host's torch.mm BIT FOR BIT on equal
+ * features, so that what is left of the arg-max near-tie flips comes from the trunk features alone.  The Python mirror probes the
+ * host's KC once (rfx/ops.py::host_sgemm_k_block) and sets it; default 8 (256 products). */
+int rfx_mutual_nn_set_chunk(int k_steps);
 int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
                       const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
                       void* stream);

@@ -15,6 +15,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -531,6 +532,13 @@ extern "C" size_t rfx_mutual_nn_ws_bytes(int nA, int nB) {
     return layout(nA, nB).total;
 }
 
+// K steps (of 32 products) per accumulation chunk of a score.  The host mirror sets it to the K blocking of the HOST's sgemm
+// (rfx/ops.py::host_sgemm_k_block: 192 products on the GPU box's EPYC, 384 on a Xeon -- MKL 2024.2), which makes a score
+// bit-identical to the reference's torch.mm on the same host; 8 (256 products) until it is told.
+static std::atomic<int> g_mnn_chunk{8};
+
+extern "C" int rfx_mutual_nn_set_chunk(int k_steps) { return g_mnn_chunk.exchange(k_steps > 0 ? k_steps : 0); }
+
 static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     const WsLayout L = layout(a.nA, a.nB);
     a.tilesA = (a.nA + BM - 1) / BM; a.tilesB = (a.nB + BN - 1) / BN;
@@ -541,8 +549,8 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
     const bool vec = a.ldA % 4 == 0 && a.ldB % 4 == 0 && a.strideA % 4 == 0 && a.strideB % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
-    const char* ce = getenv("RFX_MNN_CHUNK");                 // K steps per chunk (default 8 = 256 k); 0 = one chain (tests, A/B runs)
-    a.kch = ce ? (atoi(ce) > 0 ? atoi(ce) : 0) : 8;
+    const char* ce = getenv("RFX_MNN_CHUNK");                 // overrides rfx_mutual_nn_set_chunk (tests, A/B runs); 0 = one chain
+    a.kch = ce ? (atoi(ce) > 0 ? atoi(ce) : 0) : g_mnn_chunk.load(std::memory_order_relaxed);
     const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
     const int form = fe ? atoi(fe) : 0;
     const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);

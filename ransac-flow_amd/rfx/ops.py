@@ -24,6 +24,8 @@ def _call(name, dev, *args):
     current device is switched for the launch when the tensors do not live on it (ctypes bypasses torch's
     device guard)."""
     fn = getattr(_lib.load(), name)
+    if not _SCORES_CALIBRATED and name.startswith("rfx_mutual_nn"):
+        calibrate_score_sums()             # scores summed in the host sgemm's K blocks: bit-equal to the reference's torch.mm
     if dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             rc = fn(*args, _stream(dev))
@@ -581,6 +583,61 @@ def remove_small_cc(match, cc_th, match_th=0.99):
     _call("rfx_remove_small_cc_f32", _one_device(m3), _p(m3), _p(out), N, H, W, float(match_th), cc_max_area(H * W, float(cc_th)),
           _p(ws))
     return out[0] if squeeze else out
+
+
+_HOST_KC = None
+
+
+def host_sgemm_k_block(K=1024):
+    """How the HOST's float32 matrix product -- torch.mm, the reference's score product (utils/outil.py:34) -- sums over k: MKL's
+    sgemm accumulates an fma chain inside blocks of KC products and adds each block's sum to C; KC depends on the code path MKL
+    picks for the CPU (192 on the GPU box's EPYC 9575F, 384 on a Xeon; MKL 2024.2; scripts/mm_blocking_probe.py).  Returns the
+    KC whose float32 emulation reproduces torch.mm on a 384 x 256 post-ReLU, L2-normalised problem (MKL's small-matrix paths sum
+    differently: the probe has to be large enough to take the blocked path the real 8 531 ... 25 747 x 1 200 ... 8 250 products
+    take) bit for bit on all but <= 1e-4 of the elements (an edge kernel), or None when no candidate does -- another BLAS: the
+    device then keeps its default chunking.  Pure host arithmetic, ~0.3 s per candidate, cached."""
+    global _HOST_KC
+    if _HOST_KC is not None:
+        return _HOST_KC or None
+    import numpy as np
+    g = torch.Generator().manual_seed(7)
+    A = torch.relu(torch.randn(K, 384, generator=g))
+    B = torch.relu(torch.randn(K, 256, generator=g))
+    A, B = A / A.norm(dim=0, keepdim=True), B / B.norm(dim=0, keepdim=True)
+    mm = (A.t() @ B).numpy()
+    a, b = A.numpy().astype(np.float64), B.numpy().astype(np.float64)
+    found = 0
+    for kc in (192, 384, 256, 128, 512, K):
+        tot = np.zeros(mm.shape, np.float32)
+        for k0 in range(0, K, kc):
+            acc = np.zeros(mm.shape, np.float32)
+            for k in range(k0, min(K, k0 + kc)):
+                acc = (acc.astype(np.float64) + np.outer(a[k], b[k])).astype(np.float32)      # fma: exact product, one rounding
+            tot = (tot.astype(np.float64) + acc).astype(np.float32)
+        if float((tot != mm).mean()) <= 1e-4:
+            found = kc
+            break
+    _HOST_KC = found
+    return found or None
+
+
+_SCORES_CALIBRATED = False
+
+
+def calibrate_score_sums():
+    """Once per process, before the first mutual-NN launch: tell the library to accumulate a score in chunks of the host sgemm's
+    K block (rfx_mutual_nn_set_chunk), which makes the device's scores equal the reference's torch.mm on THIS host bit for bit on
+    equal features -- like the rank-deficient DLT systems (lapack_dlt), "the reference's value" is what this host's library
+    computes.  RFX_SCORE_SUMS=default keeps the library's own chunking (256 products); RFX_MNN_CHUNK overrides everything."""
+    global _SCORES_CALIBRATED
+    if _SCORES_CALIBRATED:
+        return
+    _SCORES_CALIBRATED = True
+    if os.environ.get("RFX_SCORE_SUMS", "host") != "host":
+        return
+    kc = host_sgemm_k_block()
+    if kc and kc % 32 == 0:
+        _lib.load().rfx_mutual_nn_set_chunk(kc // 32)
 
 
 def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
