@@ -622,6 +622,7 @@ def host_sgemm_k_block(K=1024):
 
 
 _SCORES_CALIBRATED = False
+_CAL_LOCK = threading.Lock()
 
 
 def calibrate_score_sums():
@@ -630,14 +631,14 @@ def calibrate_score_sums():
     equal features -- like the rank-deficient DLT systems (lapack_dlt), "the reference's value" is what this host's library
     computes.  RFX_SCORE_SUMS=default keeps the library's own chunking (256 products); RFX_MNN_CHUNK overrides everything."""
     global _SCORES_CALIBRATED
-    if _SCORES_CALIBRATED:
-        return
-    _SCORES_CALIBRATED = True
-    if os.environ.get("RFX_SCORE_SUMS", "host") != "host":
-        return
-    kc = host_sgemm_k_block()
-    if kc and kc % 32 == 0:
-        _lib.load().rfx_mutual_nn_set_chunk(kc // 32)
+    with _CAL_LOCK:                          # a second thread waits for the probe instead of launching with the default chunks
+        if _SCORES_CALIBRATED:
+            return
+        if os.environ.get("RFX_SCORE_SUMS", "host") == "host":
+            kc = host_sgemm_k_block()
+            if kc and kc % 32 == 0:
+                _lib.load().rfx_mutual_nn_set_chunk(kc // 32)
+        _SCORES_CALIBRATED = True
 
 
 def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):

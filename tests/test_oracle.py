@@ -534,3 +534,38 @@ def test_fused_tail_patch_choice_and_packed_weight_layout():
         a = ops.cc_max_area(size, th)
         assert a / float(size) <= th and (a + 1) / float(size) > th
 
+
+
+def test_host_sgemm_probe_and_score_chunk_setter():
+    """Host logic of the score calibration (no GPU needed): ops.host_sgemm_k_block() finds the K blocking with which a float32
+    emulation reproduces THIS host's torch.mm (the reference's score product, utils/outil.py:34) bit for bit -- 384 on the authoring
+    container's Xeon, 192 on the GPU box's EPYC (profiles/r04_mm_blocking_probe.json) -- and ops.calibrate_score_sums() hands it to the
+    library as a chunk length in K steps of 32 (rfx_mutual_nn_set_chunk returns the previous value)."""
+    from rfx import ops
+    lib = _lib.load()
+    kc = ops.host_sgemm_k_block()
+    assert kc in (None, 128, 192, 256, 384, 512, 1024)
+    assert ops.host_sgemm_k_block() == kc                                  # cached
+    prev = lib.rfx_mutual_nn_set_chunk(8)
+    try:
+        assert lib.rfx_mutual_nn_set_chunk(5) == 8 and lib.rfx_mutual_nn_set_chunk(-3) == 5 and lib.rfx_mutual_nn_set_chunk(8) == 0
+        ops._SCORES_CALIBRATED = False
+        ops.calibrate_score_sums()
+        assert lib.rfx_mutual_nn_set_chunk(8) == (kc // 32 if kc else 8)
+    finally:
+        lib.rfx_mutual_nn_set_chunk(prev)
+        ops._SCORES_CALIBRATED = False
+    if kc:                                                                 # the emulation the probe relies on, on a second, independent problem
+        import numpy as np
+        g = torch.Generator().manual_seed(3)
+        A = torch.relu(torch.randn(1024, 400, generator=g)); B = torch.relu(torch.randn(1024, 300, generator=g))
+        A, B = A / A.norm(dim=0, keepdim=True), B / B.norm(dim=0, keepdim=True)
+        mm = (A.t() @ B).numpy()
+        a, b = A.numpy().astype(np.float64), B.numpy().astype(np.float64)
+        tot = np.zeros(mm.shape, np.float32)
+        for k0 in range(0, 1024, kc):
+            acc = np.zeros(mm.shape, np.float32)
+            for k in range(k0, min(1024, k0 + kc)):
+                acc = (acc.astype(np.float64) + np.outer(a[k], b[k])).astype(np.float32)
+            tot = (tot.astype(np.float64) + acc).astype(np.float32)
+        assert float((tot != mm).mean()) <= 1e-4
