@@ -83,7 +83,9 @@ def cpu_baseline_subprocess(args):
     """The CPU leg in a child process with a hard wall-clock limit so that it can never stall the bench."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config, "--height", str(args.height),
            "--width", str(args.width), "--nb-scale", str(args.nb_scale), "--nb-iter", str(args.nb_iter), "--cpu-pairs", str(args.cpu_pairs)]
-    fail = {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "reference"}
+    have_ref = os.path.isdir(os.path.join(ROOT, "oracle", "_ref")) or os.path.isdir("/root/reference/utils")
+    fail = {"value": None, "unit": "pairs/s", "cores": cpu_threads(), "kind": "reference" if have_ref else "port",
+            "kind_note": "the leg failed: kind = what WOULD have run (oracle/_ref or /root/reference present: %s)" % have_ref}
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         for ln in out.stdout.splitlines():
@@ -179,7 +181,7 @@ def parity_subprocess(cfg, dump_dir, seeds, H, W, budget, stability=False):
            str(H), "--width", str(W), "--budget", str(budget)] + (["--stability", "--threads", "8"] if stability else ["--dump", dump_dir])
     cmd += ["--seeds"] + [str(s) for s in seeds]
     if os.environ.get("RFX_PARITY_RECORDS"):        # per-pair records for profiles/ (evidence scripts)
-        cmd += ["--records", os.environ["RFX_PARITY_RECORDS"] + "_" + cfg + ".json"]
+        cmd += ["--records", os.environ["RFX_PARITY_RECORDS"] + "_" + cfg + os.environ.get("RFX_PARITY_RECORDS_SUFFIX", "") + ".json"]
     env = dict(os.environ, OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0")     # many oracle workers side by side: no spin-waiting
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget + 120, env=env)
@@ -209,10 +211,20 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--host-draw", action="store_true", help="RANSAC index draw with torch.randint on the CPU generator (what a "
                     "CPU run of the reference draws) instead of on the device")
+    ap.add_argument("--degenerate", default="auto", choices=["auto", "device", "lapack"],
+                    help="rank-deficient 4-point samples (AlignPipeline): auto = the host's LAPACK with host draws, the device's own null "
+                         "vector with device draws (the timed default); lapack = the exact mode also with device draws")
+    ap.add_argument("--score-chunk", default="host",
+                    help="how the mutual-NN scores are summed (ops.resolve_score_chunk): 'host' (default here: the K blocking of this host's "
+                         "sgemm, probed ONCE on rank 0 before the workload is built and broadcast -- the parity legs compare with this host's "
+                         "CPU run of the reference), 'default' (fixed 256 products) or a number of products per chunk")
+    ap.add_argument("--no-exact-leg", action="store_true", help="default run: skip extra.exact_mode (throughput of the exact modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline + parity sweep)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=None, help="pairs of the batch covered by the parity sweep (default: all)")
     ap.add_argument("--parity-budget", type=float, default=110.0, help="wall-clock bound of the headline's parity sweep, seconds")
+    ap.add_argument("--timed-parity-budget", type=float, default=100.0,
+                    help="wall-clock bound of the sweep over the TIMED mode (device draws replayed on the reference), seconds")
     ap.add_argument("--qs-parity-budget", type=float, default=60.0, help="wall-clock bound of the quick_start leg's parity sweep")
     ap.add_argument("--stability-budget", type=float, default=70.0, help="wall-clock bound of the reference-vs-reference sweep")
     ap.add_argument("--no-qs-leg", "--no-config3-leg", dest="no_qs_leg", action="store_true",
@@ -313,7 +325,7 @@ def _download(rec, keep):
     return rec
 
 
-def build_workload(args, dev, rank, world):
+def build_workload(args, dev, rank, world, score_chunk=None):
     """Returns (step() -> (B, width) float32 record tensor on ``dev``, meta dict, extras for the parity leg).  Record columns:
     meta["col"] = dict(status=..., nbh=... or None, rank=...)."""
     import torch
@@ -322,6 +334,7 @@ def build_workload(args, dev, rank, world):
     from rfx import dist as rdist
     H, W, B, cfg = args.height, args.width, args.batch, args.config
     draw = "host" if args.host_draw else "device"
+    pkw = dict(device=dev, draw=draw, seed=1000, degenerate=args.degenerate, score_chunk=score_chunk)
     draw_txt = ("RANSAC index draw: Philox on the device from the device-side match counts, keyed by (seed, absolute pair id, round)" if draw == "device" else
                 "RANSAC index draw: torch.randint on the CPU generator per pair and homography")
     sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
@@ -329,7 +342,7 @@ def build_workload(args, dev, rank, world):
     seeds = [rank + world * i for i in range(B)]        # this rank's shard of the synthetic stream: pair i -> rank i mod world
     if cfg in ("qs", "2"):
         pipe = AlignPipeline(sds, nbScale=args.nb_scale, nbIter=args.nb_iter, tolerance=0.05, minSize=max(H, W), scaleR=1.2,
-                             variant="A", device=dev, draw=draw, seed=1000)
+                             variant="A", **pkw)
         pairs = [synth.make_pair(H, W, seed=s) for s in seeds]
         raw = pipe.upload_raw(pairs)
         prep0 = pipe.prepare(pairs) if args.host_prep else None
@@ -356,8 +369,7 @@ def build_workload(args, dev, rank, world):
     col = dict(status=1, nbh=0, rank=2)
     if cfg in ("3", "4"):
         nbScale, nbIter = (7, 10000) if cfg == "3" else (5, 50000)
-        pipe = AlignPipeline(sds, nbScale=nbScale, nbIter=nbIter, tolerance=0.05, minSize=min(H, W), scaleR=2.0, variant="B", device=dev,
-                             draw=draw, seed=1000)
+        pipe = AlignPipeline(sds, nbScale=nbScale, nbIter=nbIter, tolerance=0.05, minSize=min(H, W), scaleR=2.0, variant="B", **pkw)
         raw = pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True) for s in seeds])
 
         raw_h, rec_h = _pinned(raw) if args.pcie else None, {}
@@ -376,8 +388,7 @@ def build_workload(args, dev, rank, world):
               % (cfg, B, H, W, min(H, W), nbScale, nbIter, draw_txt))
         return step, dict(workload=wl, nbIter=nbIter, nbScale=nbScale, matchability_init_std=MULTIH_MATCH_STD, col=col), dict(pipe=pipe, seeds=seeds)
     # config 5: KITTI-shaped stream, two-resolution driver
-    pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", device=dev, draw=draw,
-                         seed=1000)
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=50000, tolerance=0.05, minSize=800, scaleR=1.2, variant="B", **pkw)
     raws = [pipe.upload_raw([synth.make_pair(H, W, seed=s, homography=True, amp=0.02)]) for s in seeds]
 
     raw_all = (torch.cat([r[0] for r in raws]), torch.cat([r[1] for r in raws]))
@@ -471,10 +482,15 @@ def pmc_traffic(kernel, cfg):
     passes: FETCH_SIZE and WRITE_SIZE cannot share a pass and rocprofv3 cannot wrap the process that is being timed), corrected as
     MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 16-byte/lane reads at half: doubled; WRITE_SIZE raw).  None when
     the summary or the kernel is missing."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_summary_config%s.json" % cfg)
-    try:
-        ks = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
+    ks = None
+    for rnd in ("r05", "r04"):            # the newest committed summary of this command
+        path = os.path.join(ROOT, "profiles", "%s_pmc_summary_config%s.json" % (rnd, cfg))
+        try:
+            ks = json.load(open(path))["kernels"]
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if ks is None:
         return None, None
     norm = lambda t: t.replace(" ", "")
     for name, o in ks.items():
@@ -599,13 +615,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         preflight(dist, backend, rank, world, dev)
     sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
+    if world > 1:
+        # N ranks share one host: each gets its share of the cores for the little CPU work a step has (cell-coordinate tables,
+        # the host sgemm probe on rank 0, torch's intra-op pool) instead of N full-size thread pools
+        torch.set_num_threads(max(1, cpu_threads() // world))
+    # the score chunk: resolved ONCE, on rank 0, BEFORE the workload is built (never inside a launch), and broadcast -- every rank
+    # must sum its scores the same way, whatever host it would probe
+    from rfx import ops
+    sc = [None, None]
+    if rank == 0:
+        sc = list(ops.resolve_score_chunk(args.score_chunk if not args.score_chunk.lstrip("-").isdigit() else int(args.score_chunk)))
+    if dist is not None:
+        dist.broadcast_object_list(sc, src=0)
+    score_chunk, score_chunk_source = int(sc[0]), sc[1]
+    log("score chunk: %d products (%s)" % (score_chunk, score_chunk_source))
 
     if args.dry_run:
         step, meta, extra = dry_run_step(args, rank), dict(workload="DRY RUN (no GPU): launcher / process-group rehearsal"), None
         prof_factory = _NoProf
     else:
-        from rfx import ops
-        step, meta, extra = build_workload(args, dev, rank, world)
+        step, meta, extra = build_workload(args, dev, rank, world, score_chunk=score_chunk)
         prof_factory = ops.Profiler
         torch.manual_seed(123 + rank)
     log("workload built (config %s, rank %d/%d)" % (args.config, rank, world))
@@ -621,8 +650,12 @@ def main():
     profiled_elapsed = elapsed
     if unprofiled is not None:
         elapsed = unprofiled
+    per_rank_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else None)
+        allt = torch.empty((world,), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(allt, t)                              # every rank's own clock: a SCALE record explains itself
+        per_rank_ms = [round(float(x) / args.steps * 1e3, 3) for x in allt.tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B = args.batch
@@ -639,8 +672,21 @@ def main():
                            gathered_records=int(out.shape[0]), record_bytes_per_pair=int(out.shape[1]) * 4, aligned_ok_last_step=ok_pairs,
                            ranks_seen_in_gather=sorted(set(int(x) for x in out[:, col["rank"]].tolist())),
                            collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
+                           score_chunk_products=score_chunk, score_chunk_source=score_chunk_source,
+                           ransac_draw="host (torch.randint, CPU generator)" if args.host_draw else "device (Philox4x32-10)",
+                           rank_deficient_samples=("host LAPACK (exact mode)" if (args.degenerate == "lapack" or (args.degenerate == "auto" and args.host_draw))
+                                                   else "device null vector"),
                            preprocessing="host PIL, outside the timed region" if args.host_prep else
                            "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step")}
+    if dist is not None:
+        try:
+            rv = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:  # noqa: BLE001
+            rv = None
+        line["config"].update(n_ranks_in_process_group=int(dist.get_world_size()), backend=backend, rccl_version=rv,
+                              ms_per_step_per_rank=per_rank_ms, cpu_threads_per_rank=torch.get_num_threads())
+        if backend == "nccl":
+            line["config"]["n_ranks_in_rccl"] = int(dist.get_world_size())
     if args.pcie:
         line["config"]["pcie_inclusive"] = ("NOT the headline: raw uint8 images uploaded from pinned host memory and the result records copied "
                                             "back to pinned host memory inside every timed step (%.1f + %.1f MB per step)"
@@ -666,7 +712,7 @@ def main():
         if not args.no_qs_leg:
             aq = argparse.Namespace(**vars(args))
             aq.config, aq.steps, aq.warmup, aq.nb_iter, aq.nb_scale = "qs", 10, 2, 1000, 7
-            stepq, metaq, extraq = build_workload(aq, dev, rank, world)
+            stepq, metaq, extraq = build_workload(aq, dev, rank, world, score_chunk=score_chunk)
             torch.manual_seed(123)
             eq, outq, profq = timed_loop(stepq, aq, None, sync, ops.Profiler)
             rq, cq = rooflines(profq, eq, rank, "qs")
@@ -676,6 +722,26 @@ def main():
                                      "roofline": {k: rq[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops", "conv_time_share", "traffic")},
                                      "roofline_corr": cq}
             log("quick_start leg done: %.1f pairs/s" % extras["quick_start"]["value"])
+        # ---- the exact modes' throughput on the SAME workload: what bit-for-bit comparability with a CPU run costs ----
+        if not args.no_exact_leg:
+            ex = {}
+            for name, hd, dg in (("host_draw_lapack", True, "auto"), ("device_draw_lapack", False, "lapack")):
+                ae = argparse.Namespace(**vars(args))
+                ae.host_draw, ae.degenerate, ae.steps, ae.warmup = hd, dg, 5, 1
+                stepe, _, _ = build_workload(ae, dev, rank, world, score_chunk=score_chunk)
+                torch.manual_seed(123)
+                ee, oute, _ = timed_loop(stepe, ae, None, sync, _NoProf)
+                ex[name] = {"pairs_per_s": round(B * ae.steps / ee, 3), "ms_per_step": round(ee / ae.steps * 1e3, 2), "steps": ae.steps,
+                            "vs_timed_mode": round((B * ae.steps / ee) / line["value"], 4),
+                            "aligned_ok_last_step": int((oute[:, col["status"]] == 0).sum().item())}
+                del stepe
+                torch.cuda.empty_cache()
+            ex["note"] = ("host_draw_lapack = torch.randint on the CPU generator per pair and round + rank-deficient samples re-solved by the "
+                          "host's LAPACK: the mode `parity` is measured in; device_draw_lapack = the timed mode's Philox draws + the same "
+                          "LAPACK patching (one more sync per round); value = the timed mode (device draws, device null vector), whose "
+                          "own parity is `parity_timed_mode`")
+            extras["exact_mode"] = ex
+            log("exact-mode leg done: %s" % {k: v["pairs_per_s"] for k, v in ex.items() if isinstance(v, dict)})
         # ---- CPU legs: bounded oracle baseline, then the parity sweeps over pairs of the timed batches ----
         if not args.no_cpu_baseline:
             log("GPU legs done; timing the CPU oracle (bounded sample, child process)")
@@ -684,12 +750,24 @@ def main():
                 import parity_sweep   # the CHECKER: dumps the device results, the oracle runs in child processes
                 seeds = extra["seeds"][:args.parity_pairs] if args.parity_pairs else extra["seeds"]
                 d = tempfile.mkdtemp(prefix="rfx_parity_loop_")
-                parity_sweep.dump_gpu_loop("ev_loop", seeds, dev, d, batch=16)
-                log("parity sweep (config 3: every round of the multi-H loop on the oracle), %d pairs dumped, budget %.0f s" % (len(seeds), args.parity_budget))
+                parity_sweep.dump_gpu_loop("ev_loop", seeds, dev, d, batch=16,
+                                           pipe=parity_sweep.gpu_pipeline("ev_loop", args.height, args.width, dev, score_chunk=score_chunk))
+                log("parity sweep (config 3, exact mode: every round of the multi-H loop on the oracle), %d pairs dumped, budget %.0f s" % (len(seeds), args.parity_budget))
                 line["parity"] = parity_subprocess("ev_loop", d, seeds, args.height, args.width, args.parity_budget)
+                # ---- the mode that is TIMED: device Philox draws, device null vectors; every round replayed on the reference with
+                # the device's own samples injected at utils/outil.py:120
+                d = tempfile.mkdtemp(prefix="rfx_parity_timed_")
+                parity_sweep.dump_gpu_loop("ev_loop", seeds, dev, d, batch=16, draw="device",
+                                           pipe=parity_sweep.gpu_pipeline("ev_loop", args.height, args.width, dev, draw="device",
+                                                                          score_chunk=score_chunk, degenerate=args.degenerate))
+                log("parity sweep over the TIMED mode (device draws replayed on the reference), budget %.0f s" % args.timed_parity_budget)
+                os.environ["RFX_PARITY_RECORDS_SUFFIX"] = "_timed_mode"
+                line["parity_timed_mode"] = parity_subprocess("ev_loop", d, seeds, args.height, args.width, args.timed_parity_budget)
+                os.environ.pop("RFX_PARITY_RECORDS_SUFFIX", None)
                 if not args.no_qs_leg:
                     d = tempfile.mkdtemp(prefix="rfx_parity_qs_")
-                    parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
+                    parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d,
+                                                pipe=parity_sweep.gpu_pipeline("qs", args.height, args.width, dev, score_chunk=score_chunk))
                     log("parity sweep (quick_start: oracle end to end), budget %.0f s" % args.qs_parity_budget)
                     extras["quick_start"]["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.qs_parity_budget)
                     log("reference vs reference (quick_start: two CPU execution settings), budget %.0f s" % args.stability_budget)
@@ -706,7 +784,8 @@ def main():
             import parity_sweep
             seeds = extra["seeds"][:args.parity_pairs] if args.parity_pairs else extra["seeds"]
             d = tempfile.mkdtemp(prefix="rfx_parity_")
-            parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d)
+            parity_sweep.dump_gpu_pairs("qs", seeds, args.height, args.width, dev, d,
+                                        pipe=parity_sweep.gpu_pipeline("qs", args.height, args.width, dev, score_chunk=score_chunk))
             line["parity"] = parity_subprocess("qs", d, seeds, args.height, args.width, args.parity_budget)
     if dist is not None:
         # all collectives are done: leave the group BEFORE rank 0's CPU leg, so that no rank waits in a communicator for it

@@ -42,7 +42,7 @@ const char* rfx_version(void);
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
  * round kernels, two-direction correlation, grouped launches; round 4: rfx_draw_samples_i64 keyed by pair id).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 7
+#define RFX_ABI_VERSION 8
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -305,28 +305,30 @@ int rfx_remove_small_cc_f32(const float* in, float* out, int N, int H, int W, fl
  * maskB (optional, nB floats, 0/1) multiplies featB's columns (quick_start/coarseAlignFeatMatch.py:143).
  * Outputs: idx1/idx2 (int64, capacity min(nA,nB)) in ascending idx1 order, count (int32[1]).
  * The nA x nB score matrix is never written to memory.  A score -- a sum of C non-negative products -- is accumulated in chunks of
- * 256 products that are added to a running total (round 4; RFX_MNN_CHUNK=0: one fma chain): the chain's round-off over C = 1024 is
+ * 256 products (default; argument score_chunk) that are added to a running total (round 4): the chain's round-off over C = 1024 is
  * 2.8x that of the reference's torch.mm and flipped float64 near-ties of the arg-max 1.5-2.3x as often as the reference flips them
  * against itself; chunked: 1.0-1.1x on the 64 bench pairs, 1.25x over 128 / 160 pairs.
  * ws: rfx_mutual_nn_ws_bytes(nA, nB) bytes.
  * ------------------------------------------------------------------------------------------ */
 size_t rfx_mutual_nn_ws_bytes(int nA, int nB);
-/* (ABI 7) K steps of 32 products per accumulation chunk of a score (process-wide; returns the previous value; 0 = one chain; the
- * environment variable RFX_MNN_CHUNK overrides it).  The reference's score is torch.mm on the HOST (utils/outil.py:34): MKL's sgemm
- * sums k as an fma chain inside blocks of KC products and adds the block sums to C -- KC = 192 on the GPU box's EPYC host, 384 on a
- * Xeon (scripts/mm_blocking_probe.py).  With k_steps = KC / 32 the device's scores equal the host's torch.mm BIT FOR BIT on equal
- * features, so that what is left of the arg-max near-tie flips comes from the trunk features alone.  The Python mirror probes the
- * host's KC once (rfx/ops.py::host_sgemm_k_block) and sets it; default 8 (256 products). */
-int rfx_mutual_nn_set_chunk(int k_steps);
+/* (ABI 8) score_chunk: how a score's C products are summed -- an fma chain inside chunks of `score_chunk` consecutive products
+ * (a multiple of 32), the chunk sums added to a running total in k order.  0 = the library default, 256 products; < 0 = ONE chain
+ * over all C.  The reference's score is torch.mm on the HOST (utils/outil.py:34): MKL's sgemm sums k as an fma chain inside blocks
+ * of KC products and adds the block sums to C -- KC = 192 on the GPU box's EPYC host, 384 on a Xeon (scripts/mm_blocking_probe.py).
+ * With score_chunk = KC the device's scores equal that host's torch.mm BIT FOR BIT on equal features, so that what is left of the
+ * arg-max near-tie flips comes from the trunk features alone.  It is an ARGUMENT of every call (ABI 7 had a process-wide setter):
+ * two pipelines of one process, or two ranks, never share it by accident; the Python mirror resolves it ONCE per pipeline
+ * (rfx/ops.py::resolve_score_chunk: an explicit value, or a probe of the host's KC) and records it in its results.
+ * Returns RFX_E_ARG for a positive score_chunk that is not a multiple of 32. */
 int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
-                      const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
+                      const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws, int score_chunk,
                       void* stream);
 
 /* The same for `batch` independent pairs in one launch (blockIdx.y = pair): pair b reads featA + b*strideA,
  * featB + b*strideB, maskB + b*nB, writes idx1/idx2 + b*min(nA,nB), count[b], and uses ws + b*ws_bytes(nA,nB). */
 int rfx_mutual_nn_batched_f32(const float* featA, int ldA, int nA, long long strideA, const float* featB, int ldB,
                               int nB, long long strideB, int C, const float* maskB, int64_t* idx1, int64_t* idx2,
-                              int32_t* count, void* ws, int batch, void* stream);
+                              int32_t* count, void* ws, int batch, int score_chunk, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * RANSAC over 4-point DLT homographies (utils/outil.py:68-164).
@@ -344,9 +346,12 @@ int rfx_prediction_f32(const float* match1, const float* match2, int n, const fl
                        void* stream);
 
 /* outil.ScoreRANSAC (utils/outil.py:102-113): H per hypothesis + inlier count * (det(H) > 1e-6).
- * Hout (N,3,3) f32, counts (N) int64.  ws: rfx_ransac_ws_bytes(n, N). */
+ * Hout (N,3,3) f32, counts (N) int64.  ws: rfx_ransac_ws_bytes(n, N).
+ * flags_out (ABI 8; optional, N bytes): the per-hypothesis flags of the SAME DLT pass -- bit 0 evaluated, bit 1 det gate passed,
+ * bit 2 the 8x9 system is rank deficient (dlt.h: one Sturm count on the bidiagonal) -- for a caller that re-solves exactly those
+ * hypotheses with the host's LAPACK (rfx/ops.py::score_hypotheses(degenerate="lapack")); NULL skips the rank test. */
 int rfx_score_hypotheses(const float* match1, const float* match2, int n, const int64_t* samples, int N,
-                         float tol, float* Hout, int64_t* counts, void* ws, void* stream);
+                         float tol, float* Hout, int64_t* counts, uint8_t* flags_out, void* ws, void* stream);
 
 /* outil.RANSAC (utils/outil.py:117-164) given the index draw: duplicate filter (:122-133), chunks of
  * 100 with the zero-chunk abort (:140-146), tail chunk (:153-160), first-maximum selection, final

@@ -121,12 +121,28 @@ def _min_size(c, H, W):
 # ------------------------------------------------------------------------------------------------ GPU side (called by tests / bench)
 
 
-def gpu_pipeline(cfg_name, H, W, dev, sds=None):
+DEVICE_DRAW_SEED = 1000     # seed of the device-side Philox draw in the "device" sweeps = bench.py's timed pipelines
+
+
+def gpu_pipeline(cfg_name, H, W, dev, sds=None, draw="host", score_chunk="host", degenerate="auto"):
+    """The device pipeline of a sweep.  ``draw="host"`` (+ degenerate "auto" = LAPACK patching): the exact mode, every draw handed
+    over by the sweep; ``draw="device"``: the mode bench.py TIMES -- Philox draws on the device keyed by (DEVICE_DRAW_SEED, absolute
+    pair id, round), rank-deficient samples solved by the device itself.  ``score_chunk="host"``: scores summed in the host
+    sgemm's K blocks (the parity modes; resolved once, recorded in the dump's meta.json and in the summary)."""
     from rfx.pipeline import AlignPipeline
     c = CONFIGS[cfg_name]
     sds = sds or state_dicts(MULTIH_MATCH_STD if "loop" in c else None)
     return AlignPipeline(sds, nbScale=c["nbScale"], nbIter=c["nbIter"], tolerance=0.05, minSize=_min_size(c, H, W), scaleR=c["scaleR"],
-                         variant=c["variant"], device=dev, draw="host")
+                         variant=c["variant"], device=dev, draw=draw, seed=DEVICE_DRAW_SEED, score_chunk=score_chunk, degenerate=degenerate)
+
+
+def write_meta(out_dir, pipe, **extra):
+    """What the dumped results were computed WITH -- read back by sweep() into the summary (the numbers describe themselves)."""
+    meta = dict(score_chunk_products=int(pipe.score_chunk), score_chunk_source=pipe.score_chunk_source, draw=pipe.draw,
+                degenerate=pipe._degenerate_mode(pipe.draw == "host"), draw_seed=int(pipe.seed))
+    meta.update(extra)
+    json.dump(meta, open(os.path.join(out_dir, "meta.json"), "w"))
+    return meta
 
 
 def dump_gpu_pairs(cfg_name, seeds, H, W, dev, out_dir, pipe=None, batch=16):
@@ -135,6 +151,7 @@ def dump_gpu_pairs(cfg_name, seeds, H, W, dev, out_dir, pipe=None, batch=16):
     from rfx import synth, ops
     pipe = pipe or gpu_pipeline(cfg_name, H, W, dev)
     os.makedirs(out_dir, exist_ok=True)
+    write_meta(out_dir, pipe, draw="host (explicit per-pair draws: parity_sweep.draw)", degenerate=pipe._degenerate_mode(True))
     seeds = list(seeds)
     for k in range(0, len(seeds), batch):
         sub = seeds[k:k + batch]
@@ -161,17 +178,26 @@ def dump_gpu_pairs(cfg_name, seeds, H, W, dev, out_dir, pipe=None, batch=16):
     return out_dir
 
 
-def dump_gpu_loop(cfg_name, seeds, dev, out_dir, pipe=None, batch=4, sub=4):
+def dump_gpu_loop(cfg_name, seeds, dev, out_dir, pipe=None, batch=4, sub=4, draw="host"):
     """Runs the lock-step multi-homography driver of BASELINE config 3 / 4 / 5 (``cfg_name`` = ev_loop / c4 / c5) on
-    make_pair(seed) for every seed with the explicit per-round draw ``draw_round`` and writes out_dir/pair_<seed>.npz: the
-    cached match list and, per round, the mask before the round, the surviving-match count, RANSAC status and H, the /8
-    outputs, the composed flow at every ``sub``-th pixel, the accept flag / gain and the mask after the round."""
+    make_pair(seed) for every seed and writes out_dir/pair_<seed>.npz: the cached match list and, per round, the mask before the
+    round, the surviving-match count, RANSAC status and H, the /8 outputs, the composed flow at every ``sub``-th pixel, the accept
+    flag / gain and the mask after the round.
+    ``draw="host"``: the explicit per-round draw ``draw_round`` (exact mode: LAPACK-patched rank-deficient samples).
+    ``draw="device"``: THE MODE bench.py TIMES -- the device's own Philox draws keyed by (DEVICE_DRAW_SEED, pair id = seed, round),
+    the device's own null vector on rank-deficient samples; the samples of every round are dumped (int32) so that the oracle
+    replays each round with exactly the hypotheses the device scored (utils/outil.py:120 takes them through the randint proxy)."""
     import torch
     from rfx import ops
     c = CONFIGS[cfg_name]
     H, W = c["H"], c["W"]
-    pipe = pipe or gpu_pipeline(cfg_name, H, W, dev)
+    pipe = pipe or gpu_pipeline(cfg_name, H, W, dev, draw=draw)
+    device_draw = draw == "device"
+    if device_draw and pipe.draw != "device":
+        raise ValueError("draw='device' needs a pipeline built with draw='device'")
     os.makedirs(out_dir, exist_ok=True)
+    write_meta(out_dir, pipe, **(dict(draw_epoch=pipe.DRAW_TAG["multi_h" if c["loop"] == "hpatch" else "kitti"]) if device_draw else
+                                 dict(draw="host (explicit per-round draws: parity_sweep.draw_round)", degenerate=pipe._degenerate_mode(True))))
     seeds = list(seeds)
     for k0 in range(0, len(seeds), batch):
         sb = seeds[k0:k0 + batch]
@@ -181,13 +207,13 @@ def dump_gpu_loop(cfg_name, seeds, dev, out_dir, pipe=None, batch=4, sub=4):
         def fn(b, n, it):
             calls[b] += 1
             return draw_round(sb[b], calls[b] - 1, n, it)
+        kw = dict(pair_ids=sb) if device_draw else dict(sample_fn=fn)
         trace = []
         if c["loop"] == "hpatch":
-            outs = pipe.multi_h_batched(pipe.prepare_device(*raw), maxCoarse=c["maxCoarse"], maskRegionTh=c["th"], sample_fn=fn,
-                                        trace=trace)
+            outs = pipe.multi_h_batched(pipe.prepare_device(*raw), maxCoarse=c["maxCoarse"], maskRegionTh=c["th"], trace=trace, **kw)
         else:
             outs = pipe.multi_h_kitti_batched(raw[0], raw[1], fineSize=c["fineSize"], maskRegionTh=c["th"], cc_th=c["cc_th"],
-                                              sample_fn=fn, trace=trace)
+                                              trace=trace, **kw)
         for b, s in enumerate(sb):
             i1, i2, cnt = outs[b]["matches"]
             n = int(cnt.item())
@@ -205,6 +231,9 @@ def dump_gpu_loop(cfg_name, seeds, dev, out_dir, pipe=None, batch=4, sub=4):
                      flow12_sub=np.stack([t["pm"]["flow12"][k, ::sub, ::sub].cpu().numpy() for t, k in rows]),
                      accept=np.asarray([int(t["accept"][k]) for t, k in rows]), gain=np.asarray([float(t["gain"][k]) for t, k in rows]),
                      final_mask=pack(outs[b]["mask"]))
+            if device_draw:
+                d["samples"] = np.stack([t["samples"][k].cpu().numpy().astype(np.int32) for t, k in rows])
+                d["round_id"] = np.asarray([int(t["round"]) for t, k in rows])
             if c["loop"] == "kitti":
                 d["flowD2"] = np.stack([t["flowD2"][k].cpu().numpy() for t, k in rows])
             np.savez_compressed(os.path.join(out_dir, "pair_%d.npz" % s), **d)
@@ -371,6 +400,25 @@ def compare_loop(cfg_name, seed, gpu_npz):
     sds = _W.get("sds") or state_dicts(MULTIH_MATCH_STD)
     nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
     state = {"k": 0}
+    device_draw = "samples" in g.files
+    if device_draw:
+        # the TIMED mode: the device's own Philox draws.  Round k of pair ``seed`` = Philox(key = the pipeline's draw seed, counter =
+        # (hypothesis, pair id = seed, stream = (epoch 0 << 32) | k)) % n (rfx_draw_samples_i64; tests/philox_ref.py pins the
+        # generator on the published known-answer vectors).  The samples the device actually scored were dumped per round: they
+        # are what the reference's RANSAC receives; the numpy restatement regenerates them (asserted equal) and supplies the
+        # draws of the oracle's own free-running loop, whose n may differ
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import philox_ref
+        meta = json.load(open(os.path.join(os.path.dirname(gpu_npz), "meta.json")))
+
+        def draw_round(seed_, k, n, it):                              # noqa: F811 -- shadows the host-draw rule for this pair
+            smp = philox_ref.draw_samples([int(n)], int(it), meta["draw_seed"], (int(meta.get("draw_epoch", 0)) << 32) | int(k),
+                                          pair_ids=[int(seed_)])[0]
+            if k < len(g["n"]) and int(n) == int(g["n"][k]) and int(g["round_id"][k]) == k:
+                assert np.array_equal(smp, g["samples"][k].astype(np.int64)), "dumped device samples != Philox restatement"
+            return torch.from_numpy(smp)
+    else:
+        draw_round = globals()["draw_round"]
 
     def sample_fn(n, it):
         state["k"] += 1
@@ -394,7 +442,7 @@ def compare_loop(cfg_name, seed, gpu_npz):
     same = bool(np.array_equal(ca.index1.numpy(), g["index1"]) and np.array_equal(ca.index2.numpy(), g["index2"]))
     rec = dict(seed=int(seed), oracle=oracle_name(restate), nA=int(ca.featsMultiScale.shape[1]), nB=int(ca.featt.shape[2] * ca.featt.shape[3]),
                n_matches_oracle=len(ref), n_matches_gpu=len(got), identical_list=same, n_differing=len(ref ^ got),
-               rounds=int(len(g["n"])), nbH_gpu=int(g["nbH"]))
+               rounds=int(len(g["n"])), nbH_gpu=int(g["nbH"]), draw="device" if device_draw else "host")
     if not same:
         rec["flips"] = tie_evidence(ca, sorted(ref - got), sorted(got - ref))
         rec["max_tie_evidence"] = max(f["evidence"] for f in rec["flips"])
@@ -449,7 +497,11 @@ def compare_loop(cfg_name, seed, gpu_npz):
             r["winner_count_oracle"] = int(cnt_o.max())
             gi = int((uniq == wg).all(dim=1).nonzero()[0, 0]) if (uniq == wg).all(dim=1).any() else -1
             r["oracle_count_of_gpu_winner"] = int(cnt_o[gi]) if gi >= 0 else None
-            r["degenerate_winner"] = bool(sv[7] / sv[0] < 1e-10)
+            # the round is decided by a rank-deficient 4-point sample when EITHER side's winner is one (device-draw mode: the
+            # device keeps its own null vector for such a sample, the reference's LAPACK another -- either can come out on top)
+            svo = np.linalg.svd(restate.dlt_matrix(m1_all[valid][wo][None].numpy(), m2_all[valid][wo][None].numpy()), compute_uv=False)[0]
+            r["dlt_sigma8_over_sigma1_oracle_winner"] = float(svo[7] / svo[0])
+            r["degenerate_winner"] = bool(sv[7] / sv[0] < 1e-10 or svo[7] / svo[0] < 1e-10)
         Hm = torch.from_numpy(np.asarray(Hb, dtype=np.float32))[None]
         if kitti:
             match, flow_d2, fd8, md8, flow12 = restate.kitti_fine_round(nets, T, Hm, c["cc_th"])
@@ -705,9 +757,13 @@ def sweep(cfg_name, dump_dir, seeds, H, W, workers=None, threads=8, budget_s=Non
                     break
             pool.terminate()
     records.sort(key=lambda r: r["seed"])
-    if loop:
-        return summarise_loop(cfg_name, records, len(jobs), time.perf_counter() - t0), records
-    return summarise(cfg_name, records, len(jobs), time.perf_counter() - t0, H, W), records
+    summary = (summarise_loop(cfg_name, records, len(jobs), time.perf_counter() - t0) if loop else
+               summarise(cfg_name, records, len(jobs), time.perf_counter() - t0, H, W))
+    try:                                    # what the device results were computed with (dump_gpu_*: write_meta)
+        summary["device"] = json.load(open(os.path.join(dump_dir, "meta.json")))
+    except (OSError, ValueError):
+        summary["device"] = None
+    return summary, records
 
 
 def stability_sweep(cfg_name, seeds, H, W, threads_a, threads_b, budget_s=None, workers=None):

@@ -15,7 +15,6 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
-#include <atomic>
 
 namespace {
 
@@ -532,12 +531,17 @@ extern "C" size_t rfx_mutual_nn_ws_bytes(int nA, int nB) {
     return layout(nA, nB).total;
 }
 
-// K steps (of 32 products) per accumulation chunk of a score.  The host mirror sets it to the K blocking of the HOST's sgemm
-// (rfx/ops.py::host_sgemm_k_block: 192 products on the GPU box's EPYC, 384 on a Xeon -- MKL 2024.2), which makes a score
-// bit-identical to the reference's torch.mm on the same host; 8 (256 products) until it is told.
-static std::atomic<int> g_mnn_chunk{8};
-
-extern "C" int rfx_mutual_nn_set_chunk(int k_steps) { return g_mnn_chunk.exchange(k_steps > 0 ? k_steps : 0); }
+// score_chunk (ABI 8, an argument of both entry points): products per accumulation chunk of a score -> a.kch, K steps of 32.
+// 0 = the default of 256 products; < 0 = one chain over C.  The host mirror resolves it once per pipeline -- an explicit value, or the
+// K blocking of the HOST's sgemm (rfx/ops.py::host_sgemm_k_block: 192 products on the GPU box's EPYC, 384 on a Xeon -- MKL 2024.2),
+// which makes a score bit-identical to the reference's torch.mm on that host.
+static int mnn_chunk_steps(int score_chunk, int* kch) {
+    if (score_chunk == 0) { *kch = 256 / BK; return RFX_OK; }
+    if (score_chunk < 0) { *kch = 0; return RFX_OK; }
+    if (score_chunk % BK != 0) return RFX_E_ARG;
+    *kch = score_chunk / BK;
+    return RFX_OK;
+}
 
 static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     const WsLayout L = layout(a.nA, a.nB);
@@ -549,8 +553,6 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     if (nwg > 0x7fffffffLL || batch > 65535) return RFX_E_LIMIT;
     const bool vec = a.ldA % 4 == 0 && a.ldB % 4 == 0 && a.strideA % 4 == 0 && a.strideB % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
-    const char* ce = getenv("RFX_MNN_CHUNK");                 // overrides rfx_mutual_nn_set_chunk (tests, A/B runs); 0 = one chain
-    a.kch = ce ? (atoi(ce) > 0 ? atoi(ce) : 0) : g_mnn_chunk.load(std::memory_order_relaxed);
     const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
     const int form = fe ? atoi(fe) : 0;
     const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);
@@ -569,10 +571,11 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
 
 extern "C" int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const float* featB, int ldB, int nB, int C,
                                  const float* maskB, int64_t* idx1, int64_t* idx2, int32_t* count, void* ws,
-                                 void* stream) {
+                                 int score_chunk, void* stream) {
     if (!featA || !featB || !idx1 || !idx2 || !count || !ws) return RFX_E_ARG;
     if (nA <= 0 || nB <= 0 || C <= 0 || ldA < nA || ldB < nB) return RFX_E_ARG;
     MnnArgs a;
+    if (mnn_chunk_steps(score_chunk, &a.kch) != RFX_OK) return RFX_E_ARG;
     a.A = featA; a.B = featB; a.maskB = maskB; a.ldA = ldA; a.ldB = ldB; a.nA = nA; a.nB = nB; a.C = C;
     a.strideA = a.strideB = a.strideMask = 0; a.ws = static_cast<char*>(ws);
     a.idx1 = idx1; a.idx2 = idx2; a.count = count; a.idxStride = 0;
@@ -581,10 +584,11 @@ extern "C" int rfx_mutual_nn_f32(const float* featA, int ldA, int nA, const floa
 
 extern "C" int rfx_mutual_nn_batched_f32(const float* featA, int ldA, int nA, long long strideA, const float* featB, int ldB,
                                          int nB, long long strideB, int C, const float* maskB, int64_t* idx1, int64_t* idx2,
-                                         int32_t* count, void* ws, int batch, void* stream) {
+                                         int32_t* count, void* ws, int batch, int score_chunk, void* stream) {
     if (!featA || !featB || !idx1 || !idx2 || !count || !ws || batch <= 0) return RFX_E_ARG;
     if (nA <= 0 || nB <= 0 || C <= 0 || ldA < nA || ldB < nB) return RFX_E_ARG;
     MnnArgs a;
+    if (mnn_chunk_steps(score_chunk, &a.kch) != RFX_OK) return RFX_E_ARG;
     a.A = featA; a.B = featB; a.maskB = maskB; a.ldA = ldA; a.ldB = ldB; a.nA = nA; a.nB = nB; a.C = C;
     a.strideA = strideA; a.strideB = strideB; a.strideMask = nB; a.ws = static_cast<char*>(ws);
     a.idx1 = idx1; a.idx2 = idx2; a.count = count; a.idxStride = nA < nB ? nA : nB;

@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void ransac_pack_kernel(const float* __restric
 }
 
 // X,Y given either as gathered samples (N,4,3) [direct != 0] or through indices into the match arrays.
+// WANT_RANK: also extract the bidiagonal and run the Sturm count behind flag bit 2 (15 fp64 registers and divisions per
+// hypothesis) -- only the callers that read the bit ask for it (the staged "lapack" search, the *_flags entry point,
+// rfx_score_hypotheses with a `degenerate` output); the throughput path (rfx_ransac_h4[_batched]) does not pay for it.
+template <bool WANT_RANK>
 __global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict__ m1, const float* __restrict__ m2, int n,
                                                         const int64_t* __restrict__ samples, int N, int filter_dup,
                                                         float* __restrict__ Hout, uint8_t* __restrict__ flags,
@@ -83,12 +87,12 @@ __global__ __launch_bounds__(64) void ransac_dlt_kernel(const float* __restrict_
     uint8_t fl = 0;  // bit0: evaluated (survives the duplicate filter), bit1: det gate passed, bit2: rank-deficient system
     if (!(filter_dup && dup) && !bad) {
         double hv[9], bd[15];
-        rfx_dlt4_nullvec(src, tgt, hv, bd);
+        rfx_dlt4_nullvec(src, tgt, hv, WANT_RANK ? bd : nullptr);
         float hf[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) { hf[j] = (float)hv[j]; Hout[(size_t)h * 9 + j] = hf[j]; }
         fl = 1 | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);   // torch.det's own LU order (dlt.h)
-        fl |= rfx_bidiag_rank_deficient(bd, RFX_DLT_RANK_REL) ? 4 : 0;
+        if (WANT_RANK) fl |= rfx_bidiag_rank_deficient(bd, RFX_DLT_RANK_REL) ? 4 : 0;
     } else {
 #pragma unroll
         for (int j = 0; j < 9; ++j) Hout[(size_t)h * 9 + j] = 0.0f;
@@ -306,7 +310,7 @@ inline RansacWs ws_layout(int N, int n_cap) {
 
 extern "C" int rfx_dlt4_homography(const float* X, const float* Y, int N, float* Hout, void* stream) {
     if (!X || !Y || !Hout || N <= 0) return RFX_E_ARG;
-    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
+    hipLaunchKernelGGL(ransac_dlt_kernel<false>, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
                        (const int64_t*)nullptr, N, 0, Hout, (uint8_t*)nullptr, (const int32_t*)nullptr, 0, (size_t)0);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
@@ -329,7 +333,7 @@ extern "C" size_t rfx_ransac_ws_bytes(int n, int N) {
 // stages: 1 = pack + DLT (hypotheses and their flags into the workspace), 2 = count; 3 = both
 static int ransac_common(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
                          int filter_dup, const RansacWs& L, char* w, float* Hs, int64_t* counts64, hipStream_t st,
-                         const int32_t* narr = nullptr, int cap = 0, int batch = 1, int stages = 3) {
+                         const int32_t* narr = nullptr, int cap = 0, int batch = 1, int stages = 3, bool want_rank = false) {
     float4* P = reinterpret_cast<float4*>(w + L.P);
     float* Z = reinterpret_cast<float*>(w + L.Z);
     uint8_t* flags = reinterpret_cast<uint8_t*>(w + L.flags);
@@ -339,8 +343,12 @@ static int ransac_common(const float* match1, const float* match2, int n, const 
         hipLaunchKernelGGL(ransac_pack_kernel, dim3((nmax + 255) / 256, batch), dim3(256), 0, st, match1, match2, n, P, Z, narr,
                            cap, L.total);
         RFX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
-                           filter_dup, Hs, flags, narr, cap, L.total);
+        if (want_rank)
+            hipLaunchKernelGGL(ransac_dlt_kernel<true>, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
+                               filter_dup, Hs, flags, narr, cap, L.total);
+        else
+            hipLaunchKernelGGL(ransac_dlt_kernel<false>, dim3((N + 63) / 64, batch), dim3(64), 0, st, match1, match2, n, samples, N,
+                               filter_dup, Hs, flags, narr, cap, L.total);
         RFX_LAUNCH_CHECK();
     }
     if (stages & 2) {
@@ -352,11 +360,16 @@ static int ransac_common(const float* match1, const float* match2, int n, const 
 }
 
 extern "C" int rfx_score_hypotheses(const float* match1, const float* match2, int n, const int64_t* samples, int N,
-                                    float tol, float* Hout, int64_t* counts, void* ws, void* stream) {
+                                    float tol, float* Hout, int64_t* counts, uint8_t* flags_out, void* ws, void* stream) {
     if (!match1 || !match2 || !samples || !Hout || !counts || !ws || n <= 0 || N <= 0) return RFX_E_ARG;
     const RansacWs L = ws_layout(N, n);
-    return ransac_common(match1, match2, n, samples, N, tol, 0, L, static_cast<char*>(ws), Hout, counts,
-                         rfx_stream(stream));
+    hipStream_t st = rfx_stream(stream);
+    int rc = ransac_common(match1, match2, n, samples, N, tol, 0, L, static_cast<char*>(ws), Hout, counts, st, nullptr, 0, 1, 3,
+                           flags_out != nullptr);
+    if (rc != RFX_OK || !flags_out) return rc;
+    // the per-hypothesis flags of the SAME DLT pass (bit 2 = rank-deficient system): no second solve for the caller that patches
+    hipError_t e = hipMemcpyAsync(flags_out, static_cast<char*>(ws) + L.flags, (size_t)N, hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? RFX_OK : (int)e;
 }
 
 extern "C" int rfx_ransac_h4(const float* match1, const float* match2, int n, const int64_t* samples, int N, float tol,
@@ -395,7 +408,8 @@ static int ransac_batched_stages(const float* match1, const float* match2, const
     char* w = static_cast<char*>(ws);
     float* Hs = reinterpret_cast<float*>(w + L.H);
     hipStream_t st = rfx_stream(stream);
-    int rc = ransac_common(match1, match2, 0, samples, N, tol, 1, L, w, Hs, nullptr, st, n, cap, batch, stages);
+    // the rank flag is read between the stages of the staged ("lapack") search only: stages == 3 is the throughput path
+    int rc = ransac_common(match1, match2, 0, samples, N, tol, 1, L, w, Hs, nullptr, st, n, cap, batch, stages, stages == 1);
     if (rc != RFX_OK) return rc;
     if (stages & 2) {
         hipLaunchKernelGGL(ransac_select_kernel, dim3(batch), dim3(1024), 0, st, reinterpret_cast<const float4*>(w + L.P),
@@ -445,7 +459,7 @@ extern "C" int rfx_ransac_patch_h(void* ws, int cap, int N, int batch, const int
 // outil.Homography with the rank flag per system (degenerate (N) uint8: 1 = rank deficient, see dlt.h)
 extern "C" int rfx_dlt4_homography_flags(const float* X, const float* Y, int N, float* Hout, uint8_t* degenerate, void* stream) {
     if (!X || !Y || !Hout || !degenerate || N <= 0) return RFX_E_ARG;
-    hipLaunchKernelGGL(ransac_dlt_kernel, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
+    hipLaunchKernelGGL(ransac_dlt_kernel<true>, dim3((N + 63) / 64), dim3(64), 0, rfx_stream(stream), X, Y, 0,
                        (const int64_t*)nullptr, N, 0, Hout, degenerate, (const int32_t*)nullptr, 0, (size_t)0);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

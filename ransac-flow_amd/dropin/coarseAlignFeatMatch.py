@@ -162,7 +162,8 @@ class CoarseAlignA(_CoarseBase):
         with torch.no_grad():
             keep = self._mask_to_feature_res(Mt)
             # zeroed target features (reference :143) == a 0/1 column mask inside the correlation kernel
-            index1, index2 = ops.mutual_nn(self.featsMultiScale, self.featt.view(1024, -1), keep.float().view(-1))
+            index1, index2 = ops.mutual_nn(self.featsMultiScale, self.featt.view(1024, -1), keep.float().view(-1),
+                                           score_chunk=outil.SCORE_CHUNK)
             W1, H1 = self.WMultiScale[index1], self.HMultiScale[index1]
             W2, H2 = self.Wt[index2], self.Ht[index2]
             ones = torch.ones_like(W1)

@@ -20,6 +20,12 @@ from rfx import ops
 # device's own null vector (no extra sync).
 _DEGENERATE = os.environ.get("RFX_DEGENERATE", "lapack")
 
+# How mutualMatching's scores are summed (rfx_api.h, ABI 8: an argument of every call).  The drop-in's contract is "what a CPU run of
+# the reference computes on THIS host", and the reference's score is the host's torch.mm (utils/outil.py:34), so the module resolves
+# the host sgemm's K blocking ONCE, when it is imported (ops.resolve_score_chunk("host"): < 2 s of host arithmetic, never inside a
+# call); RFX_SCORE_CHUNK=<products>|default overrides.  Both values are module attributes so that a script's log can state them.
+SCORE_CHUNK, SCORE_CHUNK_SOURCE = ops.resolve_score_chunk(os.environ.get("RFX_SCORE_CHUNK") or "host")
+
 
 def resizeImg(I, strideNet, minSize=400, mode=Image.LANCZOS):
     """utils/outil.py:6-19: scale so the smaller side is ``minSize``, round both sides to the net stride."""
@@ -48,12 +54,13 @@ def getWHTensor_Int(feat):
 def mutualMatching(featA, featB):
     """utils/outil.py:32-45 -> (index1, index2) int64 device tensors, ascending index1.
     One fused MFMA correlation + arg-max kernel chain; the nA x nB score matrix is never materialised."""
-    return ops.mutual_nn(featA, featB)
+    return ops.mutual_nn(featA, featB, score_chunk=SCORE_CHUNK)
 
 
 def Homography(X, Y):
     """utils/outil.py:68-87: X, Y (N,4,3) source / target samples -> H21 (N,3,3) float32 on X's device.
-    Float64 Householder DLT with LAPACK dgesdd's sign, entirely on the device (no CPU SVD round trip)."""
+    Float64 Householder DLT with LAPACK dgesdd's sign on the device; the ~1 % of samples whose 8x9 system is rank deficient are
+    re-solved by the host's LAPACK like the reference does for every sample (one sync; RFX_DEGENERATE=device: none)."""
     return ops.dlt4_homography(X, Y, degenerate=_DEGENERATE)
 
 

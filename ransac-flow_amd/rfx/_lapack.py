@@ -1,0 +1,85 @@
+"""Host LAPACK helper of the exact mode (ops.lapack_dlt): numpy's batched SVD is a serial, GIL-holding loop of one dgesdd per 8x9
+system (~10 us each; Python threads give no speed-up, measured), and a lock-step round of 64 pairs flags ~6 000 rank-deficient
+4-point samples: 70 ms of host time per round with the GPU idle.  ``null_vectors`` deals the systems to a few persistent WORKER
+PROCESSES -- plain ``python -c`` children speaking a length-prefixed byte protocol over pipes (no multiprocessing: nothing
+re-imports the caller's ``__main__``, nothing is forked from a process that holds a HIP context) -- each running the very same
+``np.linalg.svd(A)[2][:, 8]`` (utils/outil.py:84-86) on its slice: per system the same LAPACK routine of the same numpy build on the
+same data, hence the same bits (tests/test_oracle.py pins that), in 1/N of the time."""
+import atexit
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+_WORKER = r"""
+import sys, struct
+import numpy as np
+rd, wr = sys.stdin.buffer, sys.stdout.buffer
+while True:
+    h = rd.read(8)
+    if len(h) < 8:
+        break
+    k, = struct.unpack('<q', h)
+    A = np.frombuffer(rd.read(k * 576), dtype=np.float64).reshape(k, 8, 9)
+    wr.write(np.ascontiguousarray(np.linalg.svd(A)[2][:, 8]).tobytes())
+    wr.flush()
+"""
+
+_workers = []
+
+
+def _ncpu():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def start(n=None):
+    """Start the worker processes (idempotent).  Called by pipelines built with degenerate="lapack" so that the first round
+    does not pay the ~0.2 s interpreter start-up."""
+    if _workers:
+        return len(_workers)
+    n = n or int(os.environ.get("RFX_LAPACK_WORKERS", "0")) or max(1, min(16, _ncpu() // 4))
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for _ in range(n):
+        _workers.append(subprocess.Popen([sys.executable, "-c", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env))
+    atexit.register(stop)
+    return n
+
+
+def stop():
+    while _workers:
+        w = _workers.pop()
+        try:
+            w.stdin.close()
+            w.wait(timeout=2)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown: best effort
+            w.kill()
+
+
+def null_vectors(A, min_parallel=768):
+    """A (k,8,9) float64 -> (k,9) float64: row 8 of Vh of numpy's full SVD of every system, in order."""
+    k = A.shape[0]
+    if k < min_parallel or os.environ.get("RFX_LAPACK_WORKERS") == "1":
+        return np.linalg.svd(A)[2][:, 8]
+    n = start()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    step = -(-k // n)
+    jobs = []
+    try:
+        for w, i in zip(_workers, range(0, k, step)):
+            part = A[i:i + step]
+            w.stdin.write(struct.pack("<q", part.shape[0]))
+            w.stdin.write(part.tobytes())
+            w.stdin.flush()
+            jobs.append((w, part.shape[0]))
+        out = [np.frombuffer(w.stdout.read(m * 72), dtype=np.float64).reshape(m, 9) for w, m in jobs]
+        if any(o.shape[0] != m for o, (_, m) in zip(out, jobs)):
+            raise RuntimeError("short read")
+    except Exception:  # noqa: BLE001 -- a dead worker must not lose the round: drop the pool, solve in-process (same bits)
+        stop()
+        return np.linalg.svd(A)[2][:, 8]
+    return np.concatenate(out)

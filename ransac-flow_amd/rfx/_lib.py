@@ -50,13 +50,12 @@ SIGNATURES = {
     "rfx_remove_small_cc_ws_bytes": (c_size_t, [c_int] * 3),
     "rfx_remove_small_cc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "rfx_mutual_nn_ws_bytes": (c_size_t, [c_int, c_int]),
-    "rfx_mutual_nn_set_chunk": (c_int, [c_int]),
-    "rfx_mutual_nn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "rfx_mutual_nn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
     "rfx_mutual_nn_batched_f32": (c_int, [c_void_p, c_int, c_int, c_longlong, c_void_p, c_int, c_int, c_longlong, c_int]
-                                  + [c_void_p] * 5 + [c_int, c_void_p]),
+                                  + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "rfx_dlt4_homography": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rfx_prediction_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "rfx_score_hypotheses": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4),
+    "rfx_score_hypotheses": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 5),
     "rfx_ransac_ws_bytes": (c_size_t, [c_int, c_int]),
     "rfx_ransac_h4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 5),
     "rfx_ransac_batched_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -76,7 +75,7 @@ SIGNATURES = {
                               + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),
 }
 
-ABI_VERSION = 7     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
+ABI_VERSION = 8     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
 
 _lib = None
 

@@ -24,8 +24,6 @@ def _call(name, dev, *args):
     current device is switched for the launch when the tensors do not live on it (ctypes bypasses torch's
     device guard)."""
     fn = getattr(_lib.load(), name)
-    if not _SCORES_CALIBRATED and name.startswith("rfx_mutual_nn"):
-        calibrate_score_sums()             # scores summed in the host sgemm's K blocks: bit-equal to the reference's torch.mm
     if dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             rc = fn(*args, _stream(dev))
@@ -621,28 +619,44 @@ def host_sgemm_k_block(K=1024):
     return found or None
 
 
-_SCORES_CALIBRATED = False
-_CAL_LOCK = threading.Lock()
+DEFAULT_SCORE_CHUNK = 256        # products per accumulation chunk of a mutual-NN score when nothing else is asked for
 
 
-def calibrate_score_sums():
-    """Once per process, before the first mutual-NN launch: tell the library to accumulate a score in chunks of the host sgemm's
-    K block (rfx_mutual_nn_set_chunk), which makes the device's scores equal the reference's torch.mm on THIS host bit for bit on
-    equal features -- like the rank-deficient DLT systems (lapack_dlt), "the reference's value" is what this host's library
-    computes.  RFX_SCORE_SUMS=default keeps the library's own chunking (256 products); RFX_MNN_CHUNK overrides everything."""
-    global _SCORES_CALIBRATED
-    with _CAL_LOCK:                          # a second thread waits for the probe instead of launching with the default chunks
-        if _SCORES_CALIBRATED:
-            return
-        if os.environ.get("RFX_SCORE_SUMS", "host") == "host":
+def resolve_score_chunk(spec=None):
+    """The score chunk of ONE pipeline / drop-in module -> (products per chunk, where the value came from).  ``spec``:
+      None      -> the environment variable RFX_SCORE_CHUNK if set (same grammar), else the fixed default of 256 products;
+      an int    -> that many products per chunk (a positive multiple of 32), or <= 0: ONE fma chain over all products (-1);
+      "default" -> 256;
+      "host"    -> the K blocking of THIS host's sgemm (host_sgemm_k_block: ~0.3-2 s of host arithmetic, cached per process), which
+                   makes the device's scores equal the reference's torch.mm on this host bit for bit (the parity modes: drop-in
+                   modules, parity sweeps, bench.py); 256 when no candidate reproduces the host's torch.mm (another BLAS).
+    Called where a pipeline is CONSTRUCTED, never inside a launch: the value is an explicit argument of every
+    rfx_mutual_nn*_f32 call (ABI 8) and travels with the results (AlignPipeline.score_chunk / .score_chunk_source)."""
+    src = "argument"
+    if spec is None:
+        spec, src = os.environ.get("RFX_SCORE_CHUNK"), "RFX_SCORE_CHUNK"
+        if spec is None or spec == "":
+            return DEFAULT_SCORE_CHUNK, "default (fixed 256 products)"
+    if isinstance(spec, str):
+        if spec == "default":
+            return DEFAULT_SCORE_CHUNK, "default (fixed 256 products)"
+        if spec == "host":
             kc = host_sgemm_k_block()
             if kc and kc % 32 == 0:
-                _lib.load().rfx_mutual_nn_set_chunk(kc // 32)
-        _SCORES_CALIBRATED = True
+                return int(kc), "host probe (host_sgemm_k_block: this host's torch.mm sums k in blocks of %d)" % kc
+            return DEFAULT_SCORE_CHUNK, "fallback (no K blocking reproduced this host's torch.mm: fixed 256 products)"
+        spec = int(spec)
+    spec = int(spec)
+    if spec <= 0:
+        return -1, "%s (one chain)" % src
+    if spec % 32:
+        raise ValueError("score_chunk must be a multiple of 32 products, got %d" % spec)
+    return spec, src
 
 
-def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
+def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None, score_chunk=0):
     """featA (C,nA), featB (C,nB) -> (index1, index2) int64 device tensors (ascending index1).
+    ``score_chunk``: products per accumulation chunk of a score (rfx_api.h; 0 = the library default of 256, < 0 = one chain).
     Synchronises once to read the match count (the reference's nonzero() does the same)."""
     featA, featB = _dev(featA, "featA"), _dev(featB, "featB")
     C = featA.shape[0]
@@ -658,7 +672,7 @@ def mutual_nn(featA, featB, maskB=None, ldA=None, ldB=None, nA=None, nB=None):
     count = torch.zeros(1, dtype=torch.int32, device=featA.device)
     m = _dev(maskB, "maskB") if maskB is not None else None
     _call("rfx_mutual_nn_f32", _one_device(featA, featB, m), _p(featA), ldA, nA, _p(featB), ldB, nB, C, _p(m), _p(idx1), _p(idx2), _p(count),
-                                     _p(ws))
+                                     _p(ws), int(score_chunk))
     n = int(count.item())
     return idx1[:n], idx2[:n]
 
@@ -676,7 +690,10 @@ def lapack_dlt(X, Y):
         u, v, u_, v_ = Y[:, i, 0], Y[:, i, 1], X[:, i, 0], X[:, i, 1]
         A[:, 2 * i] = np.stack([z, z, z, -u, -v, -o, v_ * u, v_ * v, v_], axis=1)
         A[:, 2 * i + 1] = np.stack([u, v, o, z, z, z, -u_ * u, -u_ * v, -u_], axis=1)
-    return np.linalg.svd(A)[2][:, 8].reshape(k, 3, 3).astype(np.float32)
+    # numpy's batched svd is a serial loop of one dgesdd per system: large batches are dealt to worker processes (rfx/_lapack.py),
+    # per system the same LAPACK call on the same data -- the same bits
+    from . import _lapack
+    return _lapack.null_vectors(A).reshape(k, 3, 3).astype(np.float32)
 
 
 def dlt4_homography(X, Y, degenerate="device", info=None):
@@ -718,14 +735,14 @@ def score_hypotheses(match1, match2, samples, tol, degenerate="device"):
     H = torch.empty((N, 3, 3), dtype=torch.float32, device=match1.device)
     counts = torch.empty(N, dtype=torch.int64, device=match1.device)
     ws = torch.empty(lib.rfx_ransac_ws_bytes(n, N), dtype=torch.uint8, device=match1.device)
-    _call("rfx_score_hypotheses", _one_device(match1, match2, samples), _p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts), _p(ws))
-    if degenerate == "lapack":
-        X, Y = match1[samples], match2[samples]
-        fl = torch.empty(N, dtype=torch.uint8, device=match1.device)
-        _call("rfx_dlt4_homography_flags", _one_device(X, Y), _p(X), _p(Y), N, _p(torch.empty_like(H)), _p(fl))
+    fl = torch.empty(N, dtype=torch.uint8, device=match1.device) if degenerate == "lapack" else None   # flags of the SAME DLT pass
+    _call("rfx_score_hypotheses", _one_device(match1, match2, samples), _p(match1), _p(match2), n, _p(samples), N, float(tol), _p(H), _p(counts),
+          _p(fl), _p(ws))
+    if fl is not None:
         bad = ((fl & 4) != 0).nonzero()[:, 0]
         if bad.numel():
-            Hp = torch.from_numpy(lapack_dlt(X[bad].cpu().numpy(), Y[bad].cpu().numpy()))
+            sb = samples[bad]
+            Hp = torch.from_numpy(lapack_dlt(match1[sb].cpu().numpy(), match2[sb].cpu().numpy()))
             H[bad] = Hp.to(H.device)
             cnt = torch.cat([(prediction(match1, match2, H[bad[i:i + 4096]]) < tol).sum(dim=1) for i in range(0, bad.numel(), 4096)])
             counts[bad] = cnt * (torch.det(Hp) > 1e-6).long().to(cnt.device)
@@ -862,7 +879,7 @@ def filter_matches(idx1, idx2, count, active, mask, bg, rt, ct, xa, ya, xb, yb, 
 class MultiHRecords:
     """The fixed-size per-pair result records of the multi-homography drivers (what
     evaluation/evalHpatch/evaluation.py:254-260 saves per pair), one float32 row per pair so that ONE all_gather moves them:
-    [0] nbH (<= max_h) | [1] status (0 ok, 1 no homography, 3 more homographies accepted than the record holds) | H (max_h,9) | flowDown8 (max_h,2,h8,w8) | matchDown8 (max_h,2,h8,w8)
+    [0] nbH (<= max_h) | [1] status (0 ok, 1 no homography, 3 more homographies accepted than the record holds, 4 stopped by the KITTI driver at the record's capacity -- the reference's ``while True`` has no limit) | H (max_h,9) | flowDown8 (max_h,2,h8,w8) | matchDown8 (max_h,2,h8,w8)
     [| flowD2 (max_h,2,hd2,wd2): the half-resolution /8 flow of the KITTI driver].  Filled on the device by multih_accept."""
 
     def __init__(self, B, h8, w8, device, max_h=11, hd2=0, wd2=0):

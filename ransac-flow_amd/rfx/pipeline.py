@@ -76,12 +76,17 @@ def cell_coords(n_rows, n_cols, device):
 
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
-                 device="cuda", kernelSize=7, draw="device", seed=0, degenerate="auto"):
+                 device="cuda", kernelSize=7, draw="device", seed=0, degenerate="auto", score_chunk=None):
         """``draw``: where the RANSAC index draw of utils/outil.py:120 happens when no explicit ``samples`` / ``sample_fn`` is
         given.  "device" (default; the reference draws on ``match1.device``, i.e. on the GPU in a GPU run): Philox4x32-10 on
         the device keyed by (``seed``, call counter, pair, hypothesis) -- no host sync for nbMatch, no CPU draw + upload.
         "host": ``torch.randint`` on the CPU generator per pair in pair order = what a CPU run of the reference draws
-        (the parity mode: the oracle can replay it from ``torch.manual_seed``)."""
+        (the parity mode: the oracle can replay it from ``torch.manual_seed``).
+        ``score_chunk``: how the mutual-NN scores are summed (ops.resolve_score_chunk, resolved HERE, once): None = RFX_SCORE_CHUNK
+        or the fixed default of 256 products per chunk; an int; "host" = the K blocking of this host's sgemm (scores bit-equal to
+        the reference's torch.mm on this host: the parity modes).  The resolved value and its origin are attributes
+        (``score_chunk``, ``score_chunk_source``) and an explicit argument of every mutual-NN launch of THIS pipeline."""
+        self.score_chunk, self.score_chunk_source = ops.resolve_score_chunk(score_chunk)
         if draw not in ("device", "host"):
             raise ValueError("draw must be 'device' or 'host'")
         if degenerate not in ("auto", "device", "lapack"):
@@ -91,6 +96,9 @@ class AlignPipeline:
         # (explicit samples / sample_fn / draw="host": the modes in which a CPU run of the reference can be compared bit for bit,
         # and which sync for the match counts anyway), device otherwise (the throughput mode: no host round trip)
         self.degenerate = degenerate
+        if degenerate == "lapack" or (degenerate == "auto" and draw == "host"):
+            from . import _lapack
+            _lapack.start()           # the exact mode's host LAPACK workers: started here, not inside the first round
         self.draw, self.seed, self._draw_calls = draw, int(seed), 0
         self.dev = torch.device(device)
         self.trunk = ResNet50Trunk(sds["trunk"], self.dev)
@@ -119,15 +127,28 @@ class AlignPipeline:
             return self._device_draw(torch.tensor([n], dtype=torch.int32, device=self.dev), ids, epoch, 0)[0]
         return torch.randint(n, (it, 4))
 
-    def _draw_epoch(self, pair_ids):
+    DRAW_TAG = dict(multi_h=0, coarse=1, kitti=2)       # which driver draws: part of the Philox stream id when pair_ids are given
+
+    def _draw_epoch(self, pair_ids, driver="multi_h", draw_epoch=0):
         """The key of a driver call's device draws besides (seed, round): ``pair_ids`` given (the caller's ABSOLUTE pair ids,
-        one per pair of the batch) -> (ids on the device, epoch 0): a pair's hypotheses depend on (seed, its id, the round) only --
-        not on the batch it rides in, on which other pairs are still active, or on how a stream is sharded over ranks.
+        one per pair of the batch) -> (ids on the device, epoch): a pair's hypotheses depend on (seed, its id, the driver, the
+        caller's ``draw_epoch``, the round) only -- not on the batch it rides in, on which other pairs are still active, or on how
+        a stream is sharded over ranks.  epoch = draw_epoch * 16 + the driver's tag: the quick_start search (coarse) and round 0 of
+        a multi-homography loop work on the same match list and must not share their samples, and a caller that retries a pair
+        passes another ``draw_epoch`` to draw afresh (draw_epoch 0 + multi_h = epoch 0: the keys of rounds 3-4 are unchanged).
+        The id tensor is cached per id tuple and uploaded from pinned memory without blocking.
         ``None`` -> ids = positions in the batch and a per-pipeline call counter as the epoch (calls draw afresh)."""
         if pair_ids is None:
             self._draw_calls += 1
             return None, self._draw_calls
-        return torch.as_tensor(pair_ids, dtype=torch.int32).to(self.dev), 0
+        key = tuple(int(i) for i in pair_ids)
+        cache = self.__dict__.setdefault("_ids_cache", {})
+        ids = cache.get(key)
+        if ids is None:
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)))
+            ids = cache[key] = torch.tensor(key, dtype=torch.int32).pin_memory().to(self.dev, non_blocking=True)
+        return ids, int(draw_epoch) * 16 + self.DRAW_TAG[driver]
 
     def _device_draw(self, n_dev, ids=None, epoch=0, rnd=0):
         return ops.draw_samples(n_dev, self.nbIter, self.seed, (int(epoch) << 32) | int(rnd), ids)
@@ -419,7 +440,7 @@ class AlignPipeline:
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
                     Wt=Wt, Ht=Ht, rt=rt, ct=ct)
 
-    def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None, pair_ids=None):
+    def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None, pair_ids=None, draw_epoch=0):
         """Per pair: mutual NN -> matches -> RANSAC.  Index draw (utils/outil.py:120): ``samples`` = list of (nbIter,4) int64
         CPU tensors, or ``sample_fn(b, nMatch, nbIter)`` -> such a tensor; otherwise the pipeline's ``draw`` mode -- "device":
         Philox on the device from the device-side match counts, ONE host sync per batch (the result records); "host":
@@ -433,7 +454,7 @@ class AlignPipeline:
         host_draw = not (samples is None and sample_fn is None and self.draw == "device")
         self._last_degenerate = {}
         if not host_draw:
-            ids, epoch = self._draw_epoch(pair_ids)
+            ids, epoch = self._draw_epoch(pair_ids, "coarse", draw_epoch)
             smp = self._device_draw(cnt, ids, epoch, 0)
             counts, draws = None, smp
         else:
@@ -496,7 +517,7 @@ class AlignPipeline:
         ldA = feats.get("ldA", nA)
         ops._call("rfx_mutual_nn_batched_f32", ops._one_device(feats["featA"], feats["featB"], mask), ops._p(feats["featA"]),
                   ldA, nA, 1024 * ldA, ops._p(feats["featB"]), nB, nB, 1024 * nB, 1024, ops._p(mask), ops._p(idx1),
-                  ops._p(idx2), ops._p(count), ops._p(ws), B)
+                  ops._p(idx2), ops._p(count), ops._p(ws), B, int(self.score_chunk))
         return idx1, idx2, count
 
     # ---------------------------------------------------------------- fine stage
@@ -576,7 +597,7 @@ class AlignPipeline:
         dev = self.dev
         h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
         IsT, ItT = prep["IsTensor"][b:b + 1], prep["ItTensor"][b:b + 1]
-        i1, i2 = ops.mutual_nn(feats["featA"][b], feats["featB"][b], ldA=feats.get("ldA"), nA=feats["nA"])
+        i1, i2 = ops.mutual_nn(feats["featA"][b], feats["featB"][b], ldA=feats.get("ldA"), nA=feats["nA"], score_chunk=self.score_chunk)
         W1, H1 = feats["WA"][i1], feats["HA"][i1]
         W2, H2 = feats["Wt"][i2], feats["Ht"][i2]
         rt, ct = feats["rt"], feats["ct"]
@@ -633,7 +654,7 @@ class AlignPipeline:
                             for b, n in zip(active, n_host)]).to(self.dev, non_blocking=True)
 
     def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None, records=None,
-                        want_lists=True, trace=None, pair_ids=None):
+                        want_lists=True, trace=None, pair_ids=None, draw_epoch=0):
         """multi_h() for every pair of the batch in lock-step: round k computes the k-th homography of all pairs that are
         still active.  A round is device work end to end -- rfx_filter_matches_f32 (mask -> keep map -> ordered compaction of
         the cached matches), the index draw (device mode), rfx_ransac_h4_batched, the warp, PredFlowMask over the active
@@ -662,7 +683,7 @@ class AlignPipeline:
         nb = [0] * B
         eye = torch.eye(3, device=dev)
         active = list(range(B))
-        ids, epoch = self._draw_epoch(pair_ids)
+        ids, epoch = self._draw_epoch(pair_ids, "multi_h", draw_epoch)
         rnd = 0
         while active:
             full = len(active) == B
@@ -683,7 +704,8 @@ class AlignPipeline:
                                              match21Down8=pm["match21Down8"], records=records)
             if trace is not None:
                 trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=pm["match"][:, 0],
-                                  accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
+                                  accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp,
+                                  round=rnd - 1))
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
             acc = accept.cpu().tolist()                                                 # the round's ONE sync
             nxt = []
@@ -736,7 +758,7 @@ class AlignPipeline:
         tensor_s, _ = ops.u8_to_f32(src_u8)                                              # source at its ORIGINAL size
         tensor_resize, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_r, h_r))
         tensor_d2, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_d2, h_d2))
-        i1, i2 = ops.mutual_nn(feats["featA"][0], feats["featB"][0], ldA=feats.get("ldA"), nA=feats["nA"])
+        i1, i2 = ops.mutual_nn(feats["featA"][0], feats["featB"][0], ldA=feats.get("ldA"), nA=feats["nA"], score_chunk=self.score_chunk)
         W1, H1 = feats["WA"][i1], feats["HA"][i1]
         W2, H2 = feats["Wt"][i2], feats["Ht"][i2]
         rt, ct = feats["rt"], feats["ct"]
@@ -811,7 +833,7 @@ class AlignPipeline:
         return flow_d2, pm, match
 
     def multi_h_kitti_batched(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, sample_fn=None,
-                              remove_small_cc=None, records=None, want_lists=True, trace=None, pair_ids=None):
+                              remove_small_cc=None, records=None, want_lists=True, trace=None, pair_ids=None, draw_epoch=0):
         """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
         computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
         the match filtering (rfx_filter_matches_f32), the index draw (device mode), RANSAC (rfx_ransac_h4_batched), the two
@@ -841,7 +863,7 @@ class AlignPipeline:
         nb = [0] * B
         eye = torch.eye(3, device=dev)
         active = list(range(B))
-        ids, epoch = self._draw_epoch(pair_ids)
+        ids, epoch = self._draw_epoch(pair_ids, "kitti", draw_epoch)
         rnd = 0
         while active:
             full = len(active) == B
@@ -863,7 +885,7 @@ class AlignPipeline:
             if trace is not None:
                 trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=match,
                                   flowD2=flow_d2, accept=accept, gain=gain,
-                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone()))
+                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp, round=rnd - 1))
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
             acc = accept.cpu().tolist()                                                 # the round's ONE sync
             nxt = []
@@ -878,7 +900,9 @@ class AlignPipeline:
                 nb[b] += 1
                 if records is not None and nb[b] >= records.max_h:
                     # the reference's ``while True`` has no round limit; a fixed-size record has: the pair stops at the
-                    # record's capacity (one more accepted homography would set the record's status to 3 = overflow)
+                    # record's capacity and its record says so (status 4 = "capped by the driver": the reference might have
+                    # gone on; a truncated pair is distinguishable from one that ended on the accept test)
+                    records.rec[b, 1] = 4.0
                     continue
                 nxt.append(b)
             active = nxt
@@ -889,8 +913,8 @@ class AlignPipeline:
         return outs
 
     # ---------------------------------------------------------------- whole path
-    def align_prepared(self, prep, fine=True, samples=None, feats=None, pair_ids=None):
-        res = self.coarse(prep, feats=feats, samples=samples, pair_ids=pair_ids)
+    def align_prepared(self, prep, fine=True, samples=None, feats=None, pair_ids=None, draw_epoch=0):
+        res = self.coarse(prep, feats=feats, samples=samples, pair_ids=pair_ids, draw_epoch=draw_epoch)
         if fine:
             eye = torch.eye(3, device=self.dev)
             Hs = torch.stack([r["H"] if r["H"] is not None else eye for r in res])

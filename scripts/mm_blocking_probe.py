@@ -6,7 +6,7 @@ CPU part: a float32 emulation of "fma chain inside blocks of KC products, block 
 KC, compared element by element with torch.mm on post-ReLU, L2-normalised columns (C = 1024).  On MKL 2024.2 (the BLAS of this
 torch build) KC = 384 reproduces torch.mm exactly, on the authoring container's Xeon and -- this script answers it -- on the GPU
 box's host.  GPU part (when a device is visible): the per-row score maxima that mnn_tile_*_kernel leaves in its workspace, for
-RFX_MNN_CHUNK = 0 (one chain) / 6 (192 k) / 8 (256 k) / 12 (384 k), compared with the row maxima of torch.mm: the share of bit-equal rows.
+score_chunk = one chain / 192 / 256 / 384 products, compared with the row maxima of torch.mm: the share of bit-equal rows.
 
     python scripts/mm_blocking_probe.py [--out profiles/r04_mm_blocking_probe.json]
 """
@@ -72,17 +72,15 @@ def main():
         Ad, Bd = A2.to(dev), B2.to(dev)
         out["device_vs_torch_mm_row_maxima"] = {}
         for chunk in ("0", "6", "8", "12"):
-            os.environ["RFX_MNN_CHUNK"] = chunk
             ws = torch.zeros(lib.rfx_mutual_nn_ws_bytes(nA2, nB2), dtype=torch.uint8, device=dev)
             i1 = torch.empty(nB2, dtype=torch.int64, device=dev); i2 = torch.empty_like(i1)
             cnt = torch.zeros(1, dtype=torch.int32, device=dev)
             ops._call("rfx_mutual_nn_f32", dev, ops._p(Ad), nA2, nA2, ops._p(Bd), nB2, nB2, C, ops._p(None), ops._p(i1), ops._p(i2), ops._p(cnt),
-                      ops._p(ws))
+                      ops._p(ws), int(chunk) * 32 if chunk != "0" else -1)       # score_chunk argument (ABI 8): products per chunk; < 0 = one chain
             rowval = ws[o_rowval:o_rowval + 4 * nA2].view(torch.float32).cpu()
             r = dict(share_of_rows_bit_equal=float((rowval == cpu_rowmax).float().mean()), max_abs=float((rowval - cpu_rowmax).abs().max()))
-            out["device_vs_torch_mm_row_maxima"]["RFX_MNN_CHUNK=%s" % chunk] = r
+            out["device_vs_torch_mm_row_maxima"]["score_chunk=%s" % (int(chunk) * 32 if chunk != "0" else "chain")] = r
             print("device chunk", chunk, r)
-        os.environ.pop("RFX_MNN_CHUNK", None)
     if a_.out:
         os.makedirs(os.path.dirname(os.path.abspath(a_.out)), exist_ok=True)
         json.dump(out, open(a_.out, "w"), indent=1)

@@ -33,7 +33,7 @@ def run(B, nA, nB, C, iters, dev):
     for form in ("0", "1"):
         os.environ["RFX_MNN_FORM"] = form
         call = lambda: ops._call("rfx_mutual_nn_batched_f32", dev, p(A), ld, nA, C * ld, p(Bm), nB, nB, C * nB, C, ctypes.c_void_p(0),
-                                 p(idx1), p(idx2), p(cnt), p(ws), B)
+                                 p(idx1), p(idx2), p(cnt), p(ws), B, 0)
         for _ in range(3):
             call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -77,6 +78,14 @@ def test_bench_rank_code_self_spawns_two_gloo_ranks():
     assert j["config"]["ranks_seen_in_gather"] == [0, 1] and j["config"]["gathered_records"] == 8
     assert j["value"] > 0 and abs(j["value"] - 4 * 3 * 2 / (j["ms_per_step"] * 3e-3)) < 1e-2 * j["value"]
     assert "preflight ok: gloo, 2 rank(s)" in out.stderr        # init + 1 MB all_gather + barrier before the workload is built
+    # first-N>1-run hygiene: the line explains itself -- ranks in the group, every rank's own clock, the per-rank
+    # CPU thread cap, and the score chunk rank 0 resolved and broadcast (all ranks sum their scores the same way)
+    c = j["config"]
+    assert c["n_ranks_in_process_group"] == 2 and c["backend"] == "gloo" and len(c["ms_per_step_per_rank"]) == 2
+    assert max(c["ms_per_step_per_rank"]) == pytest.approx(j["ms_per_step"], rel=1e-3)
+    assert c["cpu_threads_per_rank"] >= 1 and c["score_chunk_products"] in (128, 192, 256, 384, 512, 1024)
+    assert ("host probe" in c["score_chunk_source"]) or ("fallback" in c["score_chunk_source"])
+    assert out.stderr.count("score chunk: %d products" % c["score_chunk_products"]) == 2     # both ranks hold rank 0's value
     # a single rank stays a single process and says so
     out1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "0", "--batch", "3"],
                           capture_output=True, text=True, timeout=120, env=env)

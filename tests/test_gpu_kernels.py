@@ -444,7 +444,7 @@ def test_mutual_nn_scores_are_accumulated_in_chunks_of_256_products(dev, monkeyp
     """Round 4: a score (utils/outil.py:34, featA.t() @ featB) is a sum of C = 1024 NON-NEGATIVE products (post-ReLU, L2-normalised
     features).  One fma chain over them carries 2.8x the round-off of the CPU reference's K-blocked sgemm -- and that error, larger
     than what the trunk features contribute, is what decides a float64 near-tie of the arg-max.  Both tile kernels close a chunk
-    every 8 K steps (256 k) and add it to a running total (RFX_MNN_CHUNK=0: the chain).  Read back: the per-row maxima the tile
+    every 8 K steps (256 k) and add it to a running total (score_chunk < 0: the chain).  Read back: the per-row maxima the tile
     kernel leaves in the workspace (csrc/mutual_nn.hip::layout), compared with the float64 maxima."""
     gen = torch.Generator().manual_seed(5)
     C, nA, nB = 1024, 3000, 1100
@@ -463,12 +463,11 @@ def test_mutual_nn_scores_are_accumulated_in_chunks_of_256_products(dev, monkeyp
     for form in ("0", "1"):
         monkeypatch.setenv("RFX_MNN_FORM", form)
         for chunk in ("8", "0"):
-            monkeypatch.setenv("RFX_MNN_CHUNK", chunk)
             ws = torch.zeros(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=dev)
             i1 = torch.empty(nB, dtype=torch.int64, device=dev); i2 = torch.empty_like(i1)
             cnt = torch.zeros(1, dtype=torch.int32, device=dev)
             ops._call("rfx_mutual_nn_f32", dev, ops._p(Ad), nA, nA, ops._p(Bd), nB, nB, C, ops._p(None), ops._p(i1), ops._p(i2), ops._p(cnt),
-                      ops._p(ws))
+                      ops._p(ws), 256 if chunk == "8" else -1)
             rowval = ws[o_rowval:o_rowval + 4 * nA].view(torch.float32).cpu().double()
             err[form, chunk] = float(((rowval - ref) ** 2).mean().sqrt())
             n = int(cnt.item())
@@ -481,17 +480,17 @@ def test_mutual_nn_scores_are_accumulated_in_chunks_of_256_products(dev, monkeyp
     assert err["0", "8"] < 1.5 * e_cpu
 
 
-def test_scores_equal_the_hosts_torch_mm_bit_for_bit_once_calibrated(dev, monkeypatch):
+def test_scores_equal_the_hosts_torch_mm_bit_for_bit_with_the_hosts_chunk(dev):
     """The reference's score is torch.mm on the HOST (utils/outil.py:34): MKL's sgemm sums k as an fma chain inside blocks of KC
-    products and adds the block sums (KC = 192 on the GPU box's EPYC, 384 on a Xeon).  ops.calibrate_score_sums() -- run before the
-    first mutual-NN launch of a process -- probes KC on the host (ops.host_sgemm_k_block) and sets the kernels' chunk length to it:
-    the per-row score maxima the tile kernel leaves in its workspace then EQUAL torch.mm's on the same features.  Asserted: the
-    setter works and the calibrated sums are at least as close to torch.mm as the uncalibrated default; the share of bit-equal rows
-    is printed (measured 1.0 on the round-4 box, profiles/r04_mm_blocking_probe.json) -- it is a property of the host's BLAS build,
-    so it is reported, and only asserted when the probe found the host's blocking."""
+    products and adds the block sums (KC = 192 on the GPU box's EPYC, 384 on a Xeon).  A pipeline built with score_chunk="host"
+    resolves KC once at construction (ops.resolve_score_chunk -> ops.host_sgemm_k_block) and passes it to every mutual-NN launch
+    (ABI 8: an argument, no process-wide state): the per-row score maxima the tile kernel leaves in its workspace then EQUAL
+    torch.mm's on the same features.  Asserted: the argument is honoured per call (two chunk lengths interleaved give their own
+    sums), a bad value is refused, the default (0) is 256 products, and the host's chunk is at least as close to torch.mm as the
+    default; the share of bit-equal rows is printed (measured 1.0 on the round-4 box, profiles/r04_mm_blocking_probe.json) -- it is
+    a property of the host's BLAS build, so it is only asserted when the probe found the host's blocking."""
     from rfx import _lib
     lib = _lib.load()
-    monkeypatch.delenv("RFX_MNN_CHUNK", raising=False)
     gen = torch.Generator().manual_seed(9)
     C, nA, nB = 1024, 3000, 1100
     A = F.normalize(torch.relu(torch.randn(C, nA, generator=gen)), dim=0)
@@ -501,29 +500,28 @@ def test_scores_equal_the_hosts_torch_mm_bit_for_bit_once_calibrated(dev, monkey
     o_rowval = 2 * al(((nB + 127) // 128) * nA * 4) + 2 * al(((nA + 127) // 128) * nB * 4)
     Ad, Bd = A.to(dev), B.to(dev)
 
-    def rowmax():
+    def rowmax(chunk):
         ws = torch.zeros(lib.rfx_mutual_nn_ws_bytes(nA, nB), dtype=torch.uint8, device=dev)
         i1 = torch.empty(nB, dtype=torch.int64, device=dev); i2 = torch.empty_like(i1)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        ops._call("rfx_mutual_nn_f32", dev, ops._p(Ad), nA, nA, ops._p(Bd), nB, nB, C, ops._p(None), ops._p(i1), ops._p(i2), ops._p(cnt), ops._p(ws))
+        ops._call("rfx_mutual_nn_f32", dev, ops._p(Ad), nA, nA, ops._p(Bd), nB, nB, C, ops._p(None), ops._p(i1), ops._p(i2), ops._p(cnt), ops._p(ws),
+                  chunk)
         return ws[o_rowval:o_rowval + 4 * nA].view(torch.float32).cpu()
-    kc = ops.host_sgemm_k_block()
-    prev = lib.rfx_mutual_nn_set_chunk(8)
-    try:
-        r8 = rowmax()
-        assert lib.rfx_mutual_nn_set_chunk(32) == 8                      # returns the previous value; 32 steps = one chain over 1024
-        chain = rowmax()
-        assert not torch.equal(chain, r8)
-        share8 = float((r8 == cpu).float().mean())
-        print("host sgemm K block: %s; rows bit-equal to torch.mm with chunks of 256: %.3f" % (kc, share8))
-        if kc and kc % 32 == 0:
-            lib.rfx_mutual_nn_set_chunk(kc // 32)
-            rk = rowmax()
-            share = float((rk == cpu).float().mean())
-            print("... with chunks of %d (calibrated): %.3f, max |d| %.2e" % (kc, share, float((rk - cpu).abs().max())))
-            assert share >= 0.99 and share >= share8
-    finally:
-        lib.rfx_mutual_nn_set_chunk(prev)
+    r8 = rowmax(256)
+    chain = rowmax(-1)
+    assert torch.equal(rowmax(0), r8)                                    # 0 = the library default = 256 products
+    assert torch.equal(rowmax(1024), chain)                              # one chunk over all of C = the chain
+    assert not torch.equal(chain, r8) and torch.equal(rowmax(256), r8)   # per call: nothing sticks between launches
+    with pytest.raises(_lib.RfxError):
+        rowmax(100)                                                      # not a multiple of 32 products
+    kc, src = ops.resolve_score_chunk("host")
+    share8 = float((r8 == cpu).float().mean())
+    print("score chunk for this host: %d (%s); rows bit-equal to torch.mm with chunks of 256: %.3f" % (kc, src, share8))
+    if "host probe" in src:
+        rk = rowmax(kc)
+        share = float((rk == cpu).float().mean())
+        print("... with chunks of %d (the host's): %.3f, max |d| %.2e" % (kc, share, float((rk - cpu).abs().max())))
+        assert share >= 0.99 and share >= share8
 
 
 # ------------------------------------------------------------------ RANSAC

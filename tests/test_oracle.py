@@ -536,25 +536,36 @@ def test_fused_tail_patch_choice_and_packed_weight_layout():
 
 
 
-def test_host_sgemm_probe_and_score_chunk_setter():
-    """Host logic of the score calibration (no GPU needed): ops.host_sgemm_k_block() finds the K blocking with which a float32
+def test_host_sgemm_probe_and_score_chunk_resolution():
+    """Host logic of the score chunk (no GPU needed): ops.host_sgemm_k_block() finds the K blocking with which a float32
     emulation reproduces THIS host's torch.mm (the reference's score product, utils/outil.py:34) bit for bit -- 384 on the authoring
-    container's Xeon, 192 on the GPU box's EPYC (profiles/r04_mm_blocking_probe.json) -- and ops.calibrate_score_sums() hands it to the
-    library as a chunk length in K steps of 32 (rfx_mutual_nn_set_chunk returns the previous value)."""
+    container's Xeon, 192 on the GPU box's EPYC (profiles/r04_mm_blocking_probe.json) -- and ops.resolve_score_chunk() turns a
+    pipeline's ``score_chunk`` argument into (products per chunk, origin): the value every rfx_mutual_nn*_f32 call of that pipeline
+    carries explicitly since ABI 8 (no process-wide setter, no probe inside a launch)."""
     from rfx import ops
     lib = _lib.load()
+    assert not hasattr(lib, "rfx_mutual_nn_set_chunk")                     # ABI 7's process-wide setter is gone
     kc = ops.host_sgemm_k_block()
     assert kc in (None, 128, 192, 256, 384, 512, 1024)
     assert ops.host_sgemm_k_block() == kc                                  # cached
-    prev = lib.rfx_mutual_nn_set_chunk(8)
+    env = os.environ.pop("RFX_SCORE_CHUNK", None)
     try:
-        assert lib.rfx_mutual_nn_set_chunk(5) == 8 and lib.rfx_mutual_nn_set_chunk(-3) == 5 and lib.rfx_mutual_nn_set_chunk(8) == 0
-        ops._SCORES_CALIBRATED = False
-        ops.calibrate_score_sums()
-        assert lib.rfx_mutual_nn_set_chunk(8) == (kc // 32 if kc else 8)
+        assert ops.resolve_score_chunk(None) == (256, "default (fixed 256 products)")          # the FALLBACK is pinned: 256
+        assert ops.resolve_score_chunk("default")[0] == 256
+        assert ops.resolve_score_chunk(192) == (192, "argument") and ops.resolve_score_chunk("384")[0] == 384
+        assert ops.resolve_score_chunk(0)[0] == -1 and ops.resolve_score_chunk(-5)[0] == -1    # one chain
+        with pytest.raises(ValueError):
+            ops.resolve_score_chunk(100)
+        v, src = ops.resolve_score_chunk("host")
+        assert v == (kc if kc else 256) and (("host probe" in src) if kc else ("fallback" in src))
+        os.environ["RFX_SCORE_CHUNK"] = "192"
+        assert ops.resolve_score_chunk(None) == (192, "RFX_SCORE_CHUNK")
+        os.environ["RFX_SCORE_CHUNK"] = "host"
+        assert ops.resolve_score_chunk(None)[0] == v
     finally:
-        lib.rfx_mutual_nn_set_chunk(prev)
-        ops._SCORES_CALIBRATED = False
+        os.environ.pop("RFX_SCORE_CHUNK", None)
+        if env is not None:
+            os.environ["RFX_SCORE_CHUNK"] = env
     if kc:                                                                 # the emulation the probe relies on, on a second, independent problem
         import numpy as np
         g = torch.Generator().manual_seed(3)
@@ -569,3 +580,33 @@ def test_host_sgemm_probe_and_score_chunk_setter():
                 acc = (acc.astype(np.float64) + np.outer(a[k], b[k])).astype(np.float32)
             tot = (tot.astype(np.float64) + acc).astype(np.float32)
         assert float((tot != mm).mean()) <= 1e-4
+
+
+def test_lapack_worker_processes_return_the_in_process_bits():
+    """The exact mode's host stage (ops.lapack_dlt -> rfx/_lapack.py): numpy's batched SVD is a serial loop, so large batches of
+    flagged 4-point samples are dealt to persistent worker PROCESSES -- per system the same ``np.linalg.svd(A)[2][:, 8]``
+    (utils/outil.py:84-86) of the same numpy build on the same data.  Pinned here: the workers' null vectors equal the in-process
+    call bit for bit, on general systems AND on rank-deficient ones (three points collinear in both images: the 2-D null space
+    whose LAPACK pick is rounding noise -- exactly the systems the exact mode exists for), in order, for ragged slice sizes; a
+    dead worker degrades to the in-process solve."""
+    from rfx import ops, _lapack
+    rng = np.random.RandomState(0)
+    k = 1201
+    X, Y = rng.rand(k, 4, 3).astype(np.float32), rng.rand(k, 4, 3).astype(np.float32)
+    X[:500, 2] = 0.5 * (X[:500, 0] + X[:500, 1])
+    Y[:500, 2] = 0.5 * (Y[:500, 0] + Y[:500, 1])
+    X[..., 2] = Y[..., 2] = 1.0
+    serial = np.concatenate([ops.lapack_dlt(X[i:i + 300], Y[i:i + 300]) for i in range(0, k, 300)])    # < 768 systems: in-process
+    _lapack.stop()
+    os.environ["RFX_LAPACK_WORKERS"] = "3"
+    try:
+        assert _lapack.start() == 3 and _lapack.start() == 3
+        par = ops.lapack_dlt(X, Y)
+        assert par.dtype == np.float32 and np.array_equal(par, serial)
+        _lapack._workers[1].kill()
+        _lapack._workers[1].wait()
+        assert np.array_equal(ops.lapack_dlt(X, Y), serial) and not _lapack._workers      # fell back, pool dropped
+        assert np.array_equal(ops.lapack_dlt(X, Y), serial) and len(_lapack._workers) == 3  # and comes back on the next call
+    finally:
+        os.environ.pop("RFX_LAPACK_WORKERS", None)
+        _lapack.stop()
