@@ -1,9 +1,9 @@
 #!/bin/bash
 # ONE parametrised GPU-box script (replaces the per-experiment gpu_r0N_*.sh wrappers of earlier rounds).
-#   gpurun --timeout 1800 -- 'bash scripts/gpu.sh <step> [<step> ...]'     outputs under gpurun_out/$TAG (default r04)
-# steps: ref tests smoke bench bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
+#   gpurun --timeout 1800 -- 'bash scripts/gpu.sh <step> [<step> ...]'     outputs under gpurun_out/$TAG (default r05)
+# steps: ref tests smoke bench sweeps_full bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-TAG=${TAG:-r04}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+TAG=${TAG:-r05}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 for step in "$@"; do
   echo "=== $step ($(date +%T))"
   case $step in
@@ -24,6 +24,12 @@ for step in "$@"; do
     sweeps)     # full 64-pair first-homography sweeps (device vs reference) + the reference against itself on the same box
                 for c in ${SWEEP_CFGS:-qs ev}; do timeout 1200 python tests/run_parity_sweep.py $c 64 2>&1 | tail -1 | cut -c1-900; cp gpurun_out/parity_sweep_${c}_64.json $OUT/parity_sweep_${c}_64pairs.json
                   timeout 900 python oracle/parity_sweep.py --config $c --stability --threads 8 --budget 300 --records $OUT/oracle_vs_oracle_${c}_64pairs.json 2>&1 | tail -1 | cut -c1-900; done ;;
+    sweeps_full) # VERDICT r4 #1a: first-homography sweeps over ALL seeds (qs 0..127, ev 0..159) with the host-resolved score chunk, then the
+                # reference against itself on the same seeds (last: cut first if the budget runs out)
+                timeout 900 python tests/run_parity_sweep.py qs ${QS_N:-128} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_qs_${QS_N:-128}.json $OUT/parity_sweep_qs_${QS_N:-128}pairs.json
+                timeout 1200 python tests/run_parity_sweep.py ev ${EV_N:-160} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_${EV_N:-160}.json $OUT/parity_sweep_ev_${EV_N:-160}pairs.json
+                timeout 900 python oracle/parity_sweep.py --config qs --stability --threads 8 --budget 500 --seeds $(seq 0 $((${QS_N:-128}-1))) --records $OUT/oracle_vs_oracle_qs_${QS_N:-128}pairs.json 2>&1 | tail -1 | cut -c1-900
+                timeout 1200 python oracle/parity_sweep.py --config ev --stability --threads 8 --budget 800 --seeds $(seq 0 $((${EV_N:-160}-1))) --records $OUT/oracle_vs_oracle_ev_${EV_N:-160}pairs.json 2>&1 | tail -1 | cut -c1-900 ;;
     mmprobe)    timeout 120 python scripts/mm_blocking_probe.py --out $OUT/mm_blocking_probe.json 2>&1 | tail -8 ;;
     ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
     ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;
