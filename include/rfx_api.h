@@ -422,6 +422,16 @@ int rfx_gather_matches_f32(const int64_t* idx1, const int64_t* idx2, const int32
 int rfx_draw_samples_i64(const int32_t* n, int64_t* samples, int N, int batch, uint64_t seed, uint64_t stream_id,
                          const int32_t* pair_ids, void* stream);
 
+/* (ABI 8) The keep map CoarseAlign.getCoarse of variants A / C multiplies the target features with before EVERY mutual matching
+ * (quick_start/coarseAlignFeatMatch.py:136-143, evaluation/evalYFCC/coarseAlignFeatMatch.py:158-166), for the active pairs of a
+ * batch: keep[k][cell] = 1.0 where (1 - fg) bilinear-resized (align_corners=False) to the (rt, ct) target feature map exceeds
+ * 0.5, else 0.0; fg = ((mask + (1 - bg)) > 0.5) as in evaluation/evalYFCC/evaluation.py:239.  keep (n_active, rt*ct) is what
+ * rfx_mutual_nn_batched_f32 takes as maskB -- the per-round re-matching of the YFCC driver shape stays on the device.
+ * mask (batch,h,w) 0/1 floats or NULL together with bg == NULL (nothing explained, no background: all ones);
+ * bg (batch,h,w) or NULL (= all ones); active (n_active) int32 or NULL (= 0..n_active-1). */
+int rfx_keep_mask_f32(const float* mask, const float* bg, const int32_t* active, int n_active, int h, int w, int rt, int ct,
+                      float* keep, void* stream);
+
 /* CoarseAlign.getCoarse of the evaluation variant up to the match lists (evaluation/evalHpatch/coarseAlignFeatMatch.py:
  * 156-170) for the active pairs of a batch: fg = ((mask + (1 - bg)) > 0.5), MtExtend = 1 - fg bilinear-resized
  * (align_corners=False) to the (rt, ct) target feature map and thresholded at 0.5 -- evaluated only at the cells the cached

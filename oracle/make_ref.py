@@ -40,8 +40,8 @@ MODULES = [
     "evaluation/evalHpatch/coarseAlignFeatMatch.py", "evaluation/evalHpatch/evaluation.py", "evaluation/evalHpatch/utils.py",
     "evaluation/evalHpatch/getResults.py",
     "evaluation/evalKITTI/coarseAlignFeatMatch.py", "evaluation/evalKITTI/evaluation.py", "evaluation/evalKITTI/getResults.py",
-    "evaluation/evalCorr/getResults.py",
-    "evaluation/evalYFCC/coarseAlignFeatMatch.py",
+    "evaluation/evalCorr/getResults.py", "evaluation/evalCorr/coarseAlignFeatMatch.py", "evaluation/evalCorr/evaluation.py",
+    "evaluation/evalYFCC/coarseAlignFeatMatch.py", "evaluation/evalYFCC/evaluation.py",
 ]
 # scripts whose functions / loops ref_loader extracts (the module level of these parses argv and walks a dataset)
 EXTRACT = [

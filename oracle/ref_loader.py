@@ -94,6 +94,28 @@ def _extract(rel_path):
 _loaded = {}
 
 
+def _imresize(arr, size, interp="bilinear", mode=None):
+    """``scipy.misc.imresize`` as evaluation/evalYFCC/evaluation.py:23,201,212 and evaluation/evalCorr/evaluation.py:24,186 call it
+    (a 2-D array, ``size`` = (rows, cols)).  Third-party code that is NOT in /root/reference and not in the scipy the reference's
+    own requirements.txt:110 pins (1.10.1 -- the function was removed in scipy 1.3.0, so the two scripts cannot even be imported
+    under their pinned environment): restated from its last release, scipy 1.2.3 ``scipy/misc/pilutil.py`` -- ``toimage`` with
+    ``bytescale`` (non-uint8 data are stretched from [min, max] to [0, 255], a constant array becomes all zeros; + 0.5, truncate),
+    an 8-bit 'L' image, ``Image.resize((cols, rows), resample)``, ``fromimage``.  PARITY-UNPINNED against the original binary
+    (absent); pinned on its documented behaviour.  The drop-in launcher installs the same restatement
+    (ransac-flow_amd/dropin/run_reference_script.py), so both runs of a script see the same background map."""
+    import PIL.Image as Image
+    data = np.asarray(arr)
+    if data.ndim != 2:
+        raise NotImplementedError("imresize stand-in: 2-D arrays only (what the evaluation scripts pass)")
+    if data.dtype != np.uint8:
+        cmin, cmax = data.min(), data.max()
+        cscale = (cmax - cmin) or 1
+        data = (((data - cmin) * (255.0 / cscale)).clip(0, 255) + 0.5).astype(np.uint8)
+    im = Image.frombytes("L", (data.shape[1], data.shape[0]), data.tobytes())
+    resample = {"nearest": 0, "lanczos": 1, "bilinear": 2, "bicubic": 3, "cubic": 3}[interp]
+    return np.asarray(im.resize((int(size[1]), int(size[0])), resample=resample))
+
+
 def _install_stubs():
     # 1. .cuda() -> identity
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -188,7 +210,7 @@ def _install_stubs():
     # eval variants import scipy.misc.imresize (removed from scipy) and segEval
     import scipy
     sm = types.ModuleType("scipy.misc")
-    sm.imresize = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("imresize stub"))
+    sm.imresize = _imresize
     sys.modules["scipy.misc"] = sm
     scipy.misc = sm
     sys.modules.setdefault("segEval", types.ModuleType("segEval"))

@@ -6,7 +6,8 @@
 The counterpart of ``ransac-flow_amd/dropin/run_reference_script.py`` (which runs the same script on the MI355X drop-ins): here
 the script's imports resolve to the REFERENCE's own modules (``coarseAlignFeatMatch``, ``outil``, ``model`` from the tree
 ``oracle/ref_loader.py`` found: /root/reference, or the byte-compiled oracle/_ref) under ref_loader's three stubs (``.cuda()``
--> identity, stand-in torchvision / kornia).  Used by the GPU tests to compare an unchanged script's outputs on the device
+-> identity, stand-in torchvision / kornia / scipy.misc.imresize; for evalYFCC the CoarseAlign instance is switched to its own
+``use_cuda=False`` branch after construction).  Used by the GPU tests to compare an unchanged script's outputs on the device
 with the outputs of the reference's own CPU run of the same command on the same box.
 
 ``--rfx-ransac-seed S``: reseed the CPU generator with S + k before the k-th ``outil.RANSAC`` call (utils/outil.py:120 draws
@@ -44,6 +45,22 @@ def main():
             n[0] += 1
             return real(*a, **k)
         outil.RANSAC = ransac
+    if os.path.basename(os.path.dirname(script)) == "evalYFCC":
+        # evaluation/evalYFCC/evaluation.py:143 hard-codes ``use_cuda=True`` and its CoarseAlign then builds small tensors with
+        # ``torch.device("cuda")`` (evalYFCC/coarseAlignFeatMatch.py:154-155,161,176) -- next to ``.cuda()`` (identity here) the one
+        # other place a CPU run of that script names the device.  The class carries its own CPU branch (``use_cuda=False``:
+        # :113-114,122-123,141-143,157): the CPU oracle switches the instance to it right after construction, nothing else changes
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("coarseAlignFeatMatch", ref_loader.ref_path("evaluation/evalYFCC/coarseAlignFeatMatch.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+
+        class CoarseAlign(mod.CoarseAlign):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                self.use_cuda = False
+        mod.CoarseAlign = CoarseAlign
+        sys.modules["coarseAlignFeatMatch"] = mod
     torch.set_num_threads(int(os.environ.get("RFX_CPU_THREADS", "8")))
     sys.argv = [script] + rest
     os.chdir(os.path.dirname(script))

@@ -70,6 +70,11 @@ __device__ __forceinline__ bool keep_cell(const float* __restrict__ mask, const 
     return fmaf(r1, ly, __fmul_rn(r0, hy)) > 0.5f;
 }
 
+__global__ __launch_bounds__(256) void fill_ones_kernel(float* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1.0f;
+}
+
 // One workgroup per active pair: the cached matches of pair b that fall outside the explained region, in order.
 __global__ __launch_bounds__(1024) void filter_matches_kernel(
     const int64_t* __restrict__ idx1, const int64_t* __restrict__ idx2, const int32_t* __restrict__ count, int cap,
@@ -126,6 +131,21 @@ __global__ __launch_bounds__(1024) void filter_matches_kernel(
         if (kept) kept[i] = -1;
     }
     if (t == 0) n_out[k] = ntot;
+}
+
+// The whole keep map of the active pairs: what CoarseAlign.getCoarse of variants A / C multiplies the target features with before
+// EVERY mutual matching (quick_start/coarseAlignFeatMatch.py:136-143, evaluation/evalYFCC/coarseAlignFeatMatch.py:158-166) --
+// keep[k][cell] = 1 where the bilinear-resized (1 - fg) exceeds 0.5, fg = ((mask + (1 - bg)) > 0.5).
+__global__ __launch_bounds__(256) void keep_mask_kernel(const float* __restrict__ mask, const float* __restrict__ bg,
+                                                        const int32_t* __restrict__ active, int h, int w, int rt, int ct, float sh,
+                                                        float sw, float* __restrict__ keep) {
+    const int k = blockIdx.y, b = active ? active[k] : k;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= rt * ct) return;
+    const size_t HW = (size_t)h * w;
+    const float* m = mask + (size_t)b * HW;
+    const float* g = bg ? bg + (size_t)b * HW : nullptr;
+    keep[(size_t)k * rt * ct + cell] = keep_cell(m, g, h, w, sh, sw, cell / ct, cell % ct) ? 1.0f : 0.0f;
 }
 
 // ---- accept rule ----------------------------------------------------------------------------------------------------
@@ -250,6 +270,24 @@ extern "C" int rfx_filter_matches_f32(const int64_t* idx1, const int64_t* idx2, 
     const float sh = (float)h / (float)rt, sw = (float)w / (float)ct;      // as rfx_resize_bilinear_f32 (align_corners = 0)
     hipLaunchKernelGGL(filter_matches_kernel, dim3(n_active), dim3(1024), 0, rfx_stream(stream), idx1, idx2, count, cap, active,
                        mask, bg, h, w, rt, ct, sh, sw, xa, ya, xb, yb, match1, match2, n_out, kept);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_keep_mask_f32(const float* mask, const float* bg, const int32_t* active, int n_active, int h, int w, int rt,
+                                 int ct, float* keep, void* stream) {
+    if (!keep || n_active <= 0 || h <= 0 || w <= 0 || rt <= 0 || ct <= 0) return RFX_E_ARG;
+    if (n_active > 65535) return RFX_E_LIMIT;
+    if (!mask && !bg) {                      // nothing explained, no background map: every cell is kept
+        hipLaunchKernelGGL(fill_ones_kernel, dim3(((size_t)n_active * rt * ct + 255) / 256), dim3(256), 0, rfx_stream(stream), keep,
+                           (size_t)n_active * rt * ct);
+        RFX_LAUNCH_CHECK();
+        return RFX_OK;
+    }
+    const float sh = (float)h / (float)rt, sw = (float)w / (float)ct;      // as rfx_resize_bilinear_f32 (align_corners = 0)
+    if (!mask) return RFX_E_ARG;             // a background map without a mask: the caller passes a zero mask
+    hipLaunchKernelGGL(keep_mask_kernel, dim3((rt * ct + 255) / 256, n_active), dim3(256), 0, rfx_stream(stream), mask, bg, active, h,
+                       w, rt, ct, sh, sw, keep);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
 }

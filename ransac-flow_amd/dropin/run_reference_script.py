@@ -105,10 +105,22 @@ def install_misc_shims():
     if not hasattr(scipy, "misc") or not hasattr(scipy.misc, "imresize"):
         sm = types.ModuleType("scipy.misc")
 
-        def imresize(arr, size, *a, **k):
+        def imresize(arr, size, interp="bilinear", mode=None):
+            """scipy.misc.imresize (removed in scipy 1.3; evaluation/evalYFCC/evaluation.py:23,201,212, evalCorr/evaluation.py:24,186)
+            for the 2-D arrays those scripts pass, restated from scipy 1.2.3 scipy/misc/pilutil.py: bytescale of non-uint8 data
+            ([min, max] -> [0, 255]; a constant array -> zeros), 8-bit image, PIL resize to (cols, rows), back to an array."""
             import numpy as np
             import PIL.Image as Image
-            return np.asarray(Image.fromarray(arr).resize((size[1], size[0]), Image.BILINEAR))
+            data = np.asarray(arr)
+            if data.ndim != 2:
+                raise NotImplementedError("imresize stand-in: 2-D arrays only")
+            if data.dtype != np.uint8:
+                cmin, cmax = data.min(), data.max()
+                cscale = (cmax - cmin) or 1
+                data = (((data - cmin) * (255.0 / cscale)).clip(0, 255) + 0.5).astype(np.uint8)
+            im = Image.frombytes("L", (data.shape[1], data.shape[0]), data.tobytes())
+            resample = {"nearest": 0, "lanczos": 1, "bilinear": 2, "bicubic": 3, "cubic": 3}[interp]
+            return np.asarray(im.resize((int(size[1]), int(size[0])), resample=resample))
         sm.imresize = imresize
         sys.modules["scipy.misc"] = sm
         scipy.misc = sm

@@ -70,6 +70,7 @@ SIGNATURES = {
     "rfx_draw_samples_i64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "rfx_filter_matches_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 4
                                + [c_void_p] * 9),
+    "rfx_keep_mask_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p]),
     "rfx_multih_accept_ws_bytes": (c_size_t, [c_int]),
     "rfx_multih_accept_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3 + [c_double, c_int] + [c_void_p] * 7
                               + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),

@@ -876,6 +876,27 @@ def filter_matches(idx1, idx2, count, active, mask, bg, rt, ct, xa, ya, xb, yb, 
     return (m1, m2, n, kept) if want_kept else (m1, m2, n)
 
 
+def keep_mask(mask, bg, active, rt, ct, n=None, hw=None):
+    """The (a, rt*ct) 0/1 keep map of variant A / C's getCoarse for the active pairs (rfx_keep_mask_f32): what the per-call
+    mutual matching takes as its column mask.  ``mask`` (B,h,w) float32 or None (nothing explained yet; then ``n`` = number of
+    pairs and ``hw`` = (h, w) are required and a zero mask is used when a background map is given)."""
+    bgd = _dev(bg, "bg") if bg is not None else None
+    act = _dev(active, "active", torch.int32) if active is not None else None
+    if mask is None:
+        dev_ = bgd.device if bgd is not None else hw[2]
+        h, w = (bgd.shape[1], bgd.shape[2]) if bgd is not None else (int(hw[0]), int(hw[1]))
+        B = bgd.shape[0] if bgd is not None else int(n)
+        m = torch.zeros((B, h, w), dtype=torch.float32, device=dev_) if bgd is not None else None
+    else:
+        m = _dev(mask, "mask")
+        B, h, w = m.shape
+        dev_ = m.device
+    a = B if act is None else act.shape[0]
+    keep = torch.empty((a, int(rt) * int(ct)), dtype=torch.float32, device=dev_)
+    _call("rfx_keep_mask_f32", _one_device(keep, m, bgd, act), _p(m), _p(bgd), _p(act), a, h, w, int(rt), int(ct), _p(keep))
+    return keep
+
+
 class MultiHRecords:
     """The fixed-size per-pair result records of the multi-homography drivers (what
     evaluation/evalHpatch/evaluation.py:254-260 saves per pair), one float32 row per pair so that ONE all_gather moves them:

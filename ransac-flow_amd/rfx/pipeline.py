@@ -127,7 +127,8 @@ class AlignPipeline:
             return self._device_draw(torch.tensor([n], dtype=torch.int32, device=self.dev), ids, epoch, 0)[0]
         return torch.randint(n, (it, 4))
 
-    DRAW_TAG = dict(multi_h=0, coarse=1, kitti=2)       # which driver draws: part of the Philox stream id when pair_ids are given
+    # which driver draws: part of the Philox stream id when pair_ids are given
+    DRAW_TAG = dict(multi_h=0, coarse=1, kitti=2, variant_c_select=3, variant_c=4)
 
     def _draw_epoch(self, pair_ids, driver="multi_h", draw_epoch=0):
         """The key of a driver call's device draws besides (seed, round): ``pair_ids`` given (the caller's ABSOLUTE pair ids,
@@ -196,10 +197,15 @@ class AlignPipeline:
             srcs.append(norm)
             if i == mid:
                 IsT = raw
+        ItT, tnorm = self.prepare_target_device(tgt_u8)
+        return dict(src=srcs, tgt=tnorm, IsTensor=IsT, ItTensor=ItT, B=B)
+
+    def prepare_target_device(self, tgt_u8):
+        """The target half of prepare_device: raw uint8 (N,H,W,3) -> (ItTensor raw, normalised), resized like setTarget does."""
+        mode = "max" if self.variant == "A" else "min"
         th, tw = tgt_u8.shape[1], tgt_u8.shape[2]
         nw, nh = resize_dims(tw, th, self.minSize, mode)
-        ItT, tnorm = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, nw, nh), IMAGENET_MEAN, IMAGENET_STD)
-        return dict(src=srcs, tgt=tnorm, IsTensor=IsT, ItTensor=ItT, B=B)
+        return ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, nw, nh), IMAGENET_MEAN, IMAGENET_STD)
 
     # ---------------------------------------------------------------- coarse stage
     def features(self, prep):
@@ -582,7 +588,8 @@ class AlignPipeline:
         m = ops.resize_bilinear(md, (H, W), align_corners=False)
         match12, match21 = m[:B], m[B:]
         flow12, inb, flowUp = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True, want_flow_up=True, out_hw=(H, W))
-        match = match12 * ops.grid_sample(match21, flowUp) * inb.unsqueeze(1)
+        # (match12 * cycle) * in-bounds, left to right like the reference expression (evalKITTI/evaluation.py:75-77), one kernel
+        match = ops.match_score(match12[:, 0], ops.grid_sample(match21, flowUp)[:, 0], inb).unsqueeze(1)
         return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8,
                     match21Down8=match21Down8)
 
@@ -724,6 +731,156 @@ class AlignPipeline:
             outs[b]["mask"] = Mask[b]
             outs[b]["nbH"] = nb[b]
             outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
+        return outs
+
+    # ---------------------------------------------------------------- YFCC / Corr driver shape (variant C)
+    def pred_flow_mask_cycle(self, IsTensor, featt, flowCoarse):
+        """PredFlowMask of evaluation/evalYFCC/evaluation.py:32-58 (= evalCorr/evaluation.py:29-56) for a batch: the Hpatch form
+        (pred_flow_mask) with the CYCLE-CHECKED matchability -- match = match12 * grid_sample(match21, flowUp) * in-bounds(flow12)
+        -- all at the target's resolution, target features handed in."""
+        IsSample = ops.grid_sample(IsTensor, flowCoarse)
+        feats = ops.l2norm(self.feat(IsSample))
+        B = IsTensor.shape[0]
+        c = self._corr_both(featt, feats)                                  # corr12 | corr21 from one pass
+        flowDown8 = self.flow(c[:B], False)
+        md = self.match(c, False)
+        match12Down8, match21Down8 = md[:B], md[B:]
+        H, W = flowCoarse.shape[1], flowCoarse.shape[2]
+        m = ops.resize_bilinear(md, (H, W), align_corners=False)
+        flow12, inb, flowUp = ops.compose_flow(flowDown8, flowCoarse, clamp=True, want_inb=True, want_flow_up=True)
+        match = ops.match_score(m[:B, 0], ops.grid_sample(m[B:], flowUp)[:, 0], inb).unsqueeze(1)     # left to right, like the reference
+        return dict(flow12=flow12, match=match, flowDown8=flowDown8, match12Down8=match12Down8, match21Down8=match21Down8)
+
+    def multi_h_variant_c(self, src_u8, tgt_candidates_u8, maxCoarse=10, maskRegionTh=0.01, It_bg=None, sample_fn=None, records=None,
+                          want_lists=True, pair_ids=None, draw_epoch=0):
+        """The driver of evaluation/evalYFCC/evaluation.py:176-292 for a batch of B pairs in lock-step, everything on the device.
+
+        ``src_u8`` (B,H,W,3) uint8: the sources; ``tgt_candidates_u8``: K tensors (B,Hk,Wk,3) -- candidate k of every pair (the
+        script's four rotations of the target, :189; K = 1 = evalCorr-like use without a search).
+        1. *candidate search* (:191-208): source pyramid features once; per candidate: target features, the variant-C getCoarse --
+           keep map of the candidate's background (ops.keep_mask) -> mutual matching against the MASKED target features (the 0/1
+           column mask of rfx_mutual_nn_batched_f32) -> RANSAC -- and nbInlier = the winner's inlier count (0 for the (None, [])
+           sentinel: np.sum(InlierMask) counts distinct target cells, and mutual matches have distinct target cells); the chosen
+           candidate is the FIRST maximum (np.argmax, :210).  One host sync: the (B,K) count table, from which the pairs are
+           grouped by the shape of their chosen candidate.
+        2. *multi-homography loop* (:238-275) per shape group: every round RE-MATCHES -- keep map of the explained-region mask ->
+           masked mutual matching -> RANSAC -> warp -> pred_flow_mask_cycle -> accept rule / mask update / record store
+           (rfx_multih_accept_f32 mode 0: the same rule as the Hpatch loop) -- with ONE host readback per round (accept flags).
+        ``It_bg``: K tensors (B,Hk,Wk) (1 = foreground to explain, as the script's It_bg after :212) at the candidates' RESIZED
+        target size, or None (all ones).  ``sample_fn(b, n, nbIter)``: explicit draws (parity mode), called per pair in ascending
+        order, first for the candidates k = 0..K-1 with >= 4 matches, then per round.  Device draws are keyed by (seed, pair id,
+        candidate / round) with their own driver tags.
+        Returns a list of B dicts: H / flowDown8 / matchDown8 lists, mask, nbH, candidate (the chosen k), nbInlier (K counts)."""
+        dev = self.dev
+        B, K = src_u8.shape[0], len(tgt_candidates_u8)
+        host_draw = sample_fn is not None or self.draw == "host"
+        degen = self._degenerate_mode(host_draw)
+        prep = self.prepare_device(src_u8, tgt_candidates_u8[0])
+        feats = self.features(prep)
+        featA, nA, ldA = feats["featA"], feats["nA"], feats.get("ldA", feats["nA"])
+        cand = []                                                         # per candidate: ItTensor, featB, rt, ct, Wt, Ht
+        for k, t8 in enumerate(tgt_candidates_u8):
+            if k == 0:
+                ItT, fB, rt, ct, Wt, Ht = prep["ItTensor"], feats["featB"], feats["rt"], feats["ct"], feats["Wt"], feats["Ht"]
+            else:
+                ItT, tn = self.prepare_target_device(t8)
+                ft = ops.l2norm(self.trunk(tn))
+                rt, ct = ft.shape[2], ft.shape[3]
+                Wt, Ht = cell_coords_cached(rt, ct, dev)
+                fB = ft.view(B, 1024, rt * ct)
+            cand.append(dict(ItT=ItT, featB=fB, rt=rt, ct=ct, Wt=Wt, Ht=Ht,
+                             bg=None if It_bg is None or It_bg[k] is None else It_bg[k].to(dev).float().contiguous()))
+
+        def search(c, fA, maskB, n_pairs, draw_fn):
+            """variant C's getCoarse for a batch: masked mutual matching -> matches -> draw -> RANSAC."""
+            f = dict(featA=fA, featB=c["featB_sel"], nA=nA, ldA=ldA, nB=c["rt"] * c["ct"])
+            idx1, idx2, cnt = self._mutual_batched(f, n_pairs, maskB)
+            M1, M2 = ops.gather_matches(idx1, idx2, cnt, feats["HA"], feats["WA"], c["Ht"], c["Wt"])
+            smp = draw_fn(cnt)
+            bestH, inl, res = ops.ransac_h4_batched(M1, M2, cnt, smp, self.tol, degenerate=degen)
+            return cnt, bestH, res
+
+        ids, ep_sel = self._draw_epoch(pair_ids, "variant_c_select", draw_epoch)
+        ep_loop = self._draw_epoch(pair_ids, "variant_c", draw_epoch)[1]
+        all_b = list(range(B))
+        counts = []
+        for k, c in enumerate(cand):
+            c["featB_sel"] = c["featB"]
+            h, w = c["ItT"].shape[2], c["ItT"].shape[3]
+            keep = None if c["bg"] is None else ops.keep_mask(None, c["bg"], None, c["rt"], c["ct"])
+            n_k, _, res = search(c, featA, keep, B, lambda cnt, k=k: self._round_draws(all_b, cnt, sample_fn, None, ids, ep_sel, k))
+            counts.append(torch.where((res[:, 0] == 0) & (n_k >= 4), res[:, 1], torch.zeros_like(res[:, 1])))
+        table = torch.stack(counts, dim=1).cpu()                          # the ONE sync of the search: (B,K) inlier counts
+        chosen = [int(max(range(K), key=lambda k: (int(table[b, k]), -k))) for b in range(B)]     # first maximum (np.argmax)
+        outs = [dict(H=[], flowDown8=[], matchDown8=[], nbH=0, candidate=chosen[b], nbInlier=table[b].tolist()) for b in range(B)]
+        if records is not None:
+            records.rec[:, 3] = torch.tensor(chosen, dtype=torch.float32).to(dev)
+        groups = {}
+        for b in range(B):
+            groups.setdefault(tuple(cand[chosen[b]]["ItT"].shape[2:]), []).append(b)
+        IsT_all = prep["IsTensor"]
+        eye = torch.eye(3, device=dev)
+        for shape, members in groups.items():
+            # the group's tensors: pair m of the group = pair members[m] of the batch with ITS chosen candidate
+            G = len(members)
+            gi = torch.tensor(members, dtype=torch.int64, device=dev)
+            h, w = shape
+            ref_c = cand[chosen[members[0]]]
+            rt, ct = ref_c["rt"], ref_c["ct"]
+            pick = lambda key: torch.stack([cand[chosen[b]][key][b] for b in members])
+            ItT, fB = pick("ItT"), pick("featB")
+            bg = None if all(cand[chosen[b]]["bg"] is None for b in members) else torch.stack(
+                [cand[chosen[b]]["bg"][b] if cand[chosen[b]]["bg"] is not None else torch.ones((h, w), device=dev) for b in members])
+            fA, IsT = featA.index_select(0, gi), IsT_all.index_select(0, gi)
+            gids = None if ids is None else ids.index_select(0, gi)
+            featt = ops.l2norm(self.feat(ItT))
+            Mask = torch.zeros((G, h, w), dtype=torch.float32, device=dev)
+            nbH = torch.zeros(G, dtype=torch.int32, device=dev)
+            R = None
+            if records is not None:
+                if (records.h8, records.w8) != (h // 8, w // 8):
+                    raise ValueError("records were built for /8 maps of %dx%d, this group's targets give %dx%d (one MultiHRecords per "
+                                     "shape group)" % (records.h8, records.w8, h // 8, w // 8))
+                R = ops.MultiHRecords(G, records.h8, records.w8, dev, max_h=records.max_h)
+                R.rec[:, 2:4] = records.rec.index_select(0, gi)[:, 2:4]
+            nb = [0] * G
+            active = list(range(G))
+            rnd = 0
+            gc = dict(ref_c)
+            while active:
+                full = len(active) == G
+                A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
+                sel = (lambda t: t) if full else (lambda t: t.index_select(0, A.long()))
+                keep = ops.keep_mask(Mask, bg, A, rt, ct)
+                gc["featB_sel"] = sel(fB)
+                act_pairs = [members[m] for m in active]
+                n_dev, bestH, res = search(gc, sel(fA), keep, len(active), lambda cnt: self._round_draws(
+                    act_pairs, cnt, sample_fn, None, None if gids is None else sel(gids), ep_loop, rnd))
+                rnd += 1
+                Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
+                pm = self.pred_flow_mask_cycle(sel(IsT), sel(featt), ops.warp_grid(Hs, h, w))
+                accept, _ = ops.multih_accept(pm["match"], Mask, bg, A, res, n_dev, nbH, maskRegionTh, 0, bestH=bestH,
+                                              flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
+                                              match21Down8=pm["match21Down8"], records=R)
+                md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
+                acc = accept.cpu().tolist()                                                 # the round's ONE sync
+                nxt = []
+                for k, m in enumerate(active):
+                    if not acc[k]:
+                        continue
+                    if want_lists:
+                        o = outs[members[m]]
+                        o["H"].append(bestH[k])
+                        o["flowDown8"].append(pm["flowDown8"][k:k + 1])
+                        o["matchDown8"].append(md2[k:k + 1])
+                    nb[m] += 1
+                    if nb[m] <= maxCoarse:
+                        nxt.append(m)
+                active = nxt
+            for m, b in enumerate(members):
+                outs[b]["mask"], outs[b]["nbH"] = Mask[m], nb[m]
+            if R is not None:
+                records.rec.index_copy_(0, gi, R.rec)
         return outs
 
     # ---------------------------------------------------------------- KITTI two-resolution driver (SURVEY 8f1, BASELINE config 5)

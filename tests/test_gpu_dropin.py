@@ -375,3 +375,245 @@ def test_unchanged_evalkitti_script_on_a_synthetic_stream_vs_the_reference_cpu_r
             ok = ok and d <= tol
         exact += 1 if ok else 0
     assert exact >= n_pairs - 1, exact
+
+
+def _fine_ckpt(tmp_path):
+    sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+           "netMatch": weights.net_matchability_sd(3, last_std=3.0)}
+    ck = tmp_path / "ck.pth"
+    torch.save(sds, str(ck))
+    return str(ck)
+
+
+def _compare_saved_pair(g_dirs, c_dirs, tag):
+    """What evalCorr / evalYFCC save per pair (evaluation/evalCorr/evaluation.py:250-260): flow_<i>_<n>H.npy in the coarse directory
+    (the homographies) and flow_ / mask_ / maskBG_ in the fine directory.  -> (same homography count, all within tolerance)."""
+    (gc, gf), (cc, cf) = g_dirs, c_dirs
+    sel = lambda d: sorted(f for f in os.listdir(d) if f.endswith(".npy") and f.split("_")[1] == tag)
+    fg, fc = sel(gf), sel(cf)
+    assert len(fg) == 3 and len(fc) == 3, (fg, fc)                             # flow_, mask_, maskBG_
+    if fg != fc:                                                                # the names carry the homography count
+        print("pair %s: %s vs %s" % (tag, fg, fc))
+        return False, False
+    name = [f for f in fg if f.startswith("flow_")][0]
+    Hg, Hc = np.load(os.path.join(gc, name)), np.load(os.path.join(cc, name))
+    Fg, Fc = np.load(os.path.join(gf, name)), np.load(os.path.join(cf, name))
+    Mg, Mc = (np.load(os.path.join(d, name.replace("flow_", "mask_"))) for d in (gf, cf))
+    Bg, Bc = (np.load(os.path.join(d, name.replace("flow_", "maskBG_"))) for d in (gf, cf))
+    dH, dF, dM = np.abs(Hg - Hc).max(), np.abs(Fg - Fc).max(), np.abs(Mg - Mc).max()
+    print("pair %s: %d homographies, max |dH| %.2e, |d flowDown8| %.2e, |d matchDown8| %.2e, maskBG equal %s"
+          % (tag, len(Hg), dH, dF, dM, np.array_equal(Bg, Bc)))
+    return True, bool(dH <= 1e-5 and dF < 1e-3 and dM < 1e-3 and np.array_equal(Bg, Bc))
+
+
+def test_unchanged_evalcorr_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):
+    """evaluation/evalCorr/evaluation.py:1-262 ITSELF, unmodified (module-level script, MegaDepth sub-command: a csv of
+    scene / source_image / target_image rows, :157-176) over a synthetic 4-pair stream: device drop-ins (variant B CoarseAlign,
+    the multi-homography ``while`` loop :215-247 with the cycle-checked PredFlowMask :29-56) vs the reference on the host CPU.
+    Compares what the script saves per pair (:250-260)."""
+    ck = _fine_ckpt(tmp_path)
+    os.makedirs(str(tmp_path / "img" / "0001"))
+    rows = ["scene,source_image,target_image"]
+    n_pairs = 4
+    for i in range(n_pairs):
+        I1, I2 = synth.make_pair(240, 320, seed=60 + i, homography=True)
+        I1.save(str(tmp_path / "img" / "0001" / ("s%d.png" % i)))
+        I2.save(str(tmp_path / "img" / "0001" / ("t%d.png" % i)))
+        rows.append("0001,s%d.png,t%d.png" % (i, i))
+    open(str(tmp_path / "pairs.csv"), "w").write("\n".join(rows) + "\n")
+    args = ["--coarseIter", "1000", "--nbScale", "3", "--minSize", "240", "--scaleR", "1.2", "--maxCoarse", "3", "--imageNet", "--resumePth", ck]
+    tail = ["MegaDepth", "--testDir", str(tmp_path / "img"), "--testCSV", str(tmp_path / "pairs.csv"), "--endIndex", str(n_pairs)]
+    g, c = _run_both("evaluation/evalCorr/evaluation.py", args, tmp_path, 41, "--outDir", tail=tail)
+    same_nb = exact = 0
+    for i in range(n_pairs):
+        s, e = _compare_saved_pair((g + "_Coarse", g + "_Fine"), (c + "_Coarse", c + "_Fine"), str(i))
+        same_nb, exact = same_nb + s, exact + e
+    # a pair whose cached match list differs by a float32 near-tie draws other samples and may stop at another homography count
+    # (tests/test_gpu_parity_sweep.py counts and bounds those): at most one pair may
+    assert same_nb >= n_pairs - 1 and exact >= n_pairs - 1, (same_nb, exact)
+
+
+def test_unchanged_evalyfcc_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):
+    """evaluation/evalYFCC/evaluation.py:60-300 ITSELF, unmodified -- the OTHER driver shape (variant C CoarseAlign: ``setSource``
+    once, ``setTarget`` over the four rotations of the target :190-208 keeping the one with the most RANSAC inliers :210-211, then
+    the multi-homography loop :238-292 whose every ``getCoarse(fgMask)`` re-runs mutualMatching against the masked target features)
+    -- over a synthetic YFCC-shaped stream (scene pickle of index pairs + images.txt, :150-158; 3 pairs, one of them with its
+    target stored rotated by 90 degrees so that the rotation search has something to find): device drop-ins vs the reference on
+    the host CPU.  Compares rotation.json and what the script saves per pair (:277-292)."""
+    import json
+    import pickle
+    ck = _fine_ckpt(tmp_path)
+    scene = "reichstag"
+    os.makedirs(str(tmp_path / "img" / scene / "test"))
+    os.makedirs(str(tmp_path / "pairs"))
+    names, pairs = [], []
+    n_pairs = 3
+    for i in range(n_pairs):
+        I1, I2 = synth.make_pair(240, 320, seed=80 + i, homography=True)
+        if i == 1:
+            I2 = I2.rotate(270, expand=True)                 # the script's 90-degree candidate (:196) undoes this
+        for tag, im in (("s", I1), ("t", I2)):
+            names.append("%s%d.png" % (tag, i))
+            im.save(str(tmp_path / "img" / scene / "test" / names[-1]))
+        pairs.append((2 * i, 2 * i + 1))
+    open(str(tmp_path / "img" / scene / "test" / "images.txt"), "w").write("\n".join(names) + "\n")
+    pickle.dump(pairs, open(str(tmp_path / "pairs" / (scene + "-te-1000-pairs.pkl")), "wb"))
+    args = ["--coarseIter", "1000", "--nbScale", "3", "--minSize", "240", "--scaleR", "1.2", "--maxCoarse", "3", "--imageNet", "--resumePth", ck]
+    tail = ["YFCC", "--testImg", str(tmp_path / "img"), "--testPair", str(tmp_path / "pairs"), "--endIndex", str(n_pairs)]
+    g, c = _run_both("evaluation/evalYFCC/evaluation.py", args, tmp_path, 53, "--outDir", tail=tail)
+    rg, rc = (json.load(open(os.path.join(d + "_Fine", scene, "rotation.json"))) for d in (g, c))
+    print("rotations: device %s, reference %s" % (rg, rc))
+    assert rg == rc and rc["1"] == 90 and rc["0"] == 0 and rc["2"] == 0        # both sides pick the same candidate target
+    same_nb = exact = 0
+    for i in range(n_pairs):
+        s, e = _compare_saved_pair((os.path.join(g + "_Coarse", scene), os.path.join(g + "_Fine", scene)),
+                                   (os.path.join(c + "_Coarse", scene), os.path.join(c + "_Fine", scene)), str(i))
+        same_nb, exact = same_nb + s, exact + e
+    assert same_nb >= n_pairs - 1 and exact >= n_pairs - 1, (same_nb, exact)
+
+
+def test_batched_variant_c_driver_equals_the_yfcc_script_loop_on_the_dropins(dev, launcher_env):
+    """``AlignPipeline.multi_h_variant_c`` (the YFCC driver shape for a whole batch: candidate-target search by inlier count, then
+    a multi-homography loop whose every round re-matches against the masked target features, all masks on the device) against the
+    SCRIPT'S OWN LOOP -- evaluation/evalYFCC/evaluation.py:176-275 typed out below on the drop-in modules exactly as
+    ``run_reference_script.py`` sets them up (variant-C ``CoarseAlign.setSource / setTarget / getCoarse`` per call, numpy masks,
+    the script's PredFlowMask on ``model`` modules and torch.nn.functional) -- pair by pair, same draws: same chosen rotation,
+    same inlier-count table, same number of homographies, homographies and /8 outputs equal.  (The unchanged script itself is
+    compared with the reference's CPU run in test_unchanged_evalyfcc_script_...: together they tie the batched driver to the
+    reference.)"""
+    import torch.nn.functional as F
+    from rfx.pipeline import AlignPipeline
+    from rfx import ops
+    os.environ["RFX_COARSE_VARIANT"] = "C"
+    launcher = importlib.import_module("run_reference_script")
+    launcher.setup("/x/RANSAC-Flow/evaluation/evalYFCC/evaluation.py")
+    import coarseAlignFeatMatch as cam
+    import model
+    import kornia.geometry as tgm
+    trunk_sd = weights.resnet50_trunk_sd(0)
+    sds = dict(trunk=trunk_sd, feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=3.0))
+    nbIter, maxCoarse, th = 600, 3, 0.01
+    seeds = (80, 81, 82)
+    pairs = []
+    for i, s in enumerate(seeds):
+        I1, I2 = synth.make_pair(240, 320, seed=s, homography=True)
+        pairs.append((I1, I2.rotate(270, expand=True) if i == 1 else I2))    # pair 1's target is stored rotated: candidate 1 (90 degrees) undoes it
+
+    def draw(b, call, n, it):
+        return torch.randint(n, (it, 4), generator=torch.Generator().manual_seed(7000 + 100 * b + call))
+
+    # ---- the script's loop, per pair, on the drop-in modules ----------------------------------------------------------------
+    network = {"netFeatCoarse": model.FeatureExtractor(), "netCorr": model.CorrNeigh(7), "netFlowCoarse": model.NetFlowCoarse(7),
+               "netMatch": model.NetMatchability(7)}
+    for key, sd in (("netFeatCoarse", sds["feat"]), ("netFlowCoarse", sds["flow"]), ("netMatch", sds["match"])):
+        network[key].load_state_dict(sd)
+    for key in network:
+        network[key].cuda().eval()
+
+    def PredFlowMask(IsTensor, featt, flowCoarse, grid):                      # evaluation/evalYFCC/evaluation.py:32-58
+        IsSample = F.grid_sample(IsTensor, flowCoarse)
+        featsSample = F.normalize(network["netFeatCoarse"](IsSample))
+        corr12 = network["netCorr"](featt, featsSample)
+        flowDown8 = network["netFlowCoarse"](corr12, False)
+        match12Down8 = network["netMatch"](corr12, False)
+        corr21 = network["netCorr"](featsSample, featt)
+        match21Down8 = network["netMatch"](corr21, False)
+        match12 = F.interpolate(match12Down8, size=(grid.size()[1], grid.size()[2]), mode="bilinear")
+        match21 = F.interpolate(match21Down8, size=(grid.size()[1], grid.size()[2]), mode="bilinear")
+        flowUp = F.interpolate(flowDown8, size=(grid.size()[1], grid.size()[2]), mode="bilinear").permute(0, 2, 3, 1)
+        flowUp = torch.clamp(flowUp + grid, min=-1, max=1)
+        flow12 = F.grid_sample(flowCoarse.permute(0, 3, 1, 2), flowUp).permute(0, 2, 3, 1).contiguous()
+        match = match12 * F.grid_sample(match21, flowUp)
+        match = match * (((flow12.narrow(3, 0, 1) >= -1) * (flow12.narrow(3, 0, 1) <= 1)).float()
+                         * ((flow12.narrow(3, 1, 1) >= -1) * (flow12.narrow(3, 1, 1) <= 1)).float()).permute(0, 3, 1, 2)
+        return flow12, match[0, 0].cpu().numpy(), flowDown8.cpu().numpy(), torch.cat((match12Down8, match21Down8), dim=1).cpu().numpy()
+
+    import outil
+    real_ransac = outil.RANSAC
+    ref = []
+    with torch.no_grad():
+        for b, (Is, It) in enumerate(pairs):
+            calls = [0]
+
+            def ransac(nbIt, m1, m2, tol, nbPoint, Transform, b=b, calls=calls):
+                calls[0] += 1
+                return real_ransac(nbIt, m1, m2, tol, nbPoint, Transform, samples=draw(b, calls[0] - 1, len(m1), nbIt))
+            outil.RANSAC = ransac
+            cm = cam.CoarseAlign(3, nbIter, 0.05, "Homography", 240, 1, True, True, True, False, 1.2, trunk_state_dict=trunk_sd)
+            cm.setSource(Is)
+            ItList = [It, It.rotate(90, expand=True), It.rotate(180, expand=True), It.rotate(270, expand=True)]       # :189
+            nbInlier = []
+            for j in range(4):                                                                                          # :193-207
+                cm.setTarget(ItList[j])
+                Itw, Ith = cm.It.size
+                bestPara, InlierMask = cm.getCoarse(np.zeros((Ith, Itw), dtype=np.float32))
+                nbInlier.append(0 if bestPara is None else np.sum(InlierMask))
+            cm.setTarget(ItList[int(np.argmax(nbInlier))])                                                             # :209
+            Itw, Ith = cm.It.size
+            It_bg = np.ones((Ith, Itw), dtype=np.float32)
+            featt = F.normalize(network["netFeatCoarse"](cm.ItTensor))
+            gridY = torch.linspace(-1, 1, steps=Ith).view(1, -1, 1, 1).expand(1, Ith, Itw, 1)
+            gridX = torch.linspace(-1, 1, steps=Itw).view(1, 1, -1, 1).expand(1, Ith, Itw, 1)
+            grid = torch.cat((gridX, gridY), dim=3).cuda()
+            warper = tgm.HomographyWarper(Ith, Itw)
+            Mask = np.zeros((Ith, Itw), dtype=np.float32)
+            Hs, F8, M8 = [], [], []
+            nbCoarse = 0
+            while nbCoarse <= maxCoarse:                                                                               # :238-275
+                fgMask = ((Mask + (1 - It_bg)) > 0.5).astype(np.float32)
+                bestPara, InlierMask = cm.getCoarse(fgMask)
+                if bestPara is None:
+                    break
+                bestPara = torch.from_numpy(bestPara).unsqueeze(0).cuda()
+                flowCoarse = warper.warp_grid(bestPara)
+                flowFine, matchFine, flowFineDown8, matchFineDown8 = PredFlowMask(cm.IsTensor, featt, flowCoarse, grid)
+                if (matchFine * (1 - fgMask)).mean() > th or nbCoarse == 0:
+                    Hs.append(bestPara.cpu().numpy())
+                    F8.append(flowFineDown8)
+                    M8.append(matchFineDown8)
+                    nbCoarse += 1
+                    matchFine = matchFine * (1 - fgMask)
+                    Mask = ((Mask + matchFine) >= 1.0).astype(np.float32)
+                else:
+                    break
+            ref.append(dict(nbInlier=[int(v) for v in nbInlier], candidate=int(np.argmax(nbInlier)), H=Hs, F8=F8, M8=M8, mask=Mask))
+    outil.RANSAC = real_ransac
+    assert [r["candidate"] for r in ref] == [0, 1, 0] and all(len(r["H"]) >= 2 for r in ref)
+
+    # ---- the batched device driver on the same pairs, the same draws ------------------------------------------------------
+    pipe = AlignPipeline(sds, nbScale=3, nbIter=nbIter, tolerance=0.05, minSize=240, scaleR=1.2, variant="C", device=dev, draw="host",
+                         score_chunk=outil.SCORE_CHUNK)
+    up = lambda ims: torch.from_numpy(np.stack([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in ims])).to(dev)
+    src = up([p[0] for p in pairs])
+    # candidates k = 0..3 of every pair: the four rotations (pairs 0 / 2 are landscape, pair 1 is stored portrait: the batch is
+    # split by shape, as a caller batching same-size images would)
+    outs = {}
+    for group in ([0, 2], [1]):
+        cands = [up([pairs[b][1].rotate(a, expand=True) if a else pairs[b][1] for b in group]) for a in (0, 90, 180, 270)]
+        calls = {b: 0 for b in group}
+
+        def fn(b, n, it, group=group, calls=calls):
+            g = group[b]
+            calls[g] += 1
+            return draw(g, calls[g] - 1, n, it)
+        R = ops.MultiHRecords(len(group), 30, 40, dev) if group == [0, 2] else None
+        res = pipe.multi_h_variant_c(src[group], cands, maxCoarse=maxCoarse, maskRegionTh=th, sample_fn=fn, records=R)
+        for k, b in enumerate(group):
+            outs[b] = res[k]
+        if R is not None:
+            nbv, status, RH, Rf, Rm, _ = R.views()
+            for k, b in enumerate(group):
+                assert int(nbv[k]) == res[k]["nbH"] and float(status[k]) == 0.0 and int(R.rec[k, 3]) == res[k]["candidate"]
+                assert torch.equal(RH[k, 0], res[k]["H"][0]) and torch.equal(Rf[k, 1], res[k]["flowDown8"][1][0])
+    for b, r in enumerate(ref):
+        o = outs[b]
+        print("pair %d: inlier counts script %s device %s, candidate %d/%d, homographies %d/%d" %
+              (b, r["nbInlier"], o["nbInlier"], r["candidate"], o["candidate"], len(r["H"]), o["nbH"]))
+        assert o["nbInlier"] == r["nbInlier"] and o["candidate"] == r["candidate"]
+        assert o["nbH"] == len(r["H"])
+        for k in range(o["nbH"]):
+            assert np.abs(o["H"][k].cpu().numpy() - r["H"][k][0]).max() <= 1e-6, (b, k)
+            assert np.abs(o["flowDown8"][k].cpu().numpy() - r["F8"][k]).max() < 1e-5
+            assert np.abs(o["matchDown8"][k].cpu().numpy() - r["M8"][k]).max() < 1e-5
+        assert float((o["mask"].cpu().numpy() != r["mask"]).mean()) < 1e-3
