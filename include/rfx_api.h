@@ -117,9 +117,14 @@ int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, i
  * the direct kernel that stages the raw input patch in LDS.  Same epilogue and the same result, bit for bit, as
  * rfx_conv2d_f32; the weights come packed in the kernel's own LDS order so that staging is a straight copy:
  *     wP[mt][s][h][m][kk] = w[mt*128 + m, c, kh, kw]   with k = (c*3 + kh)*3 + kw = s*72 + 2*kk + h,
- *     mt < roundup(Cout,128)/128, s < ceil(Cin/8), h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout and for c >= Cin; 16-byte aligned. */
+ *     mt < roundup(Cout,128)/128, s < ceil(Cin/8), h < 2, m < 128, kk < 36; zero for mt*128 + m >= Cout and for c >= Cin; 16-byte aligned.
+ * k_chunk (ABI 8): 0 = the library's rule (chunked accumulation, bit 14 above, for K = 9 Cin >= 2048); 4 = close a chunk every 4 K
+ * steps (288 products) whatever K is -- what rfx_conv3x3_conv1x1_f32 does in its 3x3 phase since round 5, so that a Bottleneck
+ * tail run as two kernels (this one with k_chunk = 4, then the 1x1) equals the fused kernel bit for bit.  Other values: RFX_E_ARG.
+ * rfx_conv3x3_kernel_id: the instance this call launches (bits as rfx_conv2d_kernel_id). */
 int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
-                    float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
+                    float* out, int N, int Cin, int H, int W, int Cout, int act, int k_chunk, void* stream);
+int rfx_conv3x3_kernel_id(int N, int Cin, int Cout, int H, int W, int k_chunk);
 /* The same for stride 2 (pad 1, Cin % 8 == 0): out (N, Cout, (H-1)/2+1, (W-1)/2+1); wP as above.  Bit-identical to
  * rfx_conv2d_f32 on the same geometry. */
 int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
@@ -132,9 +137,12 @@ int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float* scale, con
  * rfx_conv3x3_f32) / folded BN of the 3x3 (stride 1, pad 1, Cin % 8 == 0, Cmid = 64 or 128); scale3 / shift3 of the 1x1 (Cexp % 128 == 0) and its weights in
  * "quad" order wQ3[q][h][m][j] = W3[m][8q + 2j + h] (q < Cmid/8, h < 2, m < Cexp, j < 4; 16-byte aligned): the four MFMA A
  * operands of a lane for four consecutive k-pairs are one 16-byte load, coalesced over the channels;
- * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.  Bit-identical to the two rfx_conv2d_f32 calls. */
-/* Kernel instance of the launch below (conv3x3_direct_kernel<TM, PT_C, true> as rocprofv3 prints it): bit 9 set, bit 0 =
- * 64-channel mid tile (TM = 1), bits 6-7 = output patch shape as in rfx_conv2d_kernel_id. */
+ * residual (N,Cexp,H,W) or NULL; act2 / act3 = RFX_ACT_NONE or RFX_ACT_RELU.
+ * Round 5: the 3x3 phase (K = 9 Cmid = 576 / 1152) closes a chunk every 4 K steps (288 products) into a second accumulator set --
+ * the last place the device summed a long K as ONE fma chain while the reference's oneDNN kernels block it.
+ * Bit-identical to rfx_conv3x3_f32(k_chunk = 4) followed by the 1x1 through rfx_conv2d_f32.  RFX_C3_TAIL_CHUNK=0: round 4's chain. */
+/* Kernel instance of the launch below (conv3x3_direct_kernel<TM, PT_C, true, 2, false, KCH> as rocprofv3 prints it): bit 9 set, bit 0 =
+ * 64-channel mid tile (TM = 1), bits 6-7 = output patch shape as in rfx_conv2d_kernel_id, bit 14 = chunked (KCH = 4). */
 int rfx_conv3x3_conv1x1_kernel_id(int N, int H, int W, int Cmid);
 int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
                             const float* wQ3, const float* scale3, const float* shift3, const float* residual, int act3,

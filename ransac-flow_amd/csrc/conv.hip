@@ -71,7 +71,15 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
     // LDS image per operand: [h = k&1][row (m or pixel)][kk = k>>1], 16 consecutive k-pairs per row, so that a
     // lane fetches its operands for a whole K step with four ds_read_b128.  16-byte chunk q of row r is stored
     // at chunk q ^ ((r>>2)&3): the 16-lane ds_read_b128 service groups then touch 16 distinct bank quads.
-    __shared__ __attribute__((aligned(16))) float As[2][2][BM][KK];
+    // Round 5: the A image is K-MAJOR, As[k][m].  The packed weights wT[k][m] are k-major already, so staging a
+    // float4 of 4 consecutive channels of one k row is a straight 16-byte copy -- 16 consecutive lanes write 16 consecutive
+    // 16-byte words: conflict free -- where the transposed image [h][m][kk] took a 4 x A_NJ register transpose and stores whose
+    // 16 lanes (rows 64 bytes apart, chunk = f(m >> 2)) fell on FOUR bank quads: a 4-way conflict on every weight store, the
+    // SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_ANY = 0.41-0.48 of round 4's counters (every other kernel <= 0.08).  A lane's
+    // operand for k-pair kk is then ONE ds_read_b32 at As[2kk + lrow][m] (32 consecutive lanes = 32 consecutive floats), the
+    // scheme of conv1x1.hip / mutual_nn.hip.  Same k order and pairing: bit-identical.  The gathered B image keeps its layout
+    // (its stores are conflict free: a thread owns one pixel row and writes whole swizzled 16-byte chunks).
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KK];
     __shared__ float s_scale[BM], s_shift[BM];
 
@@ -193,20 +201,9 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
     };
     auto store_lds = [&](int buf) {
         const int swb = (pc >> 2) & 3;
-        // 4x(A_NJ) register transpose: element (j, e) of the loaded rows is k-pair iA0+j of channel mg*4+e
+        // weights: k row hA + 2 (iA0 + j), channels mg*4 .. mg*4+3 -- a straight copy into the k-major image
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = mg * 4 + e;
-            float* dst = &As[buf][hA][m][0];
-            if (A_NJ == 4) {
-                f32x4 v = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
-                *reinterpret_cast<f32x4*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2)) = v;   // (m>>2)&3 == mg&3
-            } else {
-                float2 v;
-                v.x = ra[0][e]; v.y = ra[1][e];
-                *reinterpret_cast<float2*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2) + (iA0 & 3)) = v;
-            }
-        }
+        for (int j = 0; j < A_NJ; ++j) *reinterpret_cast<f32x4*>(&As[buf][hA + 2 * (iA0 + j)][mg * 4]) = ra[j];
         if (VECB) {
 #pragma unroll
             for (int j = 0; j < B_NJ; ++j) {
@@ -254,7 +251,8 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
                 const int m = (wm * TM + i) * 32 + lcol;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    af[i][q] = *reinterpret_cast<const f32x4*>(&As[cur][lrow][m][((half * 2 + q) ^ ((m >> 2) & 3)) * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[i][q][e] = As[cur][2 * ((half * 2 + q) * 4 + e) + lrow][m];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -372,7 +370,7 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
 
 int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
-                              int act, int tm, int patch_cols, hipStream_t st);  // conv3x3.hip
+                              int act, int tm, int patch_cols, hipStream_t st, bool chunked);  // conv3x3.hip
 int rfx_conv3x3_patch_cols(int N, int H, int W, bool fused);                                       // conv3x3.hip
 int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
                           float* out, int N, int Cin, int H, int W, int Cout, int act, int tm, hipStream_t st);   // conv3x3.hip
@@ -381,6 +379,7 @@ int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* sca
                               float* out, int N, int Cin, int HW, int Cout, int Mpad, int act, int tm, bool vec,
                               hipStream_t st, bool chunked);                            // conv1x1.hip
 bool rfx_conv3x3_chunked(int Cin);                                                                   // conv3x3.hip
+bool rfx_conv3x3_tail_chunked();                                                                     // conv3x3.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -406,7 +405,8 @@ static int conv_ws_env() {
 // bit 10 = the k-major 1x1 / stride 1 kernel of conv1x1.hip (conv1x1_kmajor_kernel<TM, VEC>, TM = 2 - (bits 0-1), VEC = bit 4).
 // bit 5 = the direct 3x3 / stride 1 / pad 1 kernel of conv3x3.hip (conv3x3_direct_kernel<TM, PT_C>, TM = 2 - (bits 0-1 != 0),
 // output patch 128/PT_C x PT_C with PT_C = 16 / 8 / 4 for bits 6-7 = 0 / 1 / 2).
-static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct) {
+static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, int pad, int Hout, int Wout, bool allow_direct,
+                          int k_chunk = 0) {
     static const int direct_env = getenv("RFX_CONV_DIRECT") ? atoi(getenv("RFX_CONV_DIRECT")) : 1;
     if (allow_direct && direct_env && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin >= 8) {
         const int pc = rfx_conv3x3_patch_cols(N, Hout, Wout, false), pr = 128 / pc;
@@ -414,9 +414,10 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
         const bool big = Cout > 64 && tiles * ((Cout + 127) / 128) >= 512;
         const bool rag = Cin % 8 != 0;
         // bit 14 = chunked accumulation (K >= 2048: conv3x3_direct_kernel<TM, PT_C, false, 2, false, 4>; never on the 256-pixel patches)
-        const bool chk = !rag && rfx_conv3x3_chunked(Cin);
+        // ... or asked for by the caller (k_chunk > 0: the 3x3 convolution of a Bottleneck tail run on its own, rfx_conv3x3_f32)
+        const bool chk = !rag && (rfx_conv3x3_chunked(Cin) || (k_chunk > 0 && rfx_conv3x3_tail_chunked()));
         return 32 | (big ? 0 : 1) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) |
-               (!big && !rag && !chk && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) | (rag ? 4096 : 0) | (chk ? 16384 : 0);
+               (!big && !rag && rfx_conv3x3_wide_patch(N, Hout, Wout, Cout, pc) ? 2048 : 0) | (rag ? 4096 : 0) | (chk ? 16384 : 0);
     }
     // bit 13 = the direct 3x3 / stride 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0; TM = 2 - bit 0); never inside a
     // grouped launch (it has no grouped form: a recorded group keeps the implicit-GEMM kernel)
@@ -458,15 +459,20 @@ extern "C" int rfx_conv2d_kernel_id(int N, int Cin, int Cout, int KH, int KW, in
 // it applies.  rfx_conv2d_f32 computes the same convolution, bit for bit, from the generic wT / ktab packing.
 extern "C" int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const float* shift,
                                const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int act,
-                               void* stream) {
+                               int k_chunk, void* stream) {
     if (!in || !wP || !out || N <= 0 || Cin < 8 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
     if (reinterpret_cast<uintptr_t>(wP) & 15) return RFX_E_ARG;
     if ((long long)Cin * H * W > 0x7fffffffLL) return RFX_E_LIMIT;
-    const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true);
+    if (k_chunk != 0 && k_chunk != 4) return RFX_E_ARG;                      // the one chunk length the kernels are built for
+    const int kid = conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true, k_chunk);
     const int pc = rfx_conv3x3_patch_cols(N, H, W, false);
     const int tm = (kid & 32) ? ((kid & 3) ? 1 : 2) : (Cout > 64 ? 2 : 1);   // RFX_CONV_DIRECT=0 only changes the host's choice
     return rfx_conv3x3_direct_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, (Cout + 127) / 128 * 128, act,
-                                     tm, pc, rfx_stream(stream));
+                                     tm, pc, rfx_stream(stream), (kid & 16384) != 0);
+}
+
+extern "C" int rfx_conv3x3_kernel_id(int N, int Cin, int Cout, int H, int W, int k_chunk) {
+    return conv_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W, true, k_chunk);
 }
 
 // The direct stride-2 kernel with the packed weights of rfx_conv3x3_f32 (bit 13 of rfx_conv2d_kernel_id says when it applies).

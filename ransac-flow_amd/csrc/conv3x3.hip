@@ -24,6 +24,7 @@
 #include "conv_epilogue.h"
 #include "group.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,10 @@ struct C3Args {
 #ifndef RFX_C3_DBG
 #define RFX_C3_DBG 0
 #endif
+// 1: the fused tail drains the epilogue of expansion pass p inside the K loop of pass p + 1 (round 5); 0: round 4's burst form
+#ifndef RFX_C3F_INTERLEAVE
+#define RFX_C3F_INTERLEAVE 1
+#endif
 #ifdef RFX_TRACE
 #define RFX_STAMP(i) do { if (threadIdx.x == 0 && a.trace) a.trace[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
 extern "C" long long* rfx_debug_trace_ptr();
@@ -89,11 +94,16 @@ extern "C" long long* rfx_debug_trace_ptr();
 // (KCH * 72 k) and restarted from zero: total = ((c1 + c2) + c3) + ..., the same blocked sum.  The 64 extra registers come from
 // the per-lane B-address table: baddr[kk] = pixb + (lrow ? c1[kk] : c0[kk]) with compile-time c0 / c1, i.e. ONE v_mad per
 // k-pair (lrow * (c1 - c0) + pixb) and c0 as the immediate offset of the ds_read -- 36 VALU per K step instead of 36 registers.
-// Dispatch: plain (non-fused) 128-channel instances on layers with K >= 2048 (rfx_conv3x3_chunked).
+// Dispatch (rfx_conv3x3_chunk_steps): every layer with K >= 2048, and -- round 5 -- the 3x3 convolution of a Bottleneck tail
+// (model/resnet50.py:75 in layer1 / layer2: K = 576 / 1152), fused or not: the caller's k_chunk argument (rfx_conv3x3_f32) asks
+// for the same chunks in the stand-alone kernel, so the fused tail stays bit-identical to its two-kernel form.
 template <int TM, int PTC, bool FUSE, int TN = 2, bool RAG = false, int KCH = 0>
 __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsigned bx) {
     using G = Patch<PTC, TN>;
-    static_assert(KCH == 0 || (!FUSE && !RAG && TN == 2), "chunked accumulation: plain instances only");
+    static_assert(KCH == 0 || !RAG, "chunked accumulation: Cin % 8 == 0 instances only");
+    // the 36-entry table of B offsets stays in registers where 2 x (TM * TN) accumulator tiles leave room for it (64-channel
+    // tiles of 128 pixels: 32 + 32 accumulators); the other chunked instances recompute an offset per use (one v_mad)
+    constexpr bool BTAB = KCH == 0 || TM * TN <= 2;
     static_assert(TN == 2 || (TN == 4 && TM == 1 && PTC == 16), "the 256-pixel patch is built for 64-channel tiles, 16 x 16");
     constexpr int NPX = 64 * TN;                     // output pixels of the workgroup
     constexpr int PT_R = G::PT_R, PT_C = G::PT_C, PR = G::PR, PC = G::PC, BS = G::BS, RH = G::RH;
@@ -207,14 +217,14 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
     const int pixb = (wn * TN * RH + lcol / PT_C) * BS + lcol % PT_C;   // sub-tile j adds RH rows = RH*BS
     // patch offset of tap k = c*9 + kh*3 + kw (compile-time for a constant k)
     auto koff = [](int k) constexpr { return (k / 9) * (PR * BS) + ((k % 9) / 3) * BS + (k % 9) % 3; };
-    int baddr[KCH ? 1 : KK];
-    if constexpr (KCH == 0) {
+    int baddr[BTAB ? KK : 1];
+    if constexpr (BTAB) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) baddr[kk] = pixb + (lrow ? koff(2 * kk + 1) : koff(2 * kk));
     }
-    int pixb_cur = pixb;               // KCH: laundered once per K step so that the 36 step-invariant indices are NOT hoisted
-    auto b_index = [&](int kk) {       // KCH: recomputed per use (one v_mad); else the table
-        if constexpr (KCH == 0) return baddr[kk];
+    int pixb_cur = pixb;               // !BTAB: laundered once per K step so that the 36 step-invariant indices are NOT hoisted
+    auto b_index = [&](int kk) {       // !BTAB: recomputed per use (one v_mad); else the table
+        if constexpr (BTAB) return baddr[kk];
         else return pixb_cur + koff(2 * kk) + lrow * (koff(2 * kk + 1) - koff(2 * kk));
     };
 
@@ -248,7 +258,7 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         // LDS reads run one 4-k-pair chunk ahead of the MFMAs that consume them (register double buffer)
         f32x4 af[2][TM];
         float bv[2][4 * TN];
-        if constexpr (KCH > 0) { pixb_cur = pixb; asm volatile("" : "+v"(pixb_cur)); }
+        if constexpr (!BTAB) { pixb_cur = pixb; asm volatile("" : "+v"(pixb_cur)); }
         auto read_chunk = [&](int q, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -341,7 +351,9 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                    float v = fmaf(acc[i][j][r], s_scale[ch], s_shift[ch]);
+                    float v;
+                    if constexpr (KCH > 0) v = fmaf(tot[i][j][r], s_scale[ch], s_shift[ch]);
+                    else v = fmaf(acc[i][j][r], s_scale[ch], s_shift[ch]);
                     if (a.act == RFX_ACT_RELU) v = v > 0.0f ? v : 0.0f;
                     T2[ch * NPX + (wn * TN + j) * 32 + lcol] = v;
                 }
@@ -350,6 +362,25 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
         // The weights come in "quad" order wQ[q][lrow][m][4] = W3[m][8q + 2j + lrow] (j = 0..3): the four A operands a lane
         // needs for k-pairs 4q..4q+3 are ONE 16-byte load, and consecutive lanes (channels) read consecutive 16 bytes.
         // (a 256-pixel patch runs the expansion over its two 128-pixel halves one after the other: sub-tiles ph*4 + wn*2 + j)
+        //
+        // Round 5, INTERLEAVED EPILOGUE: a pass ends with 64 outputs per lane that each cost a residual load, a
+        // fused multiply-add, an add, a max and a store -- 64 KB in + 64 KB out per pass and workgroup, issued as ONE burst
+        // during which this workgroup's share of the matrix pipe idles (~10 us of a 15 us pass, scripts/dbg/fused_trace.py).
+        // Here the finished accumulators of pass p stay in registers (`prev`) and are drained during the K loop of pass p + 1, a
+        // PV-value piece per 16-MFMA quad step: the piece's residual loads are issued one step ahead (double buffer), its
+        // arithmetic and stores run in the shadow of the step's MFMAs.  Only the LAST pass's epilogue is still exposed.  Same
+        // operations per element in the same order: bit-identical.  Taken when the tail has a residual and a ReLU (every
+        // Bottleneck of the trunk) and its folded bn3 vectors fit the 2 x 512-float LDS image; RFX_C3F_INTERLEAVE=0 (build
+        // flag) keeps round 4's burst form for A/B timing.
+        constexpr int NQ = BM / 8, AHEAD = 2;
+        constexpr int PV = 64 / NQ;                                // outputs of the previous pass finished per quad step
+        static_assert(16 % PV == 0, "a piece stays inside one 32x32 sub-tile");
+        __shared__ float s_bn3[RFX_C3F_INTERLEAVE ? 1024 : 2];
+        const bool inter = RFX_C3F_INTERLEAVE && a.Cexp <= 512 && a.Cexp >= 256 && a.res != nullptr && a.act3 == RFX_ACT_RELU;
+        if (inter) {
+            for (int i = t; i < a.Cexp; i += 256) { s_bn3[i] = a.scale3[i]; s_bn3[512 + i] = a.shift3[i]; }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int ph = 0; ph < TN / 2; ++ph) {
         size_t pix_off[2];
@@ -357,9 +388,36 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
         for (int j = 0; j < 2; ++j) pixel_of(ph * 4 + wn * 2 + j, pix_off[j], pix_ok[j]);
         const float* t2col = T2 + lrow * NPX + ph * 128 + wn * 64 + lcol;    // + 2kk*NPX (+ 32 for the second sub-tile)
-        for (int mp = 0; mp < a.Cexp; mp += 128) {
+        f32x16 prev[2][2];
+        float rres[2][PV];
+        // element offset of output v (= sub-tile s = v >> 4 [i = s >> 1, j = s & 1], accumulator register r = v & 15) of the pass at mp
+        auto out_off = [&](int v, int mp) {
+            const int s_ = v >> 4, r = v & 15;
+            return pix_off[s_ & 1] + (size_t)(mp + (wm * 2 + (s_ >> 1)) * 32 + 4 * lrow + (r & 3) + 8 * (r >> 2)) * HW;
+        };
+        auto piece_loads = [&](int piece, int slot, int pmp) {
+#pragma unroll
+            for (int u = 0; u < PV; ++u) rres[slot][u] = a.res[out_off(piece * PV + u, pmp)];
+        };
+        auto piece_finish = [&](int piece, int slot, int pmp) {
+            float x[PV];
+#pragma unroll
+            for (int u = 0; u < PV; ++u) {
+                const int v = piece * PV + u, s_ = v >> 4, r = v & 15;
+                const int ch = pmp + (wm * 2 + (s_ >> 1)) * 32 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+                x[u] = fmaf(prev[s_ >> 1][s_ & 1][r], s_bn3[ch], s_bn3[512 + ch]);
+                x[u] += rres[slot][u];
+                x[u] = x[u] > 0.0f ? x[u] : 0.0f;
+            }
+            if (pix_ok[((piece * PV) >> 4) & 1]) {
+#pragma unroll
+                for (int u = 0; u < PV; ++u) a.out[out_off(piece * PV + u, pmp)] = x[u];
+            }
+        };
+        // one pass: K loop over the mid tile; HAVE_PREV: the previous pass (at pmp) is drained piece by piece inside it
+        auto run_pass = [&](auto have_prev, int mp, int pmp, f32x16 (&acc2)[2][2]) {
+            constexpr bool HP = decltype(have_prev)::value;
             const f32x4* wq0 = reinterpret_cast<const f32x4*>(a.wT3) + (size_t)lrow * a.Cexp + mp + wm * 64 + lcol;   // + q*2*Cexp (+ 32)
-            f32x16 acc2[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -371,7 +429,6 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
             // ahead +-0; the pass's residual values fetched in front of this loop -6 % (vmcnt retires in order: the loop's weight
             // waits then wait for the residuals too); fetched inside the loop behind its last weight load -3 % on the 64-channel
             // tail, +1 % on the 128-channel one.  The epilogue's cost is not the latency of its residual loads.)
-            constexpr int NQ = BM / 8, AHEAD = 2;
             f32x4 wq[AHEAD + 1][2];
             auto load_w = [&](int q, int slot) {
                 wq[slot][0] = wq0[(size_t)q * 2 * a.Cexp];
@@ -389,10 +446,12 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
 #pragma unroll
             for (int q = 0; q < AHEAD && q < NQ; ++q) load_w(q, q);
             read_b(0, 0);
+            if constexpr (HP) piece_loads(0, 0, pmp);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (q + AHEAD < NQ) load_w(q + AHEAD, (q + AHEAD) % (AHEAD + 1));
                 if (q + 1 < NQ) read_b(q + 1, (q + 1) & 1);
+                if constexpr (HP) { if (q + 1 < NQ) piece_loads(q + 1, (q + 1) & 1, pmp); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -404,10 +463,30 @@ __device__ __forceinline__ void conv3x3_direct_body(const C3Args& a, const unsig
                     acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, b1, acc2[1][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (HP) piece_finish(q, q & 1, pmp);     // VALU + stores of the piece: issued behind the step's MFMAs
             }
-            // scale3 / shift3 are read straight from global memory (L1 hits): conv_epilogue only indexes the pointers
-            conv_epilogue<2, 2, false>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
-                                       pix_ok, true);
+        };
+        if (inter) {
+            f32x16 acc2[2][2];
+            run_pass(std::false_type{}, 0, 0, acc2);
+            for (int mp = 128; mp < a.Cexp; mp += 128) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) prev[i][j] = acc2[i][j];
+                run_pass(std::true_type{}, mp, mp - 128, acc2);
+            }
+            // the last pass's epilogue is the only exposed one
+            const int lp = a.Cexp - 128;
+            conv_epilogue<2, 2, false>(acc2, a.scale3 + lp, a.shift3 + lp, a.res, a.out, a.act3, a.Cexp, HW, lp, wm, lrow, pix_off, pix_ok, true);
+        } else {
+            for (int mp = 0; mp < a.Cexp; mp += 128) {
+                f32x16 acc2[2][2];
+                run_pass(std::false_type{}, mp, 0, acc2);
+                // scale3 / shift3 are read straight from global memory (L1 hits): conv_epilogue only indexes the pointers
+                conv_epilogue<2, 2, false>(acc2, a.scale3 + mp, a.shift3 + mp, a.res, a.out, a.act3, a.Cexp, HW, mp, wm, lrow, pix_off,
+                                           pix_ok, true);
+            }
         }
         }   // pixel halves
     }
@@ -641,6 +720,11 @@ bool rfx_conv3x3_chunked(int Cin) {
     static const int en = getenv("RFX_C3_CHUNK") ? atoi(getenv("RFX_C3_CHUNK")) : 1;
     return en && Cin % CH == 0 && Cin * 9 >= 2048;
 }
+// Round 5: the Bottleneck tails (K = 576 / 1152) close their chunks as well -- RFX_C3_TAIL_CHUNK=0: the round-4 chains (A/B runs)
+bool rfx_conv3x3_tail_chunked() {
+    static const int en = getenv("RFX_C3_TAIL_CHUNK") ? atoi(getenv("RFX_C3_TAIL_CHUNK")) : 1;
+    return en != 0;
+}
 
 // 256-pixel (16 x 16) patches for a layer whose output channels fit ONE 64-channel tile: only for launches that still fill the
 // chip two generations deep with the larger patch, never inside a grouped launch (latency-bound: more, smaller workgroups win).
@@ -697,7 +781,7 @@ static int launch_direct(C3Args& a, hipStream_t st) {
 // Cin % 8 == 0.  tm = 2 -> 128 output channels per workgroup, tm = 1 -> 64; patch_cols in {16, 8, 4}.
 int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* scale, const float* shift,
                               const float* residual, float* out, int N, int Cin, int H, int W, int Cout, int Mpad,
-                              int act, int tm, int patch_cols, hipStream_t st) {
+                              int act, int tm, int patch_cols, hipStream_t st, bool chunked) {
     C3Args a;
     a.in = in; a.wT = wP; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = Mpad;
@@ -718,7 +802,7 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
         return launch_direct<1, 4, false, 2, true>(a, st);
     }
     if (tm == 2) {
-        if (rfx_conv3x3_chunked(Cin)) {      // K >= 2048: chunks of 4 K steps (288 k)
+        if (chunked) {      // K >= 2048 (or asked for by the caller): chunks of 4 K steps (288 k)
             if (patch_cols == 16) return launch_direct<2, 16, false, 2, false, 4>(a, st);
             if (patch_cols == 8) return launch_direct<2, 8, false, 2, false, 4>(a, st);
             return launch_direct<2, 4, false, 2, false, 4>(a, st);
@@ -727,8 +811,9 @@ int rfx_conv3x3_direct_launch(const float* in, const float* wP, const float* sca
         if (patch_cols == 8) return launch_direct<2, 8>(a, st);
         return launch_direct<2, 4>(a, st);
     }
-    if (rfx_conv3x3_chunked(Cin)) {          // a single image / tiny batch runs the long-K layers on 64-channel tiles: same chunks
-        if (patch_cols == 16) return launch_direct<1, 16, false, 2, false, 4>(a, st);
+    if (chunked) {          // a single image / tiny batch runs the long-K layers on 64-channel tiles: same chunks
+        if (patch_cols == 16) return rfx_conv3x3_wide_patch(N, H, W, Cout, 16) ? launch_direct<1, 16, false, 4, false, 4>(a, st)
+                                                                               : launch_direct<1, 16, false, 2, false, 4>(a, st);
         if (patch_cols == 8) return launch_direct<1, 8, false, 2, false, 4>(a, st);
         return launch_direct<1, 4, false, 2, false, 4>(a, st);
     }
@@ -768,7 +853,7 @@ int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, 
 // tail, bit 0 = 64-channel mid tile (TM = 1), bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4).
 extern "C" int rfx_conv3x3_conv1x1_kernel_id(int N, int H, int W, int Cmid) {
     const int pc = rfx_conv3x3_patch_cols(N, H, W, true);
-    return 512 | (Cmid == 64 ? 1 : 0) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128));
+    return 512 | (Cmid == 64 ? 1 : 0) | (pc == 16 ? 0 : (pc == 8 ? 64 : 128)) | (rfx_conv3x3_tail_chunked() ? 16384 : 0);   // bit 14: chunked
 }
 
 extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const float* scale2, const float* shift2, int act2,
@@ -788,6 +873,16 @@ extern "C" int rfx_conv3x3_conv1x1_f32(const float* in, const float* wP2, const 
     a.tilesM = 1;
     hipStream_t st = rfx_stream(stream);
     const int pc = rfx_conv3x3_patch_cols(N, H, W, true);
+    if (rfx_conv3x3_tail_chunked()) {        // round 5: chunks of 4 K steps (288 k) in the 3x3 phase, like rfx_conv3x3_f32(k_chunk = 4)
+        if (Cmid == 128) {
+            if (pc == 16) return launch_direct<2, 16, true, 2, false, 4>(a, st);
+            if (pc == 8) return launch_direct<2, 8, true, 2, false, 4>(a, st);
+            return launch_direct<2, 4, true, 2, false, 4>(a, st);
+        }
+        if (pc == 16) return launch_direct<1, 16, true, 2, false, 4>(a, st);
+        if (pc == 8) return launch_direct<1, 8, true, 2, false, 4>(a, st);
+        return launch_direct<1, 4, true, 2, false, 4>(a, st);
+    }
     if (Cmid == 128) {
         if (pc == 16) return launch_direct<2, 16, true>(a, st);
         if (pc == 8) return launch_direct<2, 8, true>(a, st);

@@ -13,17 +13,32 @@ import sys
 
 import numpy as np
 
-_WORKER = r"""
-import sys, struct
+# utils/outil.py:68-87 up to the SVD: float32 products stored into a float64 8x9 system, then row 8 of Vh.  ONE source text, executed
+# in this process (small batches) and in every worker: the same numpy expressions on the same float32 inputs -> the same bits.
+_SOLVE_SRC = r"""
 import numpy as np
+def dlt_null_vectors(X, Y):
+    k = X.shape[0]
+    A = np.zeros((k, 8, 9))
+    z, o = np.zeros(k), np.ones(k)
+    for i in range(4):
+        u, v, u_, v_ = Y[:, i, 0], Y[:, i, 1], X[:, i, 0], X[:, i, 1]
+        A[:, 2 * i] = np.stack([z, z, z, -u, -v, -o, v_ * u, v_ * v, v_], axis=1)
+        A[:, 2 * i + 1] = np.stack([u, v, o, z, z, z, -u_ * u, -u_ * v, -u_], axis=1)
+    return np.linalg.svd(A)[2][:, 8]
+"""
+exec(_SOLVE_SRC)      # defines dlt_null_vectors here
+
+_WORKER = _SOLVE_SRC + r"""
+import sys, struct
 rd, wr = sys.stdin.buffer, sys.stdout.buffer
 while True:
     h = rd.read(8)
     if len(h) < 8:
         break
     k, = struct.unpack('<q', h)
-    A = np.frombuffer(rd.read(k * 576), dtype=np.float64).reshape(k, 8, 9)
-    wr.write(np.ascontiguousarray(np.linalg.svd(A)[2][:, 8]).tobytes())
+    XY = np.frombuffer(rd.read(k * 96), dtype=np.float32).reshape(2, k, 4, 3)     # 96 bytes per system instead of a 576-byte matrix
+    wr.write(np.ascontiguousarray(dlt_null_vectors(XY[0], XY[1])).tobytes())
     wr.flush()
 """
 
@@ -60,26 +75,27 @@ def stop():
             w.kill()
 
 
-def null_vectors(A, min_parallel=768):
-    """A (k,8,9) float64 -> (k,9) float64: row 8 of Vh of numpy's full SVD of every system, in order."""
-    k = A.shape[0]
+def null_vectors(X, Y, min_parallel=768):
+    """X, Y (k,4,3) float32 source / target samples -> (k,9) float64: row 8 of Vh of numpy's full SVD of every DLT system, in order."""
+    k = X.shape[0]
+    X, Y = np.ascontiguousarray(X, dtype=np.float32), np.ascontiguousarray(Y, dtype=np.float32)
     if k < min_parallel or os.environ.get("RFX_LAPACK_WORKERS") == "1":
-        return np.linalg.svd(A)[2][:, 8]
+        return dlt_null_vectors(X, Y)                  # noqa: F821 -- defined by exec(_SOLVE_SRC)
     n = start()
-    A = np.ascontiguousarray(A, dtype=np.float64)
     step = -(-k // n)
     jobs = []
     try:
         for w, i in zip(_workers, range(0, k, step)):
-            part = A[i:i + step]
-            w.stdin.write(struct.pack("<q", part.shape[0]))
-            w.stdin.write(part.tobytes())
+            m = min(step, k - i)
+            w.stdin.write(struct.pack("<q", m))
+            w.stdin.write(X[i:i + m].tobytes())
+            w.stdin.write(Y[i:i + m].tobytes())
             w.stdin.flush()
-            jobs.append((w, part.shape[0]))
-        out = [np.frombuffer(w.stdout.read(m * 72), dtype=np.float64).reshape(m, 9) for w, m in jobs]
+            jobs.append((w, m))
+        out = [np.frombuffer(w.stdout.read(m * 72), dtype=np.float64).reshape(-1, 9) for w, m in jobs]
         if any(o.shape[0] != m for o, (_, m) in zip(out, jobs)):
             raise RuntimeError("short read")
     except Exception:  # noqa: BLE001 -- a dead worker must not lose the round: drop the pool, solve in-process (same bits)
         stop()
-        return np.linalg.svd(A)[2][:, 8]
+        return dlt_null_vectors(X, Y)                  # noqa: F821
     return np.concatenate(out)

@@ -22,7 +22,8 @@ SIGNATURES = {
     "rfx_conv2d_f32": (c_int, [c_void_p] * 7 + [c_int] * 10 + [c_void_p]),
     "rfx_conv2d_tile_variant": (c_int, [c_int] * 4),
     "rfx_conv2d_kernel_id": (c_int, [c_int] * 9),
-    "rfx_conv3x3_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "rfx_conv3x3_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "rfx_conv3x3_kernel_id": (c_int, [c_int] * 6),
     "rfx_conv3x3_s2_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "rfx_conv3x3_conv1x1_kernel_id": (c_int, [c_int] * 4),
     "rfx_conv3x3_conv1x1_f32": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 6 + [c_void_p]),

@@ -35,6 +35,10 @@ class ResNet50Trunk:
                 if (p + ".downsample.0.weight") in sd:
                     blk["ds"] = ConvPlan(sd[p + ".downsample.0.weight"], _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE,
                                          device)
+                if ops.bottleneck_tail_shape(blk["c2"], blk["c3"]):
+                    # the tail's 3x3 (K = 576 / 1152) sums in chunks of 4 K steps -- in the fused kernel and, with this argument,
+                    # in the stand-alone one (RFX_FUSE_BOTTLENECK=0): the two forms stay bit-identical
+                    blk["c2"].k_chunk = 4
                 self.blocks.append(blk)
 
     def __call__(self, x):

@@ -147,6 +147,9 @@ class ConvPlan:
         w = weight.detach().float().cpu()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
         self.stride, self.pad, self.act = stride, pad, act
+        # rfx_conv3x3_f32's k_chunk: 0 = the library's rule (chunks for K >= 2048); 4 = chunks of 4 K steps whatever K is -- set by
+        # the nets on the 3x3 convolution of a Bottleneck tail, so that the two-kernel form equals the fused kernel bit for bit
+        self.k_chunk = 0
         K = self.Cin * self.KH * self.KW
         Kpad, Mpad = (K + 31) // 32 * 32, (self.Cout + 127) // 128 * 128
         wT = torch.zeros(Kpad, Mpad, dtype=torch.float32)
@@ -202,11 +205,14 @@ class ConvPlan:
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
         lib = _lib.load()
-        kid0 = lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo) if self.wP is not None else 0
+        kid0 = 0
+        if self.wP is not None:
+            kid0 = (lib.rfx_conv3x3_kernel_id(N, self.Cin, self.Cout, Ho, Wo, self.k_chunk) if self.stride == 1 else
+                    lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo))
         e0 = Profiler.begin(x)
         if kid0 & 32:
             _call("rfx_conv3x3_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
-                  _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
+                  _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act, self.k_chunk)
         elif kid0 & 8192:
             _call("rfx_conv3x3_s2_f32", _one_device(x, res, self.wP), _p(x), _p(self.wP), _p(self.scale), _p(self.shift),
                   _p(res), _p(out), N, C, H, W, self.Cout, self.act if act is None else act)
@@ -219,18 +225,22 @@ class ConvPlan:
             flops = 2.0 * N * Ho * Wo * self.Cout * self.Cin * self.KH * self.KW
             nbytes = 4.0 * (N * C * H * W + N * self.Cout * Ho * Wo * (2 if res is not None else 1)
                             + self.Cout * self.Cin * self.KH * self.KW)
-            kid = lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo)
+            kid = kid0 if (kid0 & 32) else lib.rfx_conv2d_kernel_id(N, self.Cin, self.Cout, self.KH, self.KW, self.stride, self.pad, Ho, Wo)
             Profiler.active().conv.append((kid, flops, e0, e1, (N, self.Cin, H, W, self.Cout, self.KH, self.stride), nbytes))
         return out
 
 
-def bottleneck_tail_eligible(plan2, plan3):
-    """Can conv2 (3x3) + conv3 (1x1 expansion) of a Bottleneck run as one kernel (rfx_conv3x3_conv1x1_f32)?"""
+def bottleneck_tail_shape(plan2, plan3):
+    """Do conv2 (3x3) + conv3 (1x1 expansion) of a Bottleneck have the shape rfx_conv3x3_conv1x1_f32 serves?"""
     return (plan2.KH == 3 and plan2.KW == 3 and plan2.stride == 1 and plan2.pad == 1 and plan2.Cin % 8 == 0
             and plan2.Cout in (64, 128) and plan2.act in (ACT_NONE, ACT_RELU) and plan3.KH == 1 and plan3.KW == 1
             and plan3.stride == 1 and plan3.pad == 0 and plan3.Cin == plan2.Cout and plan3.Cout % 128 == 0
-            and plan3.act in (ACT_NONE, ACT_RELU) and plan3.scale is not None
-            and os.environ.get("RFX_FUSE_BOTTLENECK", "1") != "0")
+            and plan3.act in (ACT_NONE, ACT_RELU) and plan3.scale is not None)
+
+
+def bottleneck_tail_eligible(plan2, plan3):
+    """Can conv2 (3x3) + conv3 (1x1 expansion) of a Bottleneck run as one kernel (rfx_conv3x3_conv1x1_f32)?"""
+    return bottleneck_tail_shape(plan2, plan3) and os.environ.get("RFX_FUSE_BOTTLENECK", "1") != "0"
 
 
 def bottleneck_tail(x, plan2, plan3, residual=None):
@@ -683,17 +693,11 @@ def lapack_dlt(X, Y):
     dimensional and "the reference's value" is by definition whatever LAPACK returns on THIS host (it differs between LAPACK
     builds): no device restatement can pin it, the host's own LAPACK does.  X, Y: (k,4,3) float32 numpy -> (k,3,3) float32."""
     import numpy as np
-    k = X.shape[0]
-    A = np.zeros((k, 8, 9))
-    z, o = np.zeros(k), np.ones(k)
-    for i in range(4):
-        u, v, u_, v_ = Y[:, i, 0], Y[:, i, 1], X[:, i, 0], X[:, i, 1]
-        A[:, 2 * i] = np.stack([z, z, z, -u, -v, -o, v_ * u, v_ * v, v_], axis=1)
-        A[:, 2 * i + 1] = np.stack([u, v, o, z, z, z, -u_ * u, -u_ * v, -u_], axis=1)
-    # numpy's batched svd is a serial loop of one dgesdd per system: large batches are dealt to worker processes (rfx/_lapack.py),
-    # per system the same LAPACK call on the same data -- the same bits
     from . import _lapack
-    return _lapack.null_vectors(A).reshape(k, 3, 3).astype(np.float32)
+    # the system is built and solved by ONE source text (rfx/_lapack.py: float32 products stored into a float64 8x9 matrix, numpy's
+    # full SVD, row 8 of Vh) -- in this process for small batches, dealt to worker processes for large ones (numpy's batched SVD is
+    # a serial loop of one dgesdd per system): per system the same LAPACK call on the same data, the same bits
+    return _lapack.null_vectors(X, Y).reshape(X.shape[0], 3, 3).astype(np.float32)
 
 
 def dlt4_homography(X, Y, degenerate="device", info=None):

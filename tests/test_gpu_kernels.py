@@ -853,7 +853,11 @@ def test_fused_resnet_stem_channel_group_passes(dev, cout):
     (200, 64, 30, 44, 64, 128, False),    # ... ragged in both directions, images straddling the patches, single pass
 ])
 def test_fused_bottleneck_tail_equals_two_convs(dev, case):
-    """rfx_conv3x3_conv1x1_f32 == rfx_conv2d_f32(3x3) -> rfx_conv2d_f32(1x1 + residual), bit for bit."""
+    """rfx_conv3x3_conv1x1_f32 == rfx_conv3x3_f32(3x3, k_chunk = 4) -> rfx_conv2d_f32(1x1 + residual), bit for bit: since round 5 the
+    tail's 3x3 phase (K = 576 / 1152) closes a chunk every 4 K steps (288 products) into a second accumulator set -- the K-blocked
+    sum of the reference's oneDNN kernels instead of ONE fma chain -- and the stand-alone 3x3 kernel does the same when asked
+    (ConvPlan.k_chunk = 4, which rfx/nets.py sets on every tail).  Against float64 the chunked mid tile carries less round-off
+    than the chain form (rfx_conv2d_f32's implicit-GEMM kernel on the same layer)."""
     N, Cin, H, W, Cmid, Cexp, with_res = case
     g = torch.Generator().manual_seed(sum(case[:6]))
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -865,6 +869,22 @@ def test_fused_bottleneck_tail_equals_two_convs(dev, case):
     assert ops.bottleneck_tail_eligible(p2, p3)
     xd = x.to(dev)
     r = torch.randn(N, Cexp, H, W, generator=g).to(dev) if with_res else None
-    ref = p3(p2(xd), residual=r)
+    p2.k_chunk = 4
+    mid = p2(xd)
+    ref = p3(mid, residual=r)
     out = ops.bottleneck_tail(xd, p2, p3, residual=r)
     assert out.shape == ref.shape and torch.equal(out, ref)
+    # the chain form of the same 3x3 layer (implicit GEMM), and both against float64 on the first images
+    n2 = min(N, 2)
+    chain = torch.empty((n2, Cmid, H, W), device=dev)
+    ops._call("rfx_conv2d_f32", dev, ops._p(xd[:n2].contiguous()), ops._p(p2.wT), ops._p(p2.ktab), ops._p(p2.scale), ops._p(p2.shift), ops._p(None),
+              ops._p(chain), n2, Cin, H, W, Cmid, 3, 3, 1, 1, ops.ACT_RELU)
+    w2 = p2.wT[:Cin * 9, :Cmid].t().reshape(Cmid, Cin, 3, 3).cpu().double()
+    ref64 = F.relu(F.conv2d(x[:n2].double(), w2, padding=1) * p2.scale.cpu().double().view(1, -1, 1, 1) + p2.shift.cpu().double().view(1, -1, 1, 1))
+    e_chunk = float(((mid[:n2].cpu().double() - ref64) ** 2).mean().sqrt())
+    e_chain = float(((chain.cpu().double() - ref64) ** 2).mean().sqrt())
+    print("tail 3x3, K = %d: rms error vs float64: chunked %.3e, chain %.3e" % (9 * Cin, e_chunk, e_chain))
+    if Cin * 9 > 288:                                         # more than one chunk: the sums differ, and the blocked one is closer
+        assert not torch.equal(mid[:n2], chain) and e_chunk < e_chain
+    else:
+        assert torch.equal(mid[:n2], chain)

@@ -510,11 +510,18 @@ def test_fused_tail_patch_choice_and_packed_weight_layout():
     ConvPlan packs wP exactly as include/rfx_api.h documents: wP[mt][s][h][m][kk] = w[mt*128 + m, k = s*72 + 2*kk + h]."""
     lib = _lib.load()
     fid = lib.rfx_conv3x3_conv1x1_kernel_id
-    assert fid(64, 120, 160, 64) == 512 | 1                     # 8x16 patch, 64-channel mid tile
-    assert fid(64, 60, 80, 128) == 512                           # 128-channel mid tile
-    assert fid(64, 100, 132, 64) == 512 | 1                      # W = 132: 8x16 (144) beats 16x8 (136 * 1.09) and 32x4 (132 * 1.4)
-    assert fid(64, 112, 148, 64) == 512 | 1                      # W = 148: 8x16 (160) beats 16x8 (152 * 1.09)
-    assert fid(64, 50, 66, 128) == 512 | 64                      # W = 66: 16x8 (72 * 1.09) beats 8x16 (80)
+    CH = 16384                                                   # round 5: the tails' 3x3 phase sums in chunks of 4 K steps (bit 14)
+    assert fid(64, 120, 160, 64) == 512 | 1 | CH                 # 8x16 patch, 64-channel mid tile
+    assert fid(64, 60, 80, 128) == 512 | CH                      # 128-channel mid tile
+    assert fid(64, 100, 132, 64) == 512 | 1 | CH                 # W = 132: 8x16 (144) beats 16x8 (136 * 1.09) and 32x4 (132 * 1.4)
+    assert fid(64, 112, 148, 64) == 512 | 1 | CH                 # W = 148: 8x16 (160) beats 16x8 (152 * 1.09)
+    assert fid(64, 50, 66, 128) == 512 | 64 | CH                 # W = 66: 16x8 (72 * 1.09) beats 8x16 (80)
+    # the stand-alone 3x3 of a tail asks for the same chunks (rfx_conv3x3_f32's k_chunk = 4; ops.ConvPlan.k_chunk, set by rfx/nets.py)
+    k3 = lib.rfx_conv3x3_kernel_id
+    assert k3(64, 64, 64, 120, 160, 0) == lib.rfx_conv2d_kernel_id(64, 64, 64, 3, 3, 1, 1, 120, 160) == 33 | 2048
+    assert k3(64, 64, 64, 120, 160, 4) == 33 | 2048 | CH and k3(64, 128, 128, 60, 80, 4) == 32 | CH and k3(2, 128, 128, 60, 80, 4) == 33 | CH
+    assert k3(64, 256, 256, 30, 40, 0) == k3(64, 256, 256, 30, 40, 4) == 32 | 64 | CH          # K >= 2048: chunked either way
+    assert k3(64, 49, 512, 60, 80, 4) == 32 | 4096                                              # ragged Cin: never chunked
     kid = lambda N, Cin, Cout, H, W: lib.rfx_conv2d_kernel_id(N, Cin, Cout, 3, 3, 1, 1, H, W)
     assert kid(64, 256, 256, 26, 35) & 192 == 128                # plain kernel: least area wins (32x4 -> 36 columns)
     assert kid(64, 256, 256, 28, 37) & 192 == 64                 # 40 columns either way: the wider 16x8
