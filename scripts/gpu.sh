@@ -1,7 +1,7 @@
 #!/bin/bash
 # ONE parametrised GPU-box script (replaces the per-experiment gpu_r0N_*.sh wrappers of earlier rounds).
 #   gpurun --timeout 1800 -- 'bash scripts/gpu.sh <step> [<step> ...]'     outputs under gpurun_out/$TAG (default r05)
-# steps: ref tests smoke bench sweeps_full bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
+# steps: ref tests smoke bench sweeps_full kernels_ab newtests bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 TAG=${TAG:-r05}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 for step in "$@"; do
@@ -9,6 +9,7 @@ for step in "$@"; do
   case $step in
     ref)        ls oracle/_ref oracle/_ref/utils oracle/_ref/_extract 2>&1 | head -20; python -c "import sys; sys.path.insert(0,'oracle'); import ref_loader; print(ref_loader.REF_ROOT, ref_loader.kind() if ref_loader.available() else 'ABSENT')" ;;
     tests)      timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -${TAIL:-25} ;;
+    newtests)   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_multih.py "tests/test_gpu_dropin.py" -x -q -m gpu --durations=5 2>&1 | tail -${TAIL:-25} ;;
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ;;
     bench)      RFX_PARITY_RECORDS=$OUT/bench_parity_records timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err | cut -c1-300
                 python scripts/bench_digest.py $OUT/bench.log ;;
@@ -30,6 +31,14 @@ for step in "$@"; do
                 timeout 1200 python tests/run_parity_sweep.py ev ${EV_N:-160} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_${EV_N:-160}.json $OUT/parity_sweep_ev_${EV_N:-160}pairs.json
                 timeout 900 python oracle/parity_sweep.py --config qs --stability --threads 8 --budget 500 --seeds $(seq 0 $((${QS_N:-128}-1))) --records $OUT/oracle_vs_oracle_qs_${QS_N:-128}pairs.json 2>&1 | tail -1 | cut -c1-900
                 timeout 1200 python oracle/parity_sweep.py --config ev --stability --threads 8 --budget 800 --seeds $(seq 0 $((${EV_N:-160}-1))) --records $OUT/oracle_vs_oracle_ev_${EV_N:-160}pairs.json 2>&1 | tail -1 | cut -c1-900 ;;
+    kernels_ab) # round 5 kernel A/B on ONE box: fused tails (chunked + interleaved epilogue vs the burst form vs round 4's chains), the
+                # implicit-GEMM kernel with the k-major A image vs the transposed one
+                T="tail64_120x160 tail128_60x80 tail64_240x320 tail64_100x132 tail128_50x66"
+                G="ds_256_512_s2_120x160 s2_128_128_120x160 head49_512_60x80"
+                timeout 300 python scripts/ubench/conv_bench.py --shapes $T $G pw256_1024_30x40_res fe64_240x320 --out $OUT/conv_ab_r5.json 2>&1 | tail -14
+                RFX_LIB=$PWD/ransac-flow_amd/librfx_noint.so timeout 300 python scripts/ubench/conv_bench.py --shapes $T --out $OUT/conv_ab_burst_epilogue.json 2>&1 | tail -6
+                RFX_C3_TAIL_CHUNK=0 RFX_LIB=$PWD/ransac-flow_amd/librfx_noint.so timeout 300 python scripts/ubench/conv_bench.py --shapes $T --out $OUT/conv_ab_r4_tails.json 2>&1 | tail -6
+                RFX_LIB=$PWD/ransac-flow_amd/librfx_oldconv.so timeout 300 python scripts/ubench/conv_bench.py --shapes $G --out $OUT/conv_ab_transposed_A.json 2>&1 | tail -4 ;;
     mmprobe)    timeout 120 python scripts/mm_blocking_probe.py --out $OUT/mm_blocking_probe.json 2>&1 | tail -8 ;;
     ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
     ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;
