@@ -71,15 +71,16 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
     // LDS image per operand: [h = k&1][row (m or pixel)][kk = k>>1], 16 consecutive k-pairs per row, so that a
     // lane fetches its operands for a whole K step with four ds_read_b128.  16-byte chunk q of row r is stored
     // at chunk q ^ ((r>>2)&3): the 16-lane ds_read_b128 service groups then touch 16 distinct bank quads.
-    // Round 5: the A image is K-MAJOR, As[k][m].  The packed weights wT[k][m] are k-major already, so staging a
-    // float4 of 4 consecutive channels of one k row is a straight 16-byte copy -- 16 consecutive lanes write 16 consecutive
-    // 16-byte words: conflict free -- where the transposed image [h][m][kk] took a 4 x A_NJ register transpose and stores whose
-    // 16 lanes (rows 64 bytes apart, chunk = f(m >> 2)) fell on FOUR bank quads: a 4-way conflict on every weight store, the
-    // SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_ANY = 0.41-0.48 of round 4's counters (every other kernel <= 0.08).  A lane's
-    // operand for k-pair kk is then ONE ds_read_b32 at As[2kk + lrow][m] (32 consecutive lanes = 32 consecutive floats), the
-    // scheme of conv1x1.hip / mutual_nn.hip.  Same k order and pairing: bit-identical.  The gathered B image keeps its layout
-    // (its stores are conflict free: a thread owns one pixel row and writes whole swizzled 16-byte chunks).
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    // Round 5, WHICH access conflicts: the A-side (weight) stores below.  A 16-lane group of one store instruction
+    // writes rows mg*4 + e, mg = 0..15 -- 256 bytes apart, i.e. the same bank -- at chunk (iA0 >> 2) ^ (mg & 3): FOUR bank quads for
+    // 16 lanes, a 4-way conflict on every weight store (the gathered B side writes whole rows: conflict free; all reads are
+    // conflict free).  That is the SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_ANY = 0.41-0.48 of round 4's counters.  The cure that
+    // needs no second packed weight array -- a K-MAJOR A image As[k][m] (straight 16-byte copies, ds_read_b32 operands, the scheme
+    // of conv1x1.hip) -- was built and measured on the layer that still lives here (1x1 / stride 2 projection 256 -> 512 at 120x160,
+    // 128 images): 91.7 vs 95.0 TFLOP/s, i.e. 3.5 % SLOWER (profiles/r05_conv_ab.jsonl): 32 ds_read_b32 per K step and wave tile
+    // instead of 8 ds_read_b128 cost more issue slots next to the ~10 VALU instructions per gathered B element than the
+    // conflicting stores (8 of ~100 LDS instructions per thread and step).  Reverted; the conflicts stay, priced at < 0.2 % of the step.
+    __shared__ __attribute__((aligned(16))) float As[2][2][BM][KK];
     __shared__ __attribute__((aligned(16))) float Bs[2][2][BN][KK];
     __shared__ float s_scale[BM], s_shift[BM];
 
@@ -201,9 +202,20 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
     };
     auto store_lds = [&](int buf) {
         const int swb = (pc >> 2) & 3;
-        // weights: k row hA + 2 (iA0 + j), channels mg*4 .. mg*4+3 -- a straight copy into the k-major image
+        // 4x(A_NJ) register transpose: element (j, e) of the loaded rows is k-pair iA0+j of channel mg*4+e
 #pragma unroll
-        for (int j = 0; j < A_NJ; ++j) *reinterpret_cast<f32x4*>(&As[buf][hA + 2 * (iA0 + j)][mg * 4]) = ra[j];
+        for (int e = 0; e < 4; ++e) {
+            const int m = mg * 4 + e;
+            float* dst = &As[buf][hA][m][0];
+            if (A_NJ == 4) {
+                f32x4 v = {ra[0][e], ra[1][e], ra[2][e], ra[3][e]};
+                *reinterpret_cast<f32x4*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2)) = v;   // (m>>2)&3 == mg&3
+            } else {
+                float2 v;
+                v.x = ra[0][e]; v.y = ra[1][e];
+                *reinterpret_cast<float2*>(dst + (((iA0 >> 2) ^ (mg & 3)) << 2) + (iA0 & 3)) = v;
+            }
+        }
         if (VECB) {
 #pragma unroll
             for (int j = 0; j < B_NJ; ++j) {
@@ -251,8 +263,7 @@ __device__ __forceinline__ void conv2d_mfma_body(const ConvArgs& a, const unsign
                 const int m = (wm * TM + i) * 32 + lcol;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) af[i][q][e] = As[cur][2 * ((half * 2 + q) * 4 + e) + lrow][m];
+                    af[i][q] = *reinterpret_cast<const f32x4*>(&As[cur][lrow][m][((half * 2 + q) ^ ((m >> 2) & 3)) * 4]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -380,6 +391,7 @@ int rfx_conv1x1_kmajor_launch(const float* in, const float* wT, const float* sca
                               hipStream_t st, bool chunked);                            // conv1x1.hip
 bool rfx_conv3x3_chunked(int Cin);                                                                   // conv3x3.hip
 bool rfx_conv3x3_tail_chunked();                                                                     // conv3x3.hip
+bool rfx_conv3x3_s2_chunked(int Cin);                                                                // conv3x3.hip
 
 // tile choice: the largest tile that still gives >= ~2 workgroups per CU (256 CUs).
 // 0: 128x128 (conv2d_mfma_kernel<2,2>), 1: 64x128 (<1,2>), 2: 64x64 (<1,1>)
@@ -422,15 +434,18 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     // bit 13 = the direct 3x3 / stride 2 / pad 1 kernel conv3x3_s2_kernel<TM> (Cin % 8 == 0; TM = 2 - bit 0); never inside a
     // grouped launch (it has no grouped form: a recorded group keeps the implicit-GEMM kernel)
     static const int s2_env = getenv("RFX_CONV_S2") ? atoi(getenv("RFX_CONV_S2")) : 1;
-    if (allow_direct && direct_env && s2_env && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Cin % 8 == 0 && Cin >= 8 &&
-        !rfx_group_recording()) {
+    if (allow_direct && direct_env && s2_env && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Cin % 8 == 0 && Cin >= 8) {
         // its 8 x 16 output patches tile every image on their own (no stacked-batch trick at stride 2): on maps that pad badly
         // the implicit-GEMM kernel, which tiles the flattened pixel axis, wins.  Measured break-even (scripts/ubench/
         // conv_s2_bench.py, profiles/r04_conv_s2_ab.json): +8..16 % at 100 % / 94 % useful pixels, +-0 at 88 %, -12 % at 74 %.
+        // Round 5: the layers with K = 9 Cin >= 1152 sum in chunks in this kernel (bit 14) -- they take it on EVERY map and inside
+        // grouped launches too (it has a grouped form now), so that a layer's sums never depend on the map size or the batch; the
+        // shorter-K layers keep the rule above (either kernel: the same chain, bit-identical).
         const long long th = (Hout + 7) / 8, tw = (Wout + 15) / 16;
-        if ((long long)Hout * Wout * 100 >= 90 * th * 8 * tw * 16) {
+        const bool chk = rfx_conv3x3_s2_chunked(Cin);
+        if (chk || ((long long)Hout * Wout * 100 >= 90 * th * 8 * tw * 16 && !rfx_group_recording())) {
             const bool big = Cout > 64 && (long long)N * th * tw * ((Cout + 127) / 128) >= 512;
-            return 8192 | (big ? 0 : 1);
+            return 8192 | (big ? 0 : 1) | (chk ? 16384 : 0);
         }
     }
     const int variant = rfx_conv2d_tile_variant(N, Cout, Hout, Wout);
@@ -438,8 +453,9 @@ static int conv_kernel_id(int N, int Cin, int Cout, int KH, int KW, int stride, 
     static const int kmajor_env = getenv("RFX_CONV_1X1") ? atoi(getenv("RFX_CONV_1X1")) : 1;   // experiments: 0 = generic kernel
     // bit 14 = chunked accumulation (K >= 1024: conv1x1_kmajor_kernel<1, VEC, 8>, 64-channel tiles, at EVERY launch size -- a result
     // must not depend on how many pairs share the launch); RFX_C1_CHUNK=0: off
+    // round 5: from K = 512 on (layer2 conv1, layer3.0 conv1: two chunks of 256); RFX_C1_CHUNK=<min K> (0: never; 1: the default 512)
     static const int c1chunk = getenv("RFX_C1_CHUNK") ? atoi(getenv("RFX_C1_CHUNK")) : 1;
-    const bool chk = c1chunk && Cin >= 1024;
+    const bool chk = c1chunk && Cin >= (c1chunk > 1 ? c1chunk : 512);
     if (kmajor_env && one && stride == 1 && Cin % 32 == 0 && Cin >= 64 && (variant != 2 || chk) && (long long)N * Hout * Wout >= 4) {
         return 1024 | 4 | (chk ? 1 : variant) | (((long long)Hout * Wout) % 4 == 0 ? 16 : 0) | (chk ? 16384 : 0);   // conv1x1.hip
     }

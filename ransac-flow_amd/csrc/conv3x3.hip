@@ -69,9 +69,15 @@ struct C3Args {
 #ifndef RFX_C3_DBG
 #define RFX_C3_DBG 0
 #endif
-// 1: the fused tail drains the epilogue of expansion pass p inside the K loop of pass p + 1 (round 5); 0: round 4's burst form
+// 1: the fused tail drains the epilogue of expansion pass p inside the K loop of pass p + 1 (round 5, VERDICT r4 #6: "the one structural
+// conv idea still on the table"); 0 (default): the burst form.  MEASURED NEGATIVE on one box, same library otherwise
+// (profiles/r05_conv_ab.jsonl, 128 / 64 images): 64-channel tail 101.4 -> 98.2 TFLOP/s at 120x160, 101.9 -> 98.4 at 240x320, 86.8 -> 82.4 at
+// 100x132; 128-channel tail 110.0 -> 111.2 at 60x80, 86.7 -> 90.3 at 50x66 (four passes: three hidden epilogues).  The residual loads and
+// the stores of a piece share the CU's in-order vector-memory path with the expansion's weight stream (2 x 16 bytes per lane and quad
+// step from L2): spread over the K loop they delay the weights the next MFMAs wait for, which costs the 2-pass tail more than the one
+// hidden epilogue saves.  Kept as a build flag (make exp NAME=inter SRC=conv3x3 DEFS=-DRFX_C3F_INTERLEAVE=1); bit-identical either way.
 #ifndef RFX_C3F_INTERLEAVE
-#define RFX_C3F_INTERLEAVE 1
+#define RFX_C3F_INTERLEAVE 0
 #endif
 #ifdef RFX_TRACE
 #define RFX_STAMP(i) do { if (threadIdx.x == 0 && a.trace) a.trace[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
@@ -532,8 +538,11 @@ constexpr int NEL = CH * PRI * PCI;                  // 4488 input elements per 
 constexpr int NB = (NEL + 255) / 256;                // 18 per thread (the last round is partial)
 }  // namespace s2
 
-template <int TM>
-__global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
+// KCH > 0 (round 5): chunked accumulation as in conv3x3_direct_body -- ResNet-50 layer2.0 / layer3.0 conv2 (K = 1152 / 2304) and the
+// FeatureExtractor's 128 -> 256 strided convolution were the last long-K 3x3 layers summed as ONE fma chain.  The B-offset table is
+// recomputed per use there (one v_mad per k-pair) to make room for the second accumulator set.
+template <int TM, int KCH = 0>
+__device__ __forceinline__ void conv3x3_s2_body(const C3Args& a, const unsigned bx) {
     using namespace s2;
     constexpr int TN = 2, BM = 64 * TM;
     constexpr int AS_F = 2 * BM * KK, BS_F = CH * PRI * BS2;
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
     const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
     const int tilesP = a.tilesH * a.tilesW;           // patches per image
     const int nwg = a.tilesM * tilesP * a.N;
-    int bid = (int)blockIdx.x;
+    int bid = (int)bx;
     {   // XCD-aware bijective remap, m-tile fastest
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -643,14 +652,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
     };
     // ---- per-lane B addresses of the 36 k-pairs of a step
     const int pixb = (2 * (wn * TN * RH + lcol / PT_C)) * BS2 + lcol % PT_C;            // sub-tile j adds 2*RH rows of the patch
-    int baddr[KK];
+    auto koff2 = [](int k) constexpr { return (k / 9) * (PRI * BS2) + ((k % 9) / 3) * BS2 + (((k % 9) % 3) & 1) * PH + (((k % 9) % 3) >> 1); };
+    constexpr bool BTAB = KCH == 0 || TM == 1;
+    int baddr[BTAB ? KK : 1];
+    if constexpr (BTAB) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        const int k = 2 * kk + lrow;
-        const int cl = k / 9, t9 = k - cl * 9;
-        const int kh = t9 / 3, kw = t9 - kh * 3;
-        baddr[kk] = pixb + cl * (PRI * BS2) + kh * BS2 + (kw & 1) * PH + (kw >> 1);
+        for (int kk = 0; kk < KK; ++kk) baddr[kk] = pixb + (lrow ? koff2(2 * kk + 1) : koff2(2 * kk));
     }
+    int pixb_cur = pixb;
+    auto b_index = [&](int kk) {
+        if constexpr (BTAB) return baddr[kk];
+        else return pixb_cur + koff2(2 * kk) + lrow * (koff2(2 * kk + 1) - koff2(2 * kk));
+    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -658,6 +671,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f32x16 tot[KCH ? TM : 1][KCH ? TN : 1];
+    if constexpr (KCH > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
+    }
     {
         const char* base = reinterpret_cast<const char*>(inn);
 #pragma unroll
@@ -671,6 +693,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
         const char* base = reinterpret_cast<const char*>(inn + (size_t)sn * CH * HW);
         f32x4 af[2][TM];
         float bv[2][4 * TN];
+        if constexpr (!BTAB) { pixb_cur = pixb; asm volatile("" : "+v"(pixb_cur)); }
         auto read_chunk = [&](int q, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -678,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[baddr[q * 4 + e] + j * 2 * RH * BS2];
+                for (int j = 0; j < TN; ++j) bv[slot][TN * e + j] = bflat[b_index(q * 4 + e) + j * 2 * RH * BS2];
         };
         read_chunk(0, 0);
 #pragma unroll
@@ -697,6 +720,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bv[cur][TN * e + j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (KCH > 0) {
+            if ((s + 1) % KCH == 0 || s + 1 == nsteps) {      // wave-uniform: close the chunk
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
+            }
+        }
         __syncthreads();
         store_lds();
         __syncthreads();
@@ -709,7 +742,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
         pix_ok[j] = oh < Ho && ow < Wo;
         pix_off[j] = pix_ok[j] ? (size_t)n * a.Cout * HWo + (size_t)oh * Wo + ow : 0;
     }
-    conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HWo, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+    if constexpr (KCH > 0)
+        conv_epilogue<TM, TN, (TM > 1)>(tot, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HWo, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+    else
+        conv_epilogue<TM, TN, (TM > 1)>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HWo, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+}
+
+template <int TM, int KCH = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
+    conv3x3_s2_body<TM, KCH>(a, blockIdx.x);
+}
+
+// grouped form (group.h; round 5): blockIdx.y = problem -- the single-pair trunk pass keeps ONE launch per layer, and a strided
+// layer runs the same kernel (hence the same chunked sums) whatever the batch it rides in
+template <int TM, int KCH = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_group_kernel(RfxGroupArgs<C3Args> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv3x3_s2_body<TM, KCH>(g.p[y], blockIdx.x);
+}
+
+template <int TM, int KCH>
+static int c3s2_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<C3Args>(conv3x3_s2_group_kernel<TM, KCH>, 256, blob, gx, n, st);
 }
 
 }  // namespace
@@ -719,6 +774,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(C3Args a) {
 bool rfx_conv3x3_chunked(int Cin) {
     static const int en = getenv("RFX_C3_CHUNK") ? atoi(getenv("RFX_C3_CHUNK")) : 1;
     return en && Cin % CH == 0 && Cin * 9 >= 2048;
+}
+// Round 5: the stride-2 kernel's long-K layers (K >= 1152) -- RFX_C3_S2_CHUNK=0: chains
+bool rfx_conv3x3_s2_chunked(int Cin) {
+    static const int en = getenv("RFX_C3_S2_CHUNK") ? atoi(getenv("RFX_C3_S2_CHUNK")) : 1;
+    return en && Cin * 9 >= 1152;
 }
 // Round 5: the Bottleneck tails (K = 576 / 1152) close their chunks as well -- RFX_C3_TAIL_CHUNK=0: the round-4 chains (A/B runs)
 bool rfx_conv3x3_tail_chunked() {
@@ -840,7 +900,18 @@ int rfx_conv3x3_s2_launch(const float* in, const float* wP, const float* scale, 
     const long long nwg = (long long)a.tilesM * a.tilesH * a.tilesW * N;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
     if ((long long)Cin * H * W * 4 > 0xffffffffLL) return RFX_E_LIMIT;                    // 32-bit byte offsets inside one image
-    if (tm == 2) hipLaunchKernelGGL((conv3x3_s2_kernel<2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    // round 5: K = 9 Cin >= 1152 closes a chunk every 4 K steps (288 products), like the stride-1 kernel (RFX_C3_S2_CHUNK=0: chains)
+    const bool chk = rfx_conv3x3_s2_chunked(Cin);
+    if (rfx_group_recording()) {
+        if (chk) return tm == 2 ? rfx_group_record(&c3s2_group_launch<2, 4>, &a, sizeof(a), (unsigned)nwg)
+                                : rfx_group_record(&c3s2_group_launch<1, 4>, &a, sizeof(a), (unsigned)nwg);
+        return tm == 2 ? rfx_group_record(&c3s2_group_launch<2, 0>, &a, sizeof(a), (unsigned)nwg)
+                       : rfx_group_record(&c3s2_group_launch<1, 0>, &a, sizeof(a), (unsigned)nwg);
+    }
+    if (chk) {
+        if (tm == 2) hipLaunchKernelGGL((conv3x3_s2_kernel<2, 4>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_s2_kernel<1, 4>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    } else if (tm == 2) hipLaunchKernelGGL((conv3x3_s2_kernel<2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_s2_kernel<1>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

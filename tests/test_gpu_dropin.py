@@ -579,7 +579,7 @@ def test_batched_variant_c_driver_equals_the_yfcc_script_loop_on_the_dropins(dev
                     break
             ref.append(dict(nbInlier=[int(v) for v in nbInlier], candidate=int(np.argmax(nbInlier)), H=Hs, F8=F8, M8=M8, mask=Mask))
     outil.RANSAC = real_ransac
-    assert [r["candidate"] for r in ref] == [0, 1, 0] and all(len(r["H"]) >= 2 for r in ref)
+    assert [r["candidate"] for r in ref] == [0, 1, 0] and all(len(r["H"]) >= 1 for r in ref) and max(len(r["H"]) for r in ref) >= 2
 
     # ---- the batched device driver on the same pairs, the same draws ------------------------------------------------------
     pipe = AlignPipeline(sds, nbScale=3, nbIter=nbIter, tolerance=0.05, minSize=240, scaleR=1.2, variant="C", device=dev, draw="host",

@@ -471,7 +471,7 @@ def test_conv_dispatch_table_is_stable():
     variant, 2 = 1x1 specialisation, 3 = wave-specialised form (off by default), 4 = 16-byte pixel loads, 5 = direct 3x3
     kernel with bits 6-7 = output patch shape (0: 8x16, 1: 16x8, 2: 32x4), 10 = k-major 1x1 kernel, 11 = 256-pixel patches of the
     direct kernel (one 64-channel tile, large launch), 12 = its instance with a ragged last K step (Cin % 8 != 0), 13 = direct
-    3x3 / stride 2 kernel, 14 = chunked accumulation (direct 3x3 with K = 9 Cin >= 2048; k-major 1x1 with K >= 1024, 64-channel tiles)."""
+    3x3 / stride 2 kernel, 14 = chunked accumulation (direct 3x3 with K = 9 Cin >= 2048; stride-2 3x3 with K >= 1152; k-major 1x1 with K >= 512, 64-channel tiles)."""
     lib = _lib.load()
     kid = lambda N, Cin, Cout, k, s, p, Ho, Wo: lib.rfx_conv2d_kernel_id(N, Cin, Cout, k, k, s, p, Ho, Wo)
     # direct 3x3 / stride 1: big layers -> 128-channel tiles, 8x16 patches
@@ -484,9 +484,10 @@ def test_conv_dispatch_table_is_stable():
     assert kid(64, 49, 512, 3, 1, 1, 60, 80) == 32 | 4096                   # Cin % 8 != 0 -> the direct kernel's ragged instance
     assert kid(1, 49, 512, 3, 1, 1, 60, 80) == 32 | 1 | 4096                # ... a single image: 64-channel tiles fill the chip
     assert kid(64, 3, 64, 3, 1, 1, 480, 640) & 32 == 0                      # Cin < 8 (the stems' own kernels aside): implicit GEMM
-    assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 8192                       # 3x3 / stride 2 / pad 1, Cin % 8 == 0 -> direct stride-2 kernel <2>
-    assert kid(64, 64, 64, 3, 2, 1, 120, 160) == 8192 | 1                   # ... 64-channel tiles for Cout <= 64
-    assert kid(64, 128, 128, 3, 2, 1, 50, 66) & 8192 == 0                   # 50x66 pads to 56x80 (74 % useful): implicit GEMM
+    assert kid(64, 128, 128, 3, 2, 1, 60, 80) == 8192 | 16384               # 3x3 / stride 2 / pad 1, Cin % 8 == 0 -> direct stride-2 kernel <2>; K = 1152: chunked sums (round 5)
+    assert kid(64, 64, 64, 3, 2, 1, 120, 160) == 8192 | 1                   # ... 64-channel tiles for Cout <= 64; K = 576: one chain
+    assert kid(64, 128, 128, 3, 2, 1, 50, 66) == 8192 | 16384               # a chunked layer takes this kernel on EVERY map (50x66 pads to 56x80): its sums must not depend on the map
+    assert kid(64, 64, 128, 3, 2, 1, 50, 66) & 8192 == 0                    # K = 576 (a chain in either kernel): a badly padding map keeps the implicit GEMM
     assert kid(64, 12, 128, 3, 2, 1, 60, 80) & 8192 == 0                    # Cin % 8 != 0 -> implicit GEMM
     assert kid(64, 128, 128, 3, 2, 0, 59, 79) & 8192 == 0                   # pad != 1 -> implicit GEMM
     # 1x1: 16-byte pixel loads only for stride 1 and H*W % 4 == 0
@@ -497,7 +498,8 @@ def test_conv_dispatch_table_is_stable():
     assert kid(64, 256, 64, 1, 1, 0, 120, 160) == 1024 | 4 | 16 | 1         # Cout = 64 -> 64-wide channel tile
     assert kid(64, 1024, 256, 1, 1, 0, 30, 40) == 1024 | 4 | 16 | 1 | 16384  # K = 1024 (layer3 conv1): chunked sums, 64-channel tiles
     assert kid(1, 1024, 256, 1, 1, 0, 15, 20) == 1024 | 4 | 16 | 1 | 16384  # ... at every launch size (results do not depend on the batch)
-    assert kid(64, 512, 128, 1, 1, 0, 60, 80) == 1024 | 4 | 16              # K = 512: one chain
+    assert kid(64, 512, 128, 1, 1, 0, 60, 80) == 1024 | 4 | 16 | 1 | 16384  # K = 512 (layer2 conv1): two chunks of 256 since round 5
+    assert kid(64, 256, 64, 1, 1, 0, 120, 160) & 16384 == 0                 # K = 256: one chain
     assert kid(64, 48, 256, 1, 1, 0, 120, 160) == 4 | 16                    # Cin % 32 != 0 -> generic kernel
     # tiny problems fall back to the 64x64 tile
     assert kid(1, 128, 49, 1, 1, 0, 12, 16) & 3 == 2
