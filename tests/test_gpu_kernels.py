@@ -169,13 +169,13 @@ def test_direct_3x3_equals_implicit_gemm_bit_for_bit(dev, shape):
     assert torch.equal(direct, generic)
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 60, 80, 128), (16, 128, 120, 160, 256), (3, 8, 5, 3, 130), (2, 16, 1, 1, 8), (5, 24, 33, 47, 40),
-                                   (4, 64, 34, 66, 64), (9, 8, 2, 70, 32), (2, 256, 31, 53, 256), (70, 16, 17, 18, 192), (1, 8, 16, 32, 64)])
 def lib_kid(N, Cin, Cout, Ho, Wo):
     from rfx import _lib
     return _lib.load().rfx_conv2d_kernel_id(N, Cin, Cout, 3, 3, 2, 1, Ho, Wo)
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 60, 80, 128), (16, 128, 120, 160, 256), (3, 8, 5, 3, 130), (2, 16, 1, 1, 8), (5, 24, 33, 47, 40),
+                                   (4, 64, 34, 66, 64), (9, 8, 2, 70, 32), (2, 256, 31, 53, 256), (70, 16, 17, 18, 192), (1, 8, 16, 32, 64)])
 def test_direct_3x3_stride2_equals_implicit_gemm_bit_for_bit(dev, shape):
     """Round 4: rfx_conv3x3_s2_f32 (direct 3x3 / stride 2 / pad 1 kernel, input patch de-interleaved by column parity in LDS)
     == rfx_conv2d_f32 on the same layer, bit for bit -- odd and even map sizes, maps smaller than a patch, ragged channel tiles,
