@@ -50,12 +50,15 @@ __device__ __forceinline__ void mnn_close_chunk(f32x16 (&tot)[2][2], f32x16 (&ac
             for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
 }
 
-// Arg-max epilogue of a 128 x 128 score tile held in the accumulators of the 2 x 2 wavefronts (C/D layout: column = lcol,
+// Arg-max epilogue of a (128 WA) x 128 score tile held in the accumulators of the (2 WA) x 2 wavefronts (C/D layout: column = lcol,
 // row = (r&3) + 8*(r>>2) + 4*lrow): per-tile column and row maxima (value, first index) -> the workspace.  xval / xidx:
-// 2 x 128 floats / ints of LDS that no wavefront reads any more.
+// max(2 WA x 128, 2 x 128 WA) floats / ints of LDS that no wavefront reads any more.  `ta` indexes the column partials: one slot
+// per TILE row (a 256-row tile fills every second slot of the 128-row layout; the reduce kernel walks tilesA slots).
+template <int WA = 1>
 __device__ __forceinline__ void mnn_tile_epilogue(f32x16 (&acc)[2][2], const MnnArgs& a, float* xval, int* xidx, int i0, int j0,
                                                   int ta, int tb, float* rowPartVal, int* rowPartIdx, float* colPartVal,
                                                   int* colPartIdx) {
+    constexpr int NWM = 2 * WA, ROWS = 128 * WA;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -85,7 +88,8 @@ __device__ __forceinline__ void mnn_tile_epilogue(f32x16 (&acc)[2][2], const Mnn
     if (t < 128 && j0 + t < a.nB) {
         float bv = xval[t];
         int bi = xidx[t];
-        take_min_idx(bv, bi, xval[128 + t], xidx[128 + t]);
+#pragma unroll
+        for (int w = 1; w < NWM; ++w) take_min_idx(bv, bi, xval[w * 128 + t], xidx[w * 128 + t]);   // row blocks in increasing order
         colPartVal[(size_t)ta * a.nB + j0 + t] = bv;
         colPartIdx[(size_t)ta * a.nB + j0 + t] = bi;
     }
@@ -112,15 +116,15 @@ __device__ __forceinline__ void mnn_tile_epilogue(f32x16 (&acc)[2][2], const Mnn
             }
             if (lcol == 0) {
                 const int li = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
-                xval[wn * 128 + li] = bv;
-                xidx[wn * 128 + li] = bj;
+                xval[wn * ROWS + li] = bv;
+                xidx[wn * ROWS + li] = bj;
             }
         }
     __syncthreads();
-    if (t < 128 && i0 + t < a.nA) {
+    if (t < ROWS && i0 + t < a.nA) {
         float bv = xval[t];
         int bj = xidx[t];
-        take_min_idx(bv, bj, xval[128 + t], xidx[128 + t]);
+        take_min_idx(bv, bj, xval[ROWS + t], xidx[ROWS + t]);
         rowPartVal[(size_t)tb * a.nA + i0 + t] = bv;
         rowPartIdx[(size_t)tb * a.nA + i0 + t] = bj;
     }
@@ -304,10 +308,21 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
 // the arg-max skips.  The 0/1 column mask (quick_start/coarseAlignFeatMatch.py:143 multiplies the target features by it) is
 // applied to the finished accumulators: for a 0/1 mask the same values up to the sign of a zero, which no comparison sees.
 // Same k pairing and order as the kernel above: bit-identical scores.  Requires C % 32 == 0, C >= 64.
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
-    constexpr int NV = 4, NS = 16;                 // per operand, thread and K step: float4 (VEC) / floats (scalar)
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+// WA = 2 (round 5): a 256 x 128 tile on 512 threads = 4 x 2 wavefronts, ONE workgroup per CU (96 KB of LDS) instead of two
+// 128 x 128 ones: the same 8 wavefronts per CU and the same 64 x 64 wavefront tiles (64 + 64 accumulator registers), but a K step
+// stages (256 + 128) x 32 floats for 512 MFMAs where two small tiles stage 2 x (128 + 128) x 32 -- 25 % fewer operand bytes through
+// the CU's load path per MFMA (the resource the 128 x 128 form sits on: 8 B/clk/CU at full matrix rate) and 25 % fewer
+// panel (re-)fetches from L2 / the Infinity Cache.  Same k order per score: identical match lists.
+template <bool VEC, int WA = 1>
+__global__ __launch_bounds__(256 * WA, WA == 1 ? 2 : 1) void mnn_tile_kmajor_kernel(MnnArgs a) {
+    constexpr int BMA = BM * WA, NT = 256 * WA;
+    constexpr int A_TPR = VEC ? BMA / 4 : BMA;     // threads per A row
+    constexpr int A_RPR = NT / A_TPR;              // A rows per round of all threads: 8 (VEC) / 2 (scalar)
+    constexpr int NLA = BK / A_RPR;                // A loads per thread and K step: 4 / 16
+    constexpr int B_TPR = VEC ? BN / 4 : BN;
+    constexpr int B_RPR = NT / B_TPR;              // 8 * WA / 2 * WA
+    constexpr int NLB = BK / B_RPR;                // 4 / WA, 16 / WA
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BMA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -327,40 +342,46 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int tb = bid % a.tilesB, ta = bid / a.tilesB;
-    const int i0 = ta * BM, j0 = tb * BN;
-    // staging roles: VEC: row t>>5 (+8 per round), cells 4*(t&31)..+3; scalar: row t>>7 (+2 per round), cell t&127
-    const int srow = VEC ? t >> 5 : t >> 7, scol = VEC ? (t & 31) * 4 : t & 127;
-    int ca = i0 + scol, cb = j0 + scol;
+    const int i0 = ta * BMA, j0 = tb * BN;
+    // staging roles: row t / TPR (+ RPR per round), cells (t % TPR) * (VEC ? 4 : 1) ..
+    const int arow_s = t / A_TPR, acol_s = (t % A_TPR) * (VEC ? 4 : 1);
+    const int brow_s = t / B_TPR, bcol_s = (t % B_TPR) * (VEC ? 4 : 1);
+    int ca = i0 + acol_s, cb = j0 + bcol_s;
     if (VEC) { if (ca + 4 > a.ldA) ca = a.ldA - 4; if (cb + 4 > a.ldB) cb = a.ldB - 4; }
     else     { if (ca >= a.nA) ca = a.nA - 1;     if (cb >= a.nB) cb = a.nB - 1; }
-    const float* asrc = Ab + (size_t)srow * a.ldA + ca;
-    const float* bsrc = Bb + (size_t)srow * a.ldB + cb;
-    f32x4 va[VEC ? NV : 1], vb[VEC ? NV : 1];
-    float ra[VEC ? 1 : NS], rb[VEC ? 1 : NS];
+    const float* asrc = Ab + (size_t)arow_s * a.ldA + ca;
+    const float* bsrc = Bb + (size_t)brow_s * a.ldB + cb;
+    f32x4 va[VEC ? NLA : 1], vb[VEC ? NLB : 1];
+    float ra[VEC ? 1 : NLA], rb[VEC ? 1 : NLB];
     auto load_a = [&](int k0, int j) {
-        if (VEC) va[j] = *reinterpret_cast<const f32x4*>(asrc + (size_t)(k0 + 8 * j) * a.ldA);
-        else     ra[j] = asrc[(size_t)(k0 + 2 * j) * a.ldA];
+        if (VEC) va[j] = *reinterpret_cast<const f32x4*>(asrc + (size_t)(k0 + A_RPR * j) * a.ldA);
+        else     ra[j] = asrc[(size_t)(k0 + A_RPR * j) * a.ldA];
     };
     auto load_b = [&](int k0, int j) {
-        if (VEC) vb[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + 8 * j) * a.ldB);
-        else     rb[j] = bsrc[(size_t)(k0 + 2 * j) * a.ldB];
+        if (VEC) vb[j] = *reinterpret_cast<const f32x4*>(bsrc + (size_t)(k0 + B_RPR * j) * a.ldB);
+        else     rb[j] = bsrc[(size_t)(k0 + B_RPR * j) * a.ldB];
     };
     auto store_a = [&](int buf, int j) {
-        if (VEC) *reinterpret_cast<f32x4*>(&As[buf][srow + 8 * j][scol]) = va[j];
-        else     As[buf][srow + 2 * j][scol] = ra[j];
+        if (VEC) *reinterpret_cast<f32x4*>(&As[buf][arow_s + A_RPR * j][acol_s]) = va[j];
+        else     As[buf][arow_s + A_RPR * j][acol_s] = ra[j];
     };
     auto store_b = [&](int buf, int j) {
-        if (VEC) *reinterpret_cast<f32x4*>(&Bs[buf][srow + 8 * j][scol]) = vb[j];
-        else     Bs[buf][srow + 2 * j][scol] = rb[j];
+        if (VEC) *reinterpret_cast<f32x4*>(&Bs[buf][brow_s + B_RPR * j][bcol_s]) = vb[j];
+        else     Bs[buf][brow_s + B_RPR * j][bcol_s] = rb[j];
     };
-    constexpr int NL = VEC ? NV : NS;
     const int nk = a.C / BK;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) { load_a(0, j); load_b(0, j); }
+    for (int j = 0; j < NLA; ++j) load_a(0, j);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) { store_a(0, j); store_b(0, j); }
+    for (int j = 0; j < NLB; ++j) load_b(0, j);
 #pragma unroll
-    for (int j = 0; j < NL; ++j) { load_a(BK, j); load_b(BK, j); }
+    for (int j = 0; j < NLA; ++j) store_a(0, j);
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) store_b(0, j);
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) load_a(BK, j);
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) load_b(BK, j);
     __syncthreads();
 
     f32x16 acc[2][2], tot[2][2];
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
     const float* brow = &Bs[0][lrow][wn * 64 + lcol];
     for (int s = 0; s < nk; ++s) {
         const int cur = s & 1;
-        const float* ap = arow + cur * (BK * BM);
+        const float* ap = arow + cur * (BK * BMA);
         const float* bp = brow + cur * (BK * BN);
         const int k2 = (s + 2 < nk ? s + 2 : nk - 1) * BK;      // past the end: re-load the last step (never consumed)
         float af[2][4][2], bf[2][4][2];
@@ -383,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int kk = c * 4 + e;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[slot][e][i] = ap[2 * kk * BM + i * 32];
+                for (int i = 0; i < 2; ++i) af[slot][e][i] = ap[2 * kk * BMA + i * 32];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bf[slot][e][j] = bp[2 * kk * BN + j * 32];
             }
@@ -395,14 +416,14 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
             // the registers hold K step s+1: stored into the other buffer and re-loaded with step s+2 right behind the store
             if (c == 0) {
 #pragma unroll
-                for (int j = 0; j < NL; ++j) store_a(cur ^ 1, j);
+                for (int j = 0; j < NLA; ++j) store_a(cur ^ 1, j);
 #pragma unroll
-                for (int j = 0; j < NL; ++j) load_a(k2, j);
+                for (int j = 0; j < NLA; ++j) load_a(k2, j);
             } else if (c == 1) {
 #pragma unroll
-                for (int j = 0; j < NL; ++j) store_b(cur ^ 1, j);
+                for (int j = 0; j < NLB; ++j) store_b(cur ^ 1, j);
 #pragma unroll
-                for (int j = 0; j < NL; ++j) load_b(k2, j);
+                for (int j = 0; j < NLB; ++j) load_b(k2, j);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -428,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kmajor_kernel(MnnArgs a) {
                 for (int r = 0; r < 16; ++r) tot[i][j][r] *= mk;
         }
     }
-    mnn_tile_epilogue(tot, a, &As[0][0][0], reinterpret_cast<int*>(&Bs[0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx, colPartVal,
-                      colPartIdx);
+    mnn_tile_epilogue<WA>(tot, a, &As[0][0][0], reinterpret_cast<int*>(&Bs[0][0][0]), i0, j0, ta, tb, rowPartVal, rowPartIdx, colPartVal,
+                          colPartIdx);
 }
 
 __global__ __launch_bounds__(256) void mnn_reduce_kernel(MnnArgs a) {
@@ -556,9 +577,16 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
     const int form = fe ? atoi(fe) : 0;
     const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);
-    if (kmajor) {
-        if (vec) hipLaunchKernelGGL(mnn_tile_kmajor_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(mnn_tile_kmajor_kernel<false>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+    // 256 x 128 tiles (WA = 2) where the launch still gives every CU two generations of (one-per-CU) workgroups; RFX_MNN_WA=1: never
+    static const int wa_env = getenv("RFX_MNN_WA") ? atoi(getenv("RFX_MNN_WA")) : 2;
+    const long long nwg2 = (long long)((a.nA + 2 * BM - 1) / (2 * BM)) * a.tilesB;
+    if (kmajor && wa_env == 2 && nwg2 * batch >= 512) {
+        a.tilesA = (a.nA + 2 * BM - 1) / (2 * BM);
+        if (vec) hipLaunchKernelGGL((mnn_tile_kmajor_kernel<true, 2>), dim3((unsigned)nwg2, batch), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((mnn_tile_kmajor_kernel<false, 2>), dim3((unsigned)nwg2, batch), dim3(512), 0, st, a);
+    } else if (kmajor) {
+        if (vec) hipLaunchKernelGGL((mnn_tile_kmajor_kernel<true, 1>), dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((mnn_tile_kmajor_kernel<false, 1>), dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     } else if (vec) hipLaunchKernelGGL(mnn_tile_kernel<true>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(mnn_tile_kernel<false>, dim3((unsigned)nwg, batch), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
