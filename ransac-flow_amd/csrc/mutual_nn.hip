@@ -308,11 +308,15 @@ __global__ __launch_bounds__(256, 2) void mnn_tile_kernel(MnnArgs a) {
 // the arg-max skips.  The 0/1 column mask (quick_start/coarseAlignFeatMatch.py:143 multiplies the target features by it) is
 // applied to the finished accumulators: for a 0/1 mask the same values up to the sign of a zero, which no comparison sees.
 // Same k pairing and order as the kernel above: bit-identical scores.  Requires C % 32 == 0, C >= 64.
-// WA = 2 (round 5): a 256 x 128 tile on 512 threads = 4 x 2 wavefronts, ONE workgroup per CU (96 KB of LDS) instead of two
-// 128 x 128 ones: the same 8 wavefronts per CU and the same 64 x 64 wavefront tiles (64 + 64 accumulator registers), but a K step
-// stages (256 + 128) x 32 floats for 512 MFMAs where two small tiles stage 2 x (128 + 128) x 32 -- 25 % fewer operand bytes through
-// the CU's load path per MFMA (the resource the 128 x 128 form sits on: 8 B/clk/CU at full matrix rate) and 25 % fewer
-// panel (re-)fetches from L2 / the Infinity Cache.  Same k order per score: identical match lists.
+// WA = 2 (round 5 experiment; opt-in: RFX_MNN_WA=2): a 256 x 128 tile on 512 threads = 4 x 2 wavefronts, ONE workgroup
+// per CU (96 KB of LDS) instead of two 128 x 128 ones: the same 8 wavefronts per CU and the same 64 x 64 wavefront tiles (64 + 64
+// accumulator registers), but a K step stages (256 + 128) x 32 floats for 512 MFMAs where two small tiles stage 2 x (128 + 128) x 32
+// -- 25 % fewer operand bytes through the CU's load path per MFMA and 25 % fewer panel (re-)fetches from L2 / the Infinity Cache.
+// Same k order per score: identical match lists (scripts/ubench/mnn_bench.py).  MEASURED NEGATIVE on one box
+// (profiles/r05_mnn_tile_{128x128,256x128}.json): 106.7 -> 104.6 TFLOP/s at config 3's shape (64 x 13 065 x 1 200), 107.0 -> 104.5 at
+// quick_start's, 104.2 -> 98.5 at config 5's (8 x 25 747 x 8 250).  The tile kernel is therefore NOT bound by operand bytes per MFMA
+// (nor, a fortiori, by the 4.6x panel re-fetch traffic the counters show: it is served by L2 / the Infinity Cache at ~1 TB/s): one
+// barrier per K step across EIGHT wavefronts costs more than two independent 4-wave workgroups lose to each other.  128 x 128 stays.
 template <bool VEC, int WA = 1>
 __global__ __launch_bounds__(256 * WA, WA == 1 ? 2 : 1) void mnn_tile_kmajor_kernel(MnnArgs a) {
     constexpr int BMA = BM * WA, NT = 256 * WA;
@@ -577,8 +581,8 @@ static int mnn_launch(MnnArgs& a, int batch, hipStream_t st) {
     const char* fe = getenv("RFX_MNN_FORM");                  // 1: force the transposed-image kernel (tests, A/B timing)
     const int form = fe ? atoi(fe) : 0;
     const bool kmajor = form != 1 && a.C % BK == 0 && a.C >= 2 * BK && (vec ? (a.ldA >= 4 && a.ldB >= 4) : true);
-    // 256 x 128 tiles (WA = 2) where the launch still gives every CU two generations of (one-per-CU) workgroups; RFX_MNN_WA=1: never
-    static const int wa_env = getenv("RFX_MNN_WA") ? atoi(getenv("RFX_MNN_WA")) : 2;
+    // 256 x 128 tiles (WA = 2): measured slower than two 128 x 128 workgroups per CU (see the kernel) -- only with RFX_MNN_WA=2
+    static const int wa_env = getenv("RFX_MNN_WA") ? atoi(getenv("RFX_MNN_WA")) : 1;
     const long long nwg2 = (long long)((a.nA + 2 * BM - 1) / (2 * BM)) * a.tilesB;
     if (kmajor && wa_env == 2 && nwg2 * batch >= 512) {
         a.tilesA = (a.nA + 2 * BM - 1) / (2 * BM);
