@@ -39,6 +39,11 @@ for step in "$@"; do
                 RFX_LIB=$PWD/ransac-flow_amd/librfx_noint.so timeout 300 python scripts/ubench/conv_bench.py --shapes $T --out $OUT/conv_ab_burst_epilogue.json 2>&1 | tail -6
                 RFX_C3_TAIL_CHUNK=0 RFX_LIB=$PWD/ransac-flow_amd/librfx_noint.so timeout 300 python scripts/ubench/conv_bench.py --shapes $T --out $OUT/conv_ab_r4_tails.json 2>&1 | tail -6
                 RFX_LIB=$PWD/ransac-flow_amd/librfx_oldconv.so timeout 300 python scripts/ubench/conv_bench.py --shapes $G --out $OUT/conv_ab_transposed_A.json 2>&1 | tail -4 ;;
+    sweeps_more) # further seeds for the flip statistics (qs 128..383, ev 160..319): device vs reference, then reference vs reference
+                timeout 1200 python tests/run_parity_sweep.py qs 256 128 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_qs_256_from128.json $OUT/parity_sweep_qs_seeds128_383.json
+                timeout 1200 python tests/run_parity_sweep.py ev 160 160 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_160_from160.json $OUT/parity_sweep_ev_seeds160_319.json
+                timeout 1200 python oracle/parity_sweep.py --config qs --stability --threads 8 --budget 900 --seeds $(seq 128 383) --records $OUT/oracle_vs_oracle_qs_seeds128_383.json 2>&1 | tail -1 | cut -c1-900
+                timeout 1200 python oracle/parity_sweep.py --config ev --stability --threads 8 --budget 900 --seeds $(seq 160 319) --records $OUT/oracle_vs_oracle_ev_seeds160_319.json 2>&1 | tail -1 | cut -c1-900 ;;
     mmprobe)    timeout 120 python scripts/mm_blocking_probe.py --out $OUT/mm_blocking_probe.json 2>&1 | tail -8 ;;
     ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
     ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;
