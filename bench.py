@@ -466,8 +466,8 @@ def kernel_name(kid):
     if kid & (32 | 512):   # direct 3x3 kernel; 512 = fused with the 1x1 expansion (Bottleneck tail); 16384 = chunked accumulation (KCH = 4)
         return "conv3x3_direct_kernel<%d, %d, %s, %d, %s, %d>" % (1 if kid & 3 else 2, 4 if kid & 128 else (8 if kid & 64 else 16), tf(kid & 512),
                                                                    4 if kid & 2048 else 2, tf(kid & 4096), 4 if kid & 16384 else 0)
-    if kid & 8192:         # direct 3x3 / stride 2 kernel
-        return "conv3x3_s2_kernel<%d>" % (1 if kid & 1 else 2)
+    if kid & 8192:         # direct 3x3 / stride 2 kernel; 16384 = chunked accumulation (KCH = 4, K >= 1152)
+        return "conv3x3_s2_kernel<%d, %d>" % (1 if kid & 1 else 2, 4 if kid & 16384 else 0)
     if kid & 1024:         # k-major 1x1 kernel (conv1x1.hip); 16384 = chunked accumulation (KCH = 8)
         return "conv1x1_kmajor_kernel<%d, %s, %d>" % (1 if kid & 3 else 2, tf(kid & 16), 8 if kid & 16384 else 0)
     if kid == 256:
