@@ -244,35 +244,48 @@ extern "C" int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hi
 
 // One thread per pixel; the channel loop strides by HW so that a wave reads 64 consecutive floats per
 // channel (coalesced).  Two passes over C (the second one hits L2).
-__global__ __launch_bounds__(256) void l2norm_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          long long NP, int C, int HW, long long obs, long long ocs) {
+// F.normalize(x, dim=1) = x / max(||x||_2, 1e-12) (quick_start/coarseAlignFeatMatch.py:106,124; model/model.py PredFlowMask callers).
+// Round 5: the sum of squares runs in ATen's OWN order -- ONE fused-multiply-add chain over the channels, c = 0 .. C-1 (probed
+// against torch 2.10's CPU kernel, binary_kernel_reduce with NormTwoOps: `acc + x * x` contracted to an fma; bit-equal on every
+// shape and thread count tried, tests/test_oracle.py::test_l2norm_order_is_atens) -- then a correctly rounded sqrt and IEEE division.
+// Rounds 1-4 summed four interleaved chains (more accurate: 5e-8 vs 1.8e-7 rms relative error of the norm against float64 -- and
+// DIFFERENT from the reference in 81 % of the cells by up to 9.5e-7).  A norm error multiplies EVERY score of its cell coherently, so
+// it outweighs the convolution round-off (whose effect on a score averages down to ~2e-8) by an order of magnitude: the reference's
+// own two executions share the chain's rounding pattern almost entirely, the device's four-chain norm did not -- this, not the trunk,
+// was the bulk of the device's excess arg-max near-tie flips.
+__global__ __launch_bounds__(64) void l2norm_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         long long NP, int C, int HW, long long obs, long long ocs) {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < NP;
          p += (long long)gridDim.x * blockDim.x) {
         const long long n = p / HW;
         const int px = (int)(p - n * HW);
         const float* src = in + (size_t)n * C * HW + px;
         float* dst = out + (size_t)n * obs + px;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float s = 0.f;
         int c = 0;
-        for (; c + 3 < C; c += 4) {
-            const float a0 = src[(size_t)c * HW], a1 = src[(size_t)(c + 1) * HW];
-            const float a2 = src[(size_t)(c + 2) * HW], a3 = src[(size_t)(c + 3) * HW];
-            s0 = fmaf(a0, a0, s0); s1 = fmaf(a1, a1, s1); s2 = fmaf(a2, a2, s2); s3 = fmaf(a3, a3, s3);
+        for (; c + 15 < C; c += 16) {               // 16 loads in flight, the fma chain stays sequential in c
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(c + u) * HW];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s = fmaf(v[u], v[u], s);
         }
-        for (; c < C; ++c) { const float a0 = src[(size_t)c * HW]; s0 = fmaf(a0, a0, s0); }
-        const float nrm = sqrtf((s0 + s1) + (s2 + s3));
+        for (; c < C; ++c) { const float a0 = src[(size_t)c * HW]; s = fmaf(a0, a0, s); }
+        const float nrm = __fsqrt_rn(s);
         const float d = nrm > 1e-12f ? nrm : 1e-12f;
-        for (c = 0; c < C; ++c) dst[(size_t)c * ocs] = src[(size_t)c * HW] / d;
+        for (c = 0; c < C; ++c) dst[(size_t)c * ocs] = __fdiv_rn(src[(size_t)c * HW], d);
     }
 }
 
-// Same arithmetic, four threads per pixel: thread q of a pixel owns the channels c = q (mod 4) -- exactly the partial sum
-// s_q of the kernel above (same sequential fma chain), combined as (s0 + s1) + (s2 + s3) through LDS, so the result is
-// bit-identical.  The trunk's maps have only 1-2 k pixels per image: one thread per pixel leaves ~1 wavefront per SIMD walking
-// 1024 channels three times with four loads in flight; this form has 4x the wavefronts and 8 loads in flight per thread.
+// Same arithmetic with four wavefronts per 64 pixels doing the LOADS (wavefront q fetches the channels c = q (mod 4), 32 loads in
+// flight per thread: on the trunk's 1-5 k-pixel maps the kernel is pure load latency) while the chain itself stays ONE chain: the
+// values of 128 consecutive channels go through a 32 KB LDS tile and wavefront 0 walks them in channel order.  Bit-identical to the
+// kernel above.  The division pass is shared out over the four wavefronts again.
 __global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              long long NP, int C, int HW, long long obs, long long ocs) {
-    __shared__ float part[4][64];
+    constexpr int CB = 128;                        // channels per LDS block
+    __shared__ float tile[CB][64];
+    __shared__ float nrm_s[64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const long long p = (long long)blockIdx.x * 64 + lane;
     const bool pv = p < NP;
@@ -281,46 +294,41 @@ __global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __rest
     const int px = (int)(pc - n * HW);
     const float* src = in + (size_t)n * C * HW + px;
     float* dst = out + (size_t)n * obs + px;
-    // 32 loads in flight per thread (the chain of fmas stays sequential in c: same value): on the trunk's 1-5 k-pixel maps the
-    // kernel is a handful of wavefronts walking 1024 channels twice, i.e. pure load latency -- 8 in flight took 40 us per call
-    float s = 0.f;
+    float s = 0.f;                                 // wavefront 0: the chain
+    for (int c0 = 0; c0 < C; c0 += CB) {
+        const int nb = C - c0 < CB ? C - c0 : CB;  // a multiple of 4 (launch precondition C % 4 == 0)
+        float v[CB / 4];
+#pragma unroll
+        for (int u = 0; u < CB / 4; ++u) v[u] = (q + 4 * u < nb) ? src[(size_t)(c0 + q + 4 * u) * HW] : 0.f;
+#pragma unroll
+        for (int u = 0; u < CB / 4; ++u) tile[q + 4 * u][lane] = v[u];
+        __syncthreads();
+        if (q == 0) {
+            for (int k = 0; k < nb; ++k) { const float a0 = tile[k][lane]; s = fmaf(a0, a0, s); }
+        }
+        __syncthreads();
+    }
+    if (q == 0) nrm_s[lane] = s;
+    __syncthreads();
+    const float nrm = __fsqrt_rn(nrm_s[lane]);
+    const float d = nrm > 1e-12f ? nrm : 1e-12f;
+    if (!pv) return;
     int c = q;
     for (; c + 124 < C; c += 128) {
         float v[32];
 #pragma unroll
         for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) s = fmaf(v[u], v[u], s);
+        for (int u = 0; u < 32; ++u) dst[(size_t)(c + 4 * u) * ocs] = __fdiv_rn(v[u], d);
     }
     for (; c + 28 < C; c += 32) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s = fmaf(v[u], v[u], s);
+        for (int u = 0; u < 8; ++u) dst[(size_t)(c + 4 * u) * ocs] = __fdiv_rn(v[u], d);
     }
-    for (; c < C; c += 4) { const float v = src[(size_t)c * HW]; s = fmaf(v, v, s); }
-    part[q][lane] = s;
-    __syncthreads();
-    const float nrm = sqrtf((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-    const float d = nrm > 1e-12f ? nrm : 1e-12f;
-    if (!pv) return;
-    c = q;
-    for (; c + 124 < C; c += 128) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) dst[(size_t)(c + 4 * u) * ocs] = v[u] / d;
-    }
-    for (; c + 28 < C; c += 32) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + 4 * u) * HW];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dst[(size_t)(c + 4 * u) * ocs] = v[u] / d;
-    }
-    for (; c < C; c += 4) dst[(size_t)c * ocs] = src[(size_t)c * HW] / d;
+    for (; c < C; c += 4) dst[(size_t)c * ocs] = __fdiv_rn(src[(size_t)c * HW], d);
 }
 
 extern "C" int rfx_l2norm_nchw_f32(const float* in, float* out, int N, int C, int HW, long long out_batch_stride,

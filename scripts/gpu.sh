@@ -44,6 +44,9 @@ for step in "$@"; do
                 timeout 1200 python tests/run_parity_sweep.py ev 160 160 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_160_from160.json $OUT/parity_sweep_ev_seeds160_319.json
                 timeout 1200 python oracle/parity_sweep.py --config qs --stability --threads 8 --budget 900 --seeds $(seq 128 383) --records $OUT/oracle_vs_oracle_qs_seeds128_383.json 2>&1 | tail -1 | cut -c1-900
                 timeout 1200 python oracle/parity_sweep.py --config ev --stability --threads 8 --budget 900 --seeds $(seq 160 319) --records $OUT/oracle_vs_oracle_ev_seeds160_319.json 2>&1 | tail -1 | cut -c1-900 ;;
+    sweeps_dev) # device-vs-reference first-homography sweeps only (the reference-vs-reference figures of the same seeds are on file)
+                timeout 900 python tests/run_parity_sweep.py qs ${QS_N:-128} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_qs_${QS_N:-128}.json $OUT/parity_sweep_qs_${QS_N:-128}pairs${SUFFIX:-}.json
+                timeout 1200 python tests/run_parity_sweep.py ev ${EV_N:-160} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_${EV_N:-160}.json $OUT/parity_sweep_ev_${EV_N:-160}pairs${SUFFIX:-}.json ;;
     mmprobe)    timeout 120 python scripts/mm_blocking_probe.py --out $OUT/mm_blocking_probe.json 2>&1 | tail -8 ;;
     ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
     ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;

@@ -266,6 +266,24 @@ def test_chunked_accumulation_of_the_long_k_layers(dev):
     assert torch.equal(plan(x), chain)
 
 
+@pytest.mark.parametrize("shape", [(2, 1024, 30, 40), (1, 256, 60, 80), (3, 1024, 25, 33), (2, 36, 7, 5), (1, 50, 9, 11), (70, 1024, 3, 5)])
+def test_l2norm_equals_torch_normalize_bit_for_bit(dev, shape):
+    """Round 5: rfx_l2norm_nchw_f32 sums a cell's squares in ATen's own order (ONE fma chain over the channels; pinned on the host by
+    tests/test_oracle.py::test_l2norm_order_is_atens): ``ops.l2norm(x)`` == ``F.normalize(x.cpu())`` BIT FOR BIT -- both kernel forms
+    (four loading wavefronts per 64 pixels / one thread per pixel), also when the result is scattered into the match matrix."""
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    x = torch.relu(torch.randn(*shape, generator=g)) * torch.rand(1, shape[1], 1, 1, generator=g)
+    x[0, :, 0, 0] = 0.0                                            # an all-zero cell: 0 / 1e-12 = 0
+    want = F.normalize(x)
+    got = ops.l2norm(x.to(dev)).cpu()
+    assert torch.equal(got, want)
+    N, C, H, W = shape
+    ld = H * W + 12
+    M = torch.zeros((N, C, ld), device=dev)
+    ops.l2norm(x.to(dev), out=M[:, :, 5:], out_batch_stride=C * ld, out_chan_stride=ld)
+    assert torch.equal(M[:, :, 5:5 + H * W].cpu(), want.reshape(N, C, H * W))
+
+
 def test_pools_norm_head_resize(dev):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 5, 19, 26, generator=g)

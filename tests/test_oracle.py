@@ -619,3 +619,34 @@ def test_lapack_worker_processes_return_the_in_process_bits():
     finally:
         os.environ.pop("RFX_LAPACK_WORKERS", None)
         _lapack.stop()
+
+
+def test_l2norm_order_is_atens():
+    """F.normalize(x, dim=1) (quick_start/coarseAlignFeatMatch.py:106,124) on the CPU sums the squares of a cell's C channels as ONE
+    fused-multiply-add chain in channel order (ATen's binary_kernel_reduce with NormTwoOps), takes a correctly rounded sqrt, clamps at
+    1e-12 and divides: a float32 emulation of exactly that reproduces torch bit for bit on every shape and thread count -- the order
+    csrc/pool.hip::l2norm_nchw*_kernel follow since round 5.  The four-interleaved-chain sum of rounds 1-4 is MORE accurate against
+    float64 but differs from the reference's norm in most cells, by up to ~1e-6 relative: a coherent factor on every score of the
+    cell, an order of magnitude above what the convolutions' round-off does to a score."""
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    worst4 = 0.0
+    for shape in ((1, 1024, 15, 20), (2, 256, 30, 40), (3, 1024, 5, 7), (1, 50, 9, 11)):
+        g = torch.Generator().manual_seed(shape[2])
+        x = torch.relu(torch.randn(*shape, generator=g)) * torch.rand(1, shape[1], 1, 1, generator=g)
+        N, C = shape[0], shape[1]
+        X = x.reshape(N, C, -1).numpy()
+        s = np.zeros((N, X.shape[2]), np.float32)
+        s4 = [np.zeros((N, X.shape[2]), np.float32) for _ in range(4)]
+        for c in range(C):
+            s = fma(X[:, c], X[:, c], s)
+            s4[c % 4] = fma(X[:, c], X[:, c], s4[c % 4])
+        d = np.maximum(np.sqrt(s).astype(np.float32), np.float32(1e-12))
+        want = (X / d[:, None, :]).astype(np.float32)
+        for threads in (1, 4):
+            torch.set_num_threads(threads)
+            got = F.normalize(x).reshape(N, C, -1).numpy()
+            assert np.array_equal(got, want), (shape, threads)
+        n4 = np.sqrt((s4[0] + s4[1]) + (s4[2] + s4[3])).astype(np.float32)
+        worst4 = max(worst4, float(np.abs(n4 / np.sqrt(s).astype(np.float32) - 1).max()))
+    assert worst4 > 2e-7            # the old order is NOT the reference's: up to ~1e-6 relative on the norm of a cell
