@@ -643,10 +643,14 @@ def test_l2norm_order_is_atens():
             s4[c % 4] = fma(X[:, c], X[:, c], s4[c % 4])
         d = np.maximum(np.sqrt(s).astype(np.float32), np.float32(1e-12))
         want = (X / d[:, None, :]).astype(np.float32)
-        for threads in (1, 4):
-            torch.set_num_threads(threads)
-            got = F.normalize(x).reshape(N, C, -1).numpy()
-            assert np.array_equal(got, want), (shape, threads)
+        keep = torch.get_num_threads()
+        try:
+            for threads in (1, 4):
+                torch.set_num_threads(threads)
+                got = F.normalize(x).reshape(N, C, -1).numpy()
+                assert np.array_equal(got, want), (shape, threads)
+        finally:
+            torch.set_num_threads(keep)                 # later tests pin exact CPU results: leave the pool as it was
         n4 = np.sqrt((s4[0] + s4[1]) + (s4[2] + s4[3])).astype(np.float32)
         worst4 = max(worst4, float(np.abs(n4 / np.sqrt(s).astype(np.float32) - 1).max()))
     assert worst4 > 2e-7            # the old order is NOT the reference's: up to ~1e-6 relative on the norm of a cell
