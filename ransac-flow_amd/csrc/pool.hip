@@ -247,7 +247,9 @@ extern "C" int rfx_maxblurpool2d_f32(const float* in, float* out, int NC, int Hi
 // F.normalize(x, dim=1) = x / max(||x||_2, 1e-12) (quick_start/coarseAlignFeatMatch.py:106,124; model/model.py PredFlowMask callers).
 // Round 5: the sum of squares runs in ATen's OWN order -- ONE fused-multiply-add chain over the channels, c = 0 .. C-1 (probed
 // against torch 2.10's CPU kernel, binary_kernel_reduce with NormTwoOps: `acc + x * x` contracted to an fma; bit-equal on every
-// shape and thread count tried, tests/test_oracle.py::test_l2norm_order_is_atens) -- then a correctly rounded sqrt and IEEE division.
+// shape and thread count tried, tests/test_oracle.py::test_l2norm_order_is_atens) -- then a correctly rounded sqrt and IEEE division
+// (`sqrtf` under -fhip-fp32-correctly-rounded-divide-sqrt: v_sqrt_f32 + the two-fma fix-up; hipcc lowers `__fsqrt_rn` to the BARE
+// v_sqrt_f32, 1 ulp off in ~12 % of the cells -- measured: 6 % of the normalised values then differ from torch by one ulp).
 // Rounds 1-4 summed four interleaved chains (more accurate: 5e-8 vs 1.8e-7 rms relative error of the norm against float64 -- and
 // DIFFERENT from the reference in 81 % of the cells by up to 9.5e-7).  A norm error multiplies EVERY score of its cell coherently, so
 // it outweighs the convolution round-off (whose effect on a score averages down to ~2e-8) by an order of magnitude: the reference's
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(64) void l2norm_nchw_kernel(const float* __restrict
             for (int u = 0; u < 16; ++u) s = fmaf(v[u], v[u], s);
         }
         for (; c < C; ++c) { const float a0 = src[(size_t)c * HW]; s = fmaf(a0, a0, s); }
-        const float nrm = __fsqrt_rn(s);
+        const float nrm = sqrtf(s);                 // correctly rounded (see the Makefile note: __fsqrt_rn is NOT)
         const float d = nrm > 1e-12f ? nrm : 1e-12f;
         for (c = 0; c < C; ++c) dst[(size_t)c * ocs] = __fdiv_rn(src[(size_t)c * HW], d);
     }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void l2norm_nchw_q4_kernel(const float* __rest
     }
     if (q == 0) nrm_s[lane] = s;
     __syncthreads();
-    const float nrm = __fsqrt_rn(nrm_s[lane]);
+    const float nrm = sqrtf(nrm_s[lane]);
     const float d = nrm > 1e-12f ? nrm : 1e-12f;
     if (!pv) return;
     int c = q;
