@@ -654,3 +654,76 @@ def test_l2norm_order_is_atens():
         n4 = np.sqrt((s4[0] + s4[1]) + (s4[2] + s4[3])).astype(np.float32)
         worst4 = max(worst4, float(np.abs(n4 / np.sqrt(s).astype(np.float32) - 1).max()))
     assert worst4 > 2e-7            # the old order is NOT the reference's: up to ~1e-6 relative on the norm of a cell
+
+
+def test_timed_mode_parity_checker_replays_a_device_draw_dump(tmp_path, monkeypatch):
+    """The checker behind ``parsed.parity_timed_mode`` (oracle/parity_sweep.py::compare_loop on a dump that carries the device's own
+    Philox samples), exercised WITHOUT a GPU: the "device" here is the port oracle/restate.py running the multi-homography loop of
+    evaluation/evalHpatch/evaluation.py:211-243 with the draws rfx_draw_samples_i64 would make -- Philox4x32-10 keyed by (seed,
+    pair id, round), tests/philox_ref.py -- and leaving the per-round state in dump_gpu_loop's format.  The checker (the reference
+    itself where it is present) must regenerate every round's samples from (draw seed, pair id, round) and find them equal to the
+    dumped ones, replay every round from the dumped state exactly -- count, status, bit-equal inliers, |dH| = 0, flows, accept
+    decision, next mask -- and conclude that its own free-running loop is implied.  A dump whose samples were tampered with is caught."""
+    import json
+    import philox_ref
+    import parity_sweep
+    cfg = "t_small"
+    monkeypatch.setitem(parity_sweep.CONFIGS, cfg, dict(variant="B", nbScale=3, scaleR=1.2, size="min", nbIter=400, loop="hpatch", H=240, W=320,
+                                                        maxCoarse=2, th=0.01, amp=0.05))
+    monkeypatch.setattr(parity_sweep, "_W", {})
+    c, seed, draw_seed, sub = parity_sweep.CONFIGS[cfg], 7, 1000, 4
+    sds = parity_sweep.state_dicts(parity_sweep.MULTIH_MATCH_STD)
+    nets = dict(feat=sds["feat"], flow=sds["flow"], match=sds["match"])
+    rnd = [0]
+
+    def device_draw(n, it):                                             # what the lock-step driver draws in round rnd[0] for pair id `seed`
+        return torch.from_numpy(philox_ref.draw_samples([n], it, draw_seed, rnd[0], pair_ids=[seed])[0])
+    ca = restate.CoarseAlignOracle(sds["trunk"], c["nbScale"], c["nbIter"], 0.05, 240, c["scaleR"], variant="B", sample_fn=device_draw)
+    Is, It = parity_sweep.make_pair(cfg, seed, 240, 320)
+    ca.setPair(Is, It)
+    h, w = ca.It.size[1], ca.It.size[0]
+    with torch.no_grad():
+        featt = F.normalize(restate.feature_extractor(nets["feat"], ca.ItTensor))
+    grid = restate.identity_grid(h, w)
+    Mask = np.zeros((h, w), np.float32)
+    pack = lambda m: np.packbits(m > 0.5, axis=-1)
+    rows, nb = [], 0
+    while nb <= c["maxCoarse"]:
+        fg = Mask.copy()
+        r = ca.getCoarse(fg)
+        assert r is not None
+        with torch.no_grad():
+            flow12, match, fd8, md8 = restate.pred_flow_mask(nets, ca.IsTensor, featt, restate.warp_grid(torch.from_numpy(r["H"])[None], h, w), grid)
+        gain = float((match * (1 - fg)).mean())
+        acc = gain > c["th"] or nb == 0
+        new = ((Mask + match * (1 - fg)) >= 1.0).astype(np.float32) if acc else Mask
+        inl = np.zeros(len(ca.index1), bool)                            # the dump keeps (cap,) inlier flags per round, rows beyond n unused
+        inl[:len(r["inlier"])] = r["inlier"]
+        rows.append(dict(mask_before=pack(fg), mask_after=pack(new), n=len(r["match1"]), status=0, winner=0, inlier=np.packbits(inl),
+                         H=r["H"], flowDown8=fd8[0], matchDown8=md8[0], flow12_sub=flow12[0, ::sub, ::sub].numpy(), accept=int(acc), gain=gain,
+                         samples=r["samples"].astype(np.int32), round_id=rnd[0]))
+        rnd[0] += 1
+        if not acc:
+            break
+        Mask, nb = new, nb + 1
+    assert len(rows) >= 2 and nb >= 1
+    d = {k: np.stack([np.asarray(q[k]) for q in rows]) for k in rows[0]}
+    d.update(seed=seed, index1=ca.index1.numpy(), index2=ca.index2.numpy(), nbH=nb, sub=sub, final_mask=pack(Mask))
+    json.dump(dict(score_chunk_products=192, score_chunk_source="test", draw="device", degenerate="device", draw_seed=draw_seed, draw_epoch=0),
+              open(str(tmp_path / "meta.json"), "w"))
+    path = str(tmp_path / ("pair_%d.npz" % seed))
+    np.savez_compressed(path, **d)
+    rec = parity_sweep.compare_loop(cfg, seed, path)
+    assert rec["draw"] == "device" and rec["identical_list"] and rec["rounds"] == len(rows)
+    for q in rec["round_records"]:
+        assert q["count_equal"] and q["status_equal"] and q["inlier_bit_exact"] and q["H_delta"] == 0.0, q
+        assert q["flow12_delta"] < 1e-6 and q["flowDown8_delta"] < 1e-6 and q["accept_equal"] and q.get("mask_diff_frac", 0.0) == 0.0, q
+    assert rec["free_run"]["same_nbH"] and rec["free_run"].get("implied_by_exact_rounds")
+    s = parity_sweep.summarise_loop(cfg, [rec], 1, 0.0)
+    assert s["rounds_exact_given_state"] == "%d/%d" % (len(rows), len(rows)) and s["rounds_degenerate_winner"] == 0
+    # a dump whose samples are not the Philox draws of (seed, pair id, round) is refused
+    d["samples"] = d["samples"].copy()
+    d["samples"][0, 0, 0] = (d["samples"][0, 0, 0] + 1) % d["n"][0]
+    np.savez_compressed(path, **d)
+    with pytest.raises(AssertionError, match="dumped device samples"):
+        parity_sweep.compare_loop(cfg, seed, path)
