@@ -163,3 +163,30 @@ def test_unchanged_reference_script_runs_up_to_the_first_device_call(tmp_path):
         assert "align2images.py" in err, err[-1500:]                                 # died inside the script ...
         assert ref_loader.staged() or ".cuda()" in err, err[-1500:]                  # ... at a .cuda() call (bytecode has no source lines)
         assert any(k in err for k in ("No HIP GPUs are available", "Found no NVIDIA driver", "not compiled with CUDA", "HIP")), err[-800:]
+
+
+@pytest.mark.parametrize("rel,args,tail", [
+    ("evaluation/evalCorr/evaluation.py", ["--imageNet", "--nbScale", "3", "--minSize", "240"], ["MegaDepth", "--endIndex", "1"]),
+    ("evaluation/evalYFCC/evaluation.py", ["--imageNet", "--nbScale", "3", "--minSize", "240"], ["YFCC", "--endIndex", "1"]),
+])
+def test_unchanged_evalcorr_and_evalyfcc_scripts_run_up_to_the_first_device_call(tmp_path, rel, args, tail):
+    """Round 5: the two remaining evaluation drivers, unmodified, under dropin/run_reference_script.py in this GPU-less container --
+    every import of the scripts (coarseAlignFeatMatch, outil, model, pandas, kornia.geometry, torchvision and ``from scipy.misc import
+    imresize``, which the scipy of the reference's own requirements.txt no longer has: the launcher's restatement) must resolve, the
+    argument parsers with their sub-commands must run, the four network modules must be constructed, and the run must stop at the
+    script's first ``.cuda()`` (evalCorr/evaluation.py:126, evalYFCC/evaluation.py:116) with the HIP-device error."""
+    import subprocess
+    import ref_loader
+    from rfx import weights
+    script = os.path.join(ref_loader.REF_ROOT, rel)
+    ck = tmp_path / "ck.pth"
+    torch.save({"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+                "netMatch": weights.net_matchability_sd(3)}, str(ck))
+    launcher = os.path.join(ROOT, "ransac-flow_amd", "dropin", "run_reference_script.py")
+    cmd = [sys.executable, launcher, script] + args + ["--resumePth", str(ck), "--outDir", str(tmp_path / "out")] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MPLBACKEND="Agg"))
+    err = out.stderr
+    assert out.returncode != 0
+    assert "ImportError" not in err and "ModuleNotFoundError" not in err and "AttributeError" not in err, err[-1500:]
+    assert os.path.basename(os.path.dirname(rel)) in err, err[-1500:]              # died inside the script ...
+    assert any(k in err for k in ("No HIP GPUs are available", "Found no NVIDIA driver", "not compiled with CUDA", "HIP")), err[-800:]
