@@ -727,3 +727,33 @@ def test_timed_mode_parity_checker_replays_a_device_draw_dump(tmp_path, monkeypa
     np.savez_compressed(path, **d)
     with pytest.raises(AssertionError, match="dumped device samples"):
         parity_sweep.compare_loop(cfg, seed, path)
+
+
+def test_ctypes_prototypes_mirror_the_header_argument_by_argument():
+    """The binding's SIGNATURES table (rfx/_lib.py) against include/rfx_api.h, parsed: for every entry point the same number of
+    parameters and, per parameter, the same kind -- any pointer -> c_void_p, int / int32_t -> c_int, long long -> c_longlong,
+    uint64_t -> c_uint64, float -> c_float, double -> c_double, size_t -> c_size_t -- and the same return type.  A C-ABI change that
+    the mirror misses (ABI 8 moved three signatures) would otherwise only show as garbage arguments on a GPU box."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "rfx_api.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)                       # comments carry example prototypes
+    protos = re.findall(r"\b(const\s+char\s*\*|int|size_t)\s+(rfx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+
+    def kind(decl):
+        d = " ".join(decl.split())
+        if "*" in d:
+            return C.c_void_p
+        base = d.rsplit(" ", 1)[0] if " " in d else d                       # drop the parameter name
+        base = base.replace("const ", "").strip()
+        return {"int": C.c_int, "int32_t": C.c_int, "long long": C.c_longlong, "uint64_t": C.c_uint64, "float": C.c_float,
+                "double": C.c_double, "size_t": C.c_size_t}[base]
+    same = lambda a, b: a is b or {a, b} <= {C.c_int, C.c_int32}
+    for ret, name, args in protos:
+        res, argtypes = _lib.SIGNATURES[name]
+        want_res = {"int": C.c_int, "size_t": C.c_size_t}.get(ret, C.c_char_p)
+        assert same(res, want_res), (name, res, ret)
+        params = [] if args.strip() in ("", "void") else [p for p in args.split(",")]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        for i, (p, t) in enumerate(zip(params, argtypes)):
+            assert same(kind(p), t), (name, i, p.strip(), t)
