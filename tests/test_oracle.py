@@ -757,3 +757,47 @@ def test_ctypes_prototypes_mirror_the_header_argument_by_argument():
         assert len(params) == len(argtypes), (name, len(params), len(argtypes))
         for i, (p, t) in enumerate(zip(params, argtypes)):
             assert same(kind(p), t), (name, i, p.strip(), t)
+
+
+def test_kernel_resources_are_what_design_says():
+    """Static check of the built library (scripts/kernel_resources.py reads registers / LDS / scratch / spills of every gfx950 kernel
+    out of librfx.so's code objects and locates each scratch instruction relative to the MFMA loops): the occupancy each hot kernel
+    was tiled for is the occupancy the register and LDS budgets grant, the DLT kernel keeps its fp64 matrices in registers, and no
+    kernel pays a spill per K step beyond one scratch instruction per 36 MFMAs (the two known cases: the chunked stride-2 3x3 kernel
+    and the 128-channel fused Bottleneck tail, both at the 256-VGPR cap).  profiles/r05_kernel_resources.tsv is this table."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    rows = kr.table(_lib.LIB_PATH)
+    by = {r["kernel"]: r for r in rows}
+    assert len(rows) > 150 and len(by) == len(rows)
+    for r in rows:
+        assert r["vgpr"] + r["agpr"] <= 512 and r["lds"] <= 160 * 1024, r
+        assert r["k_loop_scratch"] <= r["k_loop_mfma"] // 36, r                       # never more than 1 scratch op per 36 MFMAs
+        if r["lds"] > 32 * 1024:
+            assert r["wg_per_cu"] * ((r["wg"] + 63) // 64) >= 8, r                    # >= 2 wavefronts per SIMD on every tiled kernel
+    hot = ["conv3x3_direct_kernel<2, 16, false, 2, false, 4>", "conv3x3_direct_kernel<2, 16, false, 2, false, 0>",
+           "conv3x3_direct_kernel<1, 16, false, 2, false, 4>", "conv1x1_kmajor_kernel<1, true, 8>", "conv1x1_kmajor_kernel<1, true, 0>",
+           "conv2d_mfma_kernel<2, 2, true, false, false>", "mnn_tile_kmajor_kernel<true, 1>", "mnn_tile_kmajor_kernel<false, 1>",
+           "stem7_conv_maxpool_kernel", "stem_conv_maxblur_kernel", "ransac_dlt_kernel<false>", "ransac_dlt_kernel<true>",
+           "l2norm_nchw_kernel", "l2norm_nchw_q4_kernel"]
+    for k in hot:
+        assert by[k]["scratch"] == 0 and by[k]["vgpr_spills"] == 0, by[k]
+    # the two-workgroups-per-CU kernels (DESIGN 3): 256 threads, <= 256 registers, <= 80 KB of LDS
+    for k in hot[:8]:
+        assert by[k]["wg"] == 256 and by[k]["wg_per_cu"] >= 2 and by[k]["k_loop_mfma"] == 0, by[k]   # (no scratch: loops not analysed)
+    # the 128x128 1x1 tile and the fused tails sit AT the cap and spill a handful of registers, all outside the K loops
+    for k in ("conv1x1_kmajor_kernel<2, true, 0>", "conv1x1_kmajor_kernel<2, false, 0>"):
+        assert by[k]["vgpr"] == 256 and by[k]["vgpr_spills"] <= 8 and by[k]["k_loop_scratch"] == 0 and by[k]["k_loop_mfma"] == 64, by[k]
+    # the committed table is the table of this build
+    path = os.path.join(ROOT, "profiles", "r05_kernel_resources.tsv")
+    lines = [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")]
+    assert lines[0] == kr.COLS
+    committed = {l[1]: dict(zip(kr.COLS, l)) for l in lines[1:]}
+    assert set(committed) == set(by)
+    for k, r in by.items():
+        assert all(str(r[c]) == committed[k][c] for c in ("wg", "vgpr", "lds", "scratch", "wg_per_cu", "k_loop_scratch")), (k, r, committed[k])
