@@ -103,8 +103,8 @@ def metadata(co):
     return [k for k in kernels if "name" in k]
 
 
-def scratch_placement(co, mangled):
-    """(MFMAs of the largest K loop, scratch instructions inside K loops, scratch instructions elsewhere) of one kernel."""
+def k_loops(co, mangled):
+    """(instructions [(offset, opcode)], the kernel's K loops [(lo, hi)], offsets of its MFMAs -- FMAs for a kernel without MFMAs)."""
     asm = subprocess.run([tool("llvm-objdump"), "-d", "--disassemble-symbols=" + mangled, co], check=True, capture_output=True,
                          text=True).stdout
     ins, base = [], None
@@ -122,12 +122,53 @@ def scratch_placement(co, mangled):
     if not mf:                                                       # a kernel without MFMAs (the 7x7 correlation): its FMA loops
         mf, need = [a for a, op, _ in ins if op.startswith(("v_fmac_f32", "v_pk_fma_f32", "v_fma_f32"))], 16
     mfma_loops = [(lo, hi) for lo, hi in loops if sum(lo <= a <= hi for a in mf) >= need]
-    k_loops = [(lo, hi) for lo, hi in mfma_loops
-               if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in mfma_loops)]
-    sc = [a for a, op, _ in ins if op.startswith("scratch_")]
-    hot = sum(1 for a in sc if any(lo <= a <= hi for lo, hi in k_loops))
-    biggest = max([sum(1 for a in mf if lo <= a <= hi) for lo, hi in k_loops] or [0])
+    inner = [(lo, hi) for lo, hi in mfma_loops
+             if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in mfma_loops)]
+    return [(a, op) for a, op, _ in ins], inner, mf
+
+
+def scratch_placement(co, mangled):
+    """(MFMAs of the largest K loop, scratch instructions inside K loops, scratch instructions elsewhere) of one kernel."""
+    ins, inner, mf = k_loops(co, mangled)
+    sc = [a for a, op in ins if op.startswith("scratch_")]
+    hot = sum(1 for a in sc if any(lo <= a <= hi for lo, hi in inner))
+    biggest = max([sum(1 for a in mf if lo <= a <= hi) for lo, hi in inner] or [0])
     return biggest, hot, len(sc) - hot
+
+
+MIX = ["mfma", "ds_read", "ds_write", "vmem_load", "vmem_store", "scratch", "valu", "salu", "waitcnt", "barrier", "other"]
+
+
+def instruction_class(op):
+    for prefix, c in (("v_mfma", "mfma"), ("ds_read", "ds_read"), ("ds_write", "ds_write"), ("global_load", "vmem_load"),
+                      ("buffer_load", "vmem_load"), ("global_store", "vmem_store"), ("buffer_store", "vmem_store"),
+                      ("scratch_", "scratch"), ("v_", "valu"), ("s_waitcnt", "waitcnt"), ("s_barrier", "barrier"), ("s_", "salu")):
+        if op.startswith(prefix):
+            return c
+    return "other"
+
+
+def k_loop_mix(co, mangled):
+    """Instruction counts by class of the kernel's largest K loop (one iteration = one K step of the tile)."""
+    ins, inner, mf = k_loops(co, mangled)
+    if not inner:
+        return None
+    lo, hi = max(inner, key=lambda r: sum(r[0] <= a <= r[1] for a in mf))
+    c = collections.Counter(instruction_class(op) for a, op in ins if lo <= a <= hi)
+    return dict({k: c.get(k, 0) for k in MIX}, bytes=hi - lo)
+
+
+def mix_table(pattern, lib=LIB):
+    rows = []
+    with tempfile.TemporaryDirectory() as d:
+        for co in code_objects(lib, d):
+            ks = metadata(co)
+            for k, name in zip(ks, demangle([k["name"] for k in ks])):
+                if re.search(pattern, name):
+                    m = k_loop_mix(co, k["name"])
+                    if m:
+                        rows.append(dict(m, kernel=name))
+    return rows
 
 
 def occupancy(vgpr, agpr, lds, wg):
@@ -160,7 +201,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tsv")
     ap.add_argument("--lib", default=LIB)
+    ap.add_argument("--mix", metavar="REGEX", help="instead: the instruction mix of the largest K loop of the kernels matching REGEX")
     a = ap.parse_args()
+    if a.mix:
+        cols = ["kernel", "bytes"] + MIX
+        text = "\t".join(cols) + "\n" + "".join("\t".join(str(r[c]) for c in cols) + "\n" for r in mix_table(a.mix, a.lib))
+        if a.tsv:
+            with open(a.tsv, "w") as f:
+                f.write("# instruction mix of one iteration of the largest K loop (scripts/kernel_resources.py --mix; static, from"
+                        " librfx.so's gfx950 code objects)\n" + text)
+        sys.stdout.write(text)
+        return
     rows = table(a.lib)
     text = "\t".join(COLS) + "\n" + "".join("\t".join(str(r[c]) for c in COLS) + "\n" for r in rows)
     if a.tsv:

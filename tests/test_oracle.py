@@ -793,6 +793,17 @@ def test_kernel_resources_are_what_design_says():
     # the 128x128 1x1 tile and the fused tails sit AT the cap and spill a handful of registers, all outside the K loops
     for k in ("conv1x1_kmajor_kernel<2, true, 0>", "conv1x1_kmajor_kernel<2, false, 0>"):
         assert by[k]["vgpr"] == 256 and by[k]["vgpr_spills"] <= 8 and by[k]["k_loop_scratch"] == 0 and by[k]["k_loop_mfma"] == 64, by[k]
+    # one K step of the dominant kernel: 144 MFMAs (8 channels x 9 taps = 36 k-pairs on 4 sub-tiles), two barriers, no scratch; the
+    # committed mix table (profiles/r05_kloop_mix.tsv) is this build's
+    mix = {r["kernel"]: r for r in kr.mix_table(r"^conv3x3_direct_kernel<2, 16, false, 2, false, 4>$|^conv1x1_kmajor_kernel<2, true, 0>$",
+                                                _lib.LIB_PATH)}
+    dom = mix["conv3x3_direct_kernel<2, 16, false, 2, false, 4>"]
+    assert (dom["mfma"], dom["barrier"], dom["scratch"]) == (144, 2, 0) and dom["valu"] < dom["mfma"], dom
+    lines = [l.rstrip("\n").split("\t") for l in open(os.path.join(ROOT, "profiles", "r05_kloop_mix.tsv")) if not l.startswith("#")]
+    for l in lines[1:]:
+        row = dict(zip(lines[0], l))
+        if row["kernel"] in mix:
+            assert all(str(mix[row["kernel"]][c]) == row[c] for c in ("mfma", "ds_read", "ds_write", "vmem_load", "barrier")), row
     # the committed table is the table of this build
     path = os.path.join(ROOT, "profiles", "r05_kernel_resources.tsv")
     lines = [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")]
