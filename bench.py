@@ -211,9 +211,14 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=6)
     ap.add_argument("--host-draw", action="store_true", help="RANSAC index draw with torch.randint on the CPU generator (what a "
                     "CPU run of the reference draws) instead of on the device")
-    ap.add_argument("--degenerate", default="auto", choices=["auto", "device", "lapack"],
-                    help="rank-deficient 4-point samples (AlignPipeline): auto = the host's LAPACK with host draws, the device's own null "
-                         "vector with device draws (the timed default); lapack = the exact mode also with device draws")
+    ap.add_argument("--degenerate", default="lapack", choices=["auto", "device", "lapack"],
+                    help="rank-deficient 4-point samples (AlignPipeline): lapack (the timed default since round 6) = the EXACT mode: re-solved "
+                         "by the host's LAPACK (librfxhost.so: numpy's own dgesdd on std::threads) like the reference does for every sample; "
+                         "device = the device's own null vector (no host round trip; rounds 3-5's timed mode); auto = lapack with host draws, "
+                         "device with device draws")
+    ap.add_argument("--split", type=int, default=None,
+                    help="lock-step groups of the multi-homography driver (AlignPipeline.multi_h_batched split=): default = the pipeline's "
+                         "rule (2 groups on 2 streams for device draws)")
     ap.add_argument("--score-chunk", default="host",
                     help="how the mutual-NN scores are summed (ops.resolve_score_chunk): 'host' (default here: the K blocking of this host's "
                          "sgemm, probed ONCE on rank 0 before the workload is built and broadcast -- the parity legs compare with this host's "
@@ -378,7 +383,7 @@ def build_workload(args, dev, rank, world, score_chunk=None):
             prep = pipe.prepare_device(*(_upload(raw_h, dev) if raw_h is not None else raw))
             R = ops.MultiHRecords(B, prep["ItTensor"].shape[2] // 8, prep["ItTensor"].shape[3] // 8, dev, max_h=11)
             R.rec[:, 2] = float(rank)
-            pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False, pair_ids=seeds)
+            pipe.multi_h_batched(prep, maxCoarse=10, maskRegionTh=0.01, records=R, want_lists=False, pair_ids=seeds, split=args.split)
             return _download(R.rec, rec_h) if raw_h is not None else R.rec
         wl = ("BASELINE config %s as worded: batch of %d %dx%d pairs per GPU per step, each target warped by a seeded random "
               "homography; evaluation semantics (variant B, minSize %d, %d scales x2, coarseIter %d) + multi-homography loop "
@@ -639,12 +644,15 @@ def main():
         torch.manual_seed(123 + rank)
     log("workload built (config %s, rank %d/%d)" % (args.config, rank, world))
     unprofiled = None
-    if not args.dry_run and args.config == "2":
-        # single-pair latency is launch-bound: the product path replays the trunk as ONE HIP graph, which cannot carry the
-        # profiler's per-launch events -> time it WITHOUT the profiler (value), then once more with it for the rooflines
+    if not args.dry_run and args.config in ("2", "3", "4"):
+        # config 2: single-pair latency is launch-bound: the product path replays the trunk as ONE HIP graph, which cannot carry the
+        # profiler's per-launch events.  configs 3 / 4: the multi-homography rounds run as two lock-step groups on two HIP streams
+        # (multi_h_batched split=2) whose kernels overlap -- a per-launch event interval would charge a kernel with its neighbour's
+        # time.  -> the product path is timed WITHOUT the profiler (value), then the same steps once more with it (one group, eager
+        # launches, per-launch events) for the rooflines
         e_np, out, _ = timed_loop(step, args, dist, sync, _NoProf)
         unprofiled = e_np
-        log("%d timed steps without the profiler (HIP-graph trunk): %.3f s" % (args.steps, e_np))
+        log("%d timed steps without the profiler (the product path): %.3f s" % (args.steps, e_np))
     elapsed, out, prof = timed_loop(step, args, dist, sync, prof_factory)
     log("%d timed steps: %.3f s" % (args.steps, elapsed))
     profiled_elapsed = elapsed
@@ -674,7 +682,8 @@ def main():
                            collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
                            score_chunk_products=score_chunk, score_chunk_source=score_chunk_source,
                            ransac_draw="host (torch.randint, CPU generator)" if args.host_draw else "device (Philox4x32-10)",
-                           rank_deficient_samples=("host LAPACK (exact mode)" if (args.degenerate == "lapack" or (args.degenerate == "auto" and args.host_draw))
+                           rank_deficient_samples=("host LAPACK (exact mode: librfxhost.so runs numpy's own dgesdd on the flagged samples)"
+                                                   if (args.degenerate == "lapack" or (args.degenerate == "auto" and args.host_draw))
                                                    else "device null vector"),
                            preprocessing="host PIL, outside the timed region" if args.host_prep else
                            "device (bit-exact Pillow LANCZOS pyramid + ToTensor/Normalize), inside the timed step")}
@@ -697,10 +706,16 @@ def main():
             line["config"]["homographies_per_pair_last_step"] = {"mean": round(float(nbh.mean()), 2), "min": int(nbh.min()), "max": int(nbh.max())}
             line["config"]["homographies_per_s"] = round(float(nbh.sum()) * args.steps / elapsed, 1)
         roof, corr = rooflines(prof, profiled_elapsed, rank, args.config)
-        if unprofiled is not None:
+        if unprofiled is not None and args.config == "2":
             roof["note"] = ("value / ms_per_step: HIP-graph trunk, no profiler (%.2f ms per pair); this roofline: a second pass of %d steps "
                             "with the per-launch events (eager launches, %.2f ms per pair)" % (unprofiled / args.steps * 1e3, args.steps,
                                                                                           profiled_elapsed / args.steps * 1e3))
+        elif unprofiled is not None:
+            roof["note"] = ("value / ms_per_step: the product path, no profiler (multi-homography rounds as lock-step groups on HIP streams, "
+                            "%.2f ms per step); this roofline: the same %d steps once more under the per-launch events (one group: "
+                            "overlapping streams would charge a kernel with its neighbour's time), %.2f ms per step"
+                            % (unprofiled / args.steps * 1e3, args.steps, profiled_elapsed / args.steps * 1e3))
+            line["config"]["ms_per_step_profiled_pass"] = round(profiled_elapsed / args.steps * 1e3, 3)
         line["roofline"] = roof
         if corr:
             line["roofline_corr"] = corr
@@ -722,26 +737,38 @@ def main():
                                      "roofline": {k: rq[k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "time_share", "all_conv_tflops", "conv_time_share", "traffic")},
                                      "roofline_corr": cq}
             log("quick_start leg done: %.1f pairs/s" % extras["quick_start"]["value"])
-        # ---- the exact modes' throughput on the SAME workload: what bit-for-bit comparability with a CPU run costs ----
+        # ---- the other draw / null-vector modes on the SAME workload: what the exact mode costs ----
         if not args.no_exact_leg:
             ex = {}
-            for name, hd, dg in (("host_draw_lapack", True, "auto"), ("device_draw_lapack", False, "lapack")):
+            for name, hd, dg in (("host_draw_lapack", True, "lapack"), ("device_draw_device_null_vector", False, "device")):
                 ae = argparse.Namespace(**vars(args))
                 ae.host_draw, ae.degenerate, ae.steps, ae.warmup = hd, dg, 5, 1
-                stepe, _, _ = build_workload(ae, dev, rank, world, score_chunk=score_chunk)
+                stepe, _, extrae = build_workload(ae, dev, rank, world, score_chunk=score_chunk)
                 torch.manual_seed(123)
                 ee, oute, _ = timed_loop(stepe, ae, None, sync, _NoProf)
                 ex[name] = {"pairs_per_s": round(B * ae.steps / ee, 3), "ms_per_step": round(ee / ae.steps * 1e3, 2), "steps": ae.steps,
                             "vs_timed_mode": round((B * ae.steps / ee) / line["value"], 4),
                             "aligned_ok_last_step": int((oute[:, col["status"]] == 0).sum().item())}
-                del stepe
+                del stepe, extrae
                 torch.cuda.empty_cache()
-            ex["note"] = ("host_draw_lapack = torch.randint on the CPU generator per pair and round + rank-deficient samples re-solved by the "
-                          "host's LAPACK: the mode `parity` is measured in; device_draw_lapack = the timed mode's Philox draws + the same "
-                          "LAPACK patching (one more sync per round); value = the timed mode (device draws, device null vector), whose "
-                          "own parity is `parity_timed_mode`")
+            # the timed (exact) mode once more with its host stage logged: flagged samples, dgesdd calls, host milliseconds per step
+            pipe_t = extra["pipe"]
+            pipe_t.exact_log = []
+            step()
+            sync()
+            L, pipe_t.exact_log = pipe_t.exact_log, None
+            from rfx import _lapack
+            ex["timed_mode_host_stage"] = {"flagged_samples_per_step": int(sum(sum(r["n_degenerate"]) for r in L)),
+                                           "dgesdd_calls_per_step": int(sum(r["n_solved"] for r in L)),
+                                           "host_ms_per_step": round(sum(r["host_ms"] for r in L), 2), "ransac_calls_per_step": len(L),
+                                           "solver": _lapack.info()}
+            ex["timed_mode_vs_device_null_vector"] = round(line["value"] / ex["device_draw_device_null_vector"]["pairs_per_s"], 4)
+            ex["note"] = ("value = the EXACT mode (device Philox draws; rank-deficient 4-point samples re-solved by the host's LAPACK through "
+                          "librfxhost.so, hidden under the other lock-step group's kernels); device_draw_device_null_vector = rounds 3-5's timed "
+                          "mode (no host stage); host_draw_lapack = torch.randint on the CPU generator per pair and round: the mode `parity` is "
+                          "measured in (one lock-step group, a second sync per round)")
             extras["exact_mode"] = ex
-            log("exact-mode leg done: %s" % {k: v["pairs_per_s"] for k, v in ex.items() if isinstance(v, dict)})
+            log("exact-mode leg done: %s" % {k: v["pairs_per_s"] for k, v in ex.items() if isinstance(v, dict) and "pairs_per_s" in v})
         # ---- CPU legs: bounded oracle baseline, then the parity sweeps over pairs of the timed batches ----
         if not args.no_cpu_baseline:
             log("GPU legs done; timing the CPU oracle (bounded sample, child process)")

@@ -42,7 +42,7 @@ const char* rfx_version(void);
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
  * round kernels, two-direction correlation, grouped launches; round 4: rfx_draw_samples_i64 keyed by pair id).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 8
+#define RFX_ABI_VERSION 9
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -402,6 +402,21 @@ int rfx_ransac_h4_batched_stage(const float* match1, const float* match2, const 
 int rfx_ransac_degenerate_list(const void* ws, int cap, int N, int batch, int32_t* idx, int32_t* count, int kcap, void* stream);
 int rfx_ransac_patch_h(void* ws, int cap, int N, int batch, const int32_t* idx, const int32_t* count, const float* Hpatch,
                        int kcap, void* stream);
+/* The same exchange in COMPACT form (round 6: what the exact mode runs on).  rfx_ransac_degenerate_gather, after stage 1: lists the
+ * flagged hypotheses of every pair (idx (batch,N) int32, count (batch) int32 -- device scratch), off (batch+1) int32 = exclusive
+ * prefix of count with off[batch] = total (device; also stored to off_host when non-NULL), and writes ONE ROW PER FLAGGED
+ * HYPOTHESIS at row off[b]+k of xy_rows: 16 floats = the sample's 4 source points (x, y) then its 4 target points (x, y), i.e.
+ * X[:, :, :2] | Y[:, :, :2] of outil.Homography(X, Y) (utils/outil.py:68-71) -- the input rows of rfx_host_dlt_null_vectors
+ * (rfx_host_api.h).  off_host and xy_rows may be PINNED HOST memory (hipHostMalloc / torch pin_memory: device-visible, coherent):
+ * the kernels then store straight into it and the host reads it after ONE event wait, no copy.  Rows >= row_cap are dropped
+ * (the caller compares off[batch] with row_cap, grows the buffer and calls again).
+ * rfx_ransac_patch_h_rows: the re-solved homographies, row off[b]+k of H_rows (9 f32 per row; device or pinned host memory),
+ * into the hypotheses idx[b][k]; det gate re-evaluated.  Then stage 2. */
+int rfx_ransac_degenerate_gather(const void* ws, const float* match1, const float* match2, const int32_t* n, int cap,
+                                 const int64_t* samples, int N, int batch, int32_t* idx, int32_t* count, int32_t* off,
+                                 int32_t* off_host, float* xy_rows, int row_cap, void* stream);
+int rfx_ransac_patch_h_rows(void* ws, int cap, int N, int batch, const int32_t* idx, const int32_t* count, const int32_t* off,
+                            const float* H_rows, int row_cap, void* stream);
 /* rfx_dlt4_homography + the per-system flag byte (bit0 set; bit1: det(H) > 1e-6; bit2 (4): rank deficient). */
 int rfx_dlt4_homography_flags(const float* X, const float* Y, int N, float* Hout, uint8_t* flags, void* stream);
 

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 #include <vector>
 
-extern "C" const char* rfx_version(void) { return "rfx 0.5.0 gfx950"; }
+extern "C" const char* rfx_version(void) { return "rfx 0.6.0 gfx950"; }
 extern "C" int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 
 namespace {

@@ -290,6 +290,64 @@ __global__ __launch_bounds__(256) void ransac_patch_kernel(float* __restrict__ H
     flags[h] = (flags[h] & ~2) | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);
 }
 
+// ---- compact form of the exact mode's exchange: ONE row per flagged hypothesis, all pairs back to back ---------------------
+// off[b] = rows of the pairs before b (exclusive prefix of cnt), off[batch] = total; written to the device copy the later
+// kernels read and to `off_out` (pinned host memory: what the host reads after the event)
+__global__ __launch_bounds__(64) void ransac_degen_scan_kernel(const int32_t* __restrict__ cnt, int batch, int32_t* __restrict__ off,
+                                                               int32_t* __restrict__ off_out) {
+    if (threadIdx.x != 0) return;
+    int acc = 0;
+    for (int b = 0; b < batch; ++b) { off[b] = acc; if (off_out) off_out[b] = acc; acc += cnt[b]; }
+    off[batch] = acc;
+    if (off_out) off_out[batch] = acc;
+}
+
+// row off[b]+k = the 4 source points (x, y) then the 4 target points (x, y) of pair b's k-th flagged sample: X[:, :, :2] | Y[:, :, :2]
+// of outil.Homography's arguments (utils/outil.py:68-71), 64 bytes, straight into pinned host memory
+__global__ __launch_bounds__(256) void ransac_degen_gather_kernel(const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                  const int32_t* __restrict__ narr, int cap,
+                                                                  const int64_t* __restrict__ samples, int N,
+                                                                  const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                                  const int32_t* __restrict__ off, float4* __restrict__ xy,
+                                                                  int row_cap) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt[b] || k >= N) return;
+    const int row = off[b] + k;
+    if (row >= row_cap) return;
+    const int h = idx[(size_t)b * N + k];
+    const int n = narr[b];
+    m1 += (size_t)b * cap * 3; m2 += (size_t)b * cap * 3;
+    float v[16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int64_t q = samples[((size_t)b * N + h) * 4 + p];
+        if (q < 0) q += n;                                   // python-style negative index (as in the DLT kernel)
+        if (q < 0 || q >= n) q = 0;
+        v[2 * p] = m1[q * 3 + 0]; v[2 * p + 1] = m1[q * 3 + 1];
+        v[8 + 2 * p] = m2[q * 3 + 0]; v[8 + 2 * p + 1] = m2[q * 3 + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xy[(size_t)row * 4 + j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+__global__ __launch_bounds__(256) void ransac_patch_compact_kernel(float* __restrict__ Hs, uint8_t* __restrict__ flags,
+                                                                   const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                                   const int32_t* __restrict__ off, const float* __restrict__ Hp,
+                                                                   int row_cap, int N, size_t wsStride) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt[b] || k >= N) return;
+    const int row = off[b] + k;
+    if (row >= row_cap) return;
+    const int h = idx[(size_t)b * N + k];
+    if (h < 0 || h >= N) return;
+    Hs = reinterpret_cast<float*>(reinterpret_cast<char*>(Hs) + b * wsStride);
+    flags += b * wsStride;
+    float hf[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { hf[j] = Hp[(size_t)row * 9 + j]; Hs[(size_t)h * 9 + j] = hf[j]; }
+    flags[h] = (flags[h] & ~2) | (rfx_det3_lu_f32(hf) > 1e-6f ? 2 : 0);
+}
+
 struct RansacWs {
     size_t P, Z, H, flags, counts, total;
 };
@@ -451,6 +509,39 @@ extern "C" int rfx_ransac_patch_h(void* ws, int cap, int N, int batch, const int
     char* w = static_cast<char*>(ws);
     hipLaunchKernelGGL(ransac_patch_kernel, dim3((kcap + 255) / 256, batch), dim3(256), 0, rfx_stream(stream),
                        reinterpret_cast<float*>(w + L.H), reinterpret_cast<uint8_t*>(w + L.flags), idx, count, Hpatch, kcap, N,
+                       L.total);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_ransac_degenerate_gather(const void* ws, const float* match1, const float* match2, const int32_t* n, int cap,
+                                            const int64_t* samples, int N, int batch, int32_t* idx, int32_t* count, int32_t* off,
+                                            int32_t* off_host, float* xy_rows, int row_cap, void* stream) {
+    if (!ws || !match1 || !match2 || !n || !samples || !idx || !count || !off || !xy_rows || cap <= 0 || N <= 0 || batch <= 0 ||
+        row_cap <= 0)
+        return RFX_E_ARG;
+    if (batch > 65535) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, cap);
+    hipStream_t st = rfx_stream(stream);
+    hipLaunchKernelGGL(ransac_degen_list_kernel, dim3(batch), dim3(1024), 0, st,
+                       reinterpret_cast<const uint8_t*>(static_cast<const char*>(ws) + L.flags), N, idx, count, N, L.total);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ransac_degen_scan_kernel, dim3(1), dim3(64), 0, st, count, batch, off, off_host);
+    RFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ransac_degen_gather_kernel, dim3((N + 255) / 256, batch), dim3(256), 0, st, match1, match2, n, cap, samples, N,
+                       idx, count, off, reinterpret_cast<float4*>(xy_rows), row_cap);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+extern "C" int rfx_ransac_patch_h_rows(void* ws, int cap, int N, int batch, const int32_t* idx, const int32_t* count,
+                                       const int32_t* off, const float* H_rows, int row_cap, void* stream) {
+    if (!ws || !idx || !count || !off || !H_rows || cap <= 0 || N <= 0 || batch <= 0 || row_cap <= 0) return RFX_E_ARG;
+    if (batch > 65535) return RFX_E_LIMIT;
+    const RansacWs L = ws_layout(N, cap);
+    char* w = static_cast<char*>(ws);
+    hipLaunchKernelGGL(ransac_patch_compact_kernel, dim3((N + 255) / 256, batch), dim3(256), 0, rfx_stream(stream),
+                       reinterpret_cast<float*>(w + L.H), reinterpret_cast<uint8_t*>(w + L.flags), idx, count, off, H_rows, row_cap, N,
                        L.total);
     RFX_LAUNCH_CHECK();
     return RFX_OK;

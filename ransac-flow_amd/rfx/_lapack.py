@@ -1,23 +1,41 @@
-"""Host LAPACK helper of the exact mode (ops.lapack_dlt): numpy's batched SVD is a serial, GIL-holding loop of one dgesdd per 8x9
-system (~10 us each; Python threads give no speed-up, measured), and a lock-step round of 64 pairs flags ~6 000 rank-deficient
-4-point samples: 70 ms of host time per round with the GPU idle.  ``null_vectors`` deals the systems to a few persistent WORKER
-PROCESSES -- plain ``python -c`` children speaking a length-prefixed byte protocol over pipes (no multiprocessing: nothing
-re-imports the caller's ``__main__``, nothing is forked from a process that holds a HIP context) -- each running the very same
-``np.linalg.svd(A)[2][:, 8]`` (utils/outil.py:84-86) on its slice: per system the same LAPACK routine of the same numpy build on the
-same data, hence the same bits (tests/test_oracle.py pins that), in 1/N of the time."""
-import atexit
+"""Host LAPACK helper of the exact mode: binding of librfxhost.so (include/rfx_host_api.h).
+
+The reference solves every 4-point DLT system with ``np.linalg.svd`` (utils/outil.py:84), i.e. with ``dgesdd`` of the LAPACK numpy
+is linked to.  numpy's batched SVD is a serial, GIL-holding loop of one dgesdd per 8x9 system (~10 us each) and a lock-step round
+of 64 pairs flags thousands of rank-deficient samples.  librfxhost.so (csrc/host_lapack.cpp) calls THE SAME routine -- resolved
+through ``numpy.linalg._umath_linalg``'s own handle, so it is the symbol numpy's svd gufunc binds -- with numpy's argument set on
+a pool of std::threads: per system the same LAPACK code on the same data, hence the same bits (tests/test_oracle.py pins that
+against ``np.linalg.svd`` itself), without Python, pipes or the GIL.  Rounds 4-5 dealt the systems to ``python -c`` worker
+processes instead (0.70x of the timed mode); those are gone.
+
+``dlt_null_vectors`` below is the numpy restatement of utils/outil.py:68-87 the native solver is pinned on; the product path
+never calls it.  There is no fallback: a missing librfxhost.so, or a numpy whose LAPACK cannot be resolved, raises."""
+import ctypes
 import os
-import struct
-import subprocess
-import sys
+import threading
 
 import numpy as np
 
-# utils/outil.py:68-87 up to the SVD: float32 products stored into a float64 8x9 system, then row 8 of Vh.  ONE source text, executed
-# in this process (small batches) and in every worker: the same numpy expressions on the same float32 inputs -> the same bits.
-_SOLVE_SRC = r"""
-import numpy as np
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("RFX_HOST_LIB") or os.path.normpath(os.path.join(_HERE, "..", "librfxhost.so"))
+
+# name -> (restype, argtypes); mirrors include/rfx_host_api.h one to one
+SIGNATURES = {
+    "rfx_host_lapack_bind": (ctypes.c_int, [ctypes.c_char_p]),
+    "rfx_host_lapack_symbol": (ctypes.c_char_p, []),
+    "rfx_host_set_threads": (ctypes.c_int, [ctypes.c_int]),
+    "rfx_host_dlt_null_vectors": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_info = {}
+
+
 def dlt_null_vectors(X, Y):
+    """utils/outil.py:68-87 up to the float32 cast, in numpy: float32 products stored into a float64 8x9 system, full SVD, row 8 of
+    Vh.  X, Y (k,4,3) float32 -> (k,9) float64.  The PIN of the native solver (tests), not a code path of the product."""
     k = X.shape[0]
     A = np.zeros((k, 8, 9))
     z, o = np.zeros(k), np.ones(k)
@@ -26,23 +44,6 @@ def dlt_null_vectors(X, Y):
         A[:, 2 * i] = np.stack([z, z, z, -u, -v, -o, v_ * u, v_ * v, v_], axis=1)
         A[:, 2 * i + 1] = np.stack([u, v, o, z, z, z, -u_ * u, -u_ * v, -u_], axis=1)
     return np.linalg.svd(A)[2][:, 8]
-"""
-exec(_SOLVE_SRC)      # defines dlt_null_vectors here
-
-_WORKER = _SOLVE_SRC + r"""
-import sys, struct
-rd, wr = sys.stdin.buffer, sys.stdout.buffer
-while True:
-    h = rd.read(8)
-    if len(h) < 8:
-        break
-    k, = struct.unpack('<q', h)
-    XY = np.frombuffer(rd.read(k * 96), dtype=np.float32).reshape(2, k, 4, 3)     # 96 bytes per system instead of a 576-byte matrix
-    wr.write(np.ascontiguousarray(dlt_null_vectors(XY[0], XY[1])).tobytes())
-    wr.flush()
-"""
-
-_workers = []
 
 
 def _ncpu():
@@ -52,50 +53,91 @@ def _ncpu():
         return os.cpu_count() or 1
 
 
-def start(n=None):
-    """Start the worker processes (idempotent).  Called by pipelines built with degenerate="lapack" so that the first round
-    does not pay the ~0.2 s interpreter start-up."""
-    if _workers:
-        return len(_workers)
-    n = n or int(os.environ.get("RFX_LAPACK_WORKERS", "0")) or max(1, min(16, _ncpu() // 4))
-    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    for _ in range(n):
-        _workers.append(subprocess.Popen([sys.executable, "-c", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env))
-    atexit.register(stop)
-    return n
+def default_threads():
+    """Solver threads of this process: RFX_LAPACK_THREADS, else the CPUs this process may run on divided by the ranks sharing
+    the host (LOCAL_WORLD_SIZE / WORLD_SIZE under torch.distributed.run), at most 64."""
+    env = int(os.environ.get("RFX_LAPACK_THREADS", "0"))
+    if env > 0:
+        return env
+    world = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or "1")
+    return max(1, min(64, _ncpu() // max(1, world)))
 
 
-def stop():
-    while _workers:
-        w = _workers.pop()
-        try:
-            w.stdin.close()
-            w.wait(timeout=2)
-        except Exception:  # noqa: BLE001 -- interpreter shutdown: best effort
-            w.kill()
+def load():
+    """Load librfxhost.so, attach prototypes, bind dgesdd through numpy's own linalg module.  Idempotent, thread-safe."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("librfxhost.so not found at %s -- build it with `make -C ransac-flow_amd/csrc` (g++; the exact RANSAC "
+                               "mode has no other host solver)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise RuntimeError("librfxhost.so is missing symbol %s (stale build?)" % name) from e
+            fn.restype, fn.argtypes = res, args
+        import numpy.linalg._umath_linalg as um          # the module whose svd gufunc the reference's np.linalg.svd runs
+        bits = lib.rfx_host_lapack_bind(os.fsencode(um.__file__))
+        if bits not in (32, 64):
+            raise RuntimeError("no dgesdd symbol resolves through %s: the exact RANSAC mode needs the LAPACK numpy itself uses" % um.__file__)
+        _info.update(symbol=lib.rfx_host_lapack_symbol().decode(), int_bits=bits, module=um.__file__,
+                     threads=lib.rfx_host_set_threads(default_threads()))
+        _lib = lib
+    return _lib
 
 
-def null_vectors(X, Y, min_parallel=768):
-    """X, Y (k,4,3) float32 source / target samples -> (k,9) float64: row 8 of Vh of numpy's full SVD of every DLT system, in order."""
+def info():
+    """dict(symbol, int_bits, module, threads) of the bound solver (loads it)."""
+    load()
+    return dict(_info)
+
+
+def set_threads(n):
+    _info["threads"] = load().rfx_host_set_threads(int(n))
+    return _info["threads"]
+
+
+def solve_rows(xy, out=None, dedupe=True, want_f64=False):
+    """xy (k,16) float32 C-contiguous host array (rows as rfx_ransac_degenerate_gather writes them: 4 source points (x,y), 4 target
+    points (x,y)) -> (k,9) float32 homographies = np.linalg.svd(A)[2][:, 8].astype(float32) of utils/outil.py:72-86; ``out``: a
+    (>=k,9) float32 C-contiguous array to fill (pinned memory).  Releases the GIL for the duration (ctypes).
+    Returns (H, n_solved[, hv float64])."""
+    lib = load()
+    if xy.dtype != np.float32 or not xy.flags.c_contiguous or xy.ndim != 2 or xy.shape[1] != 16:
+        raise ValueError("xy must be a C-contiguous (k,16) float32 array")
+    k = xy.shape[0]
+    if out is None:
+        out = np.empty((k, 9), dtype=np.float32)
+    elif out.dtype != np.float32 or not out.flags.c_contiguous or out.shape[0] < k or out.shape[1:] != (9,):
+        raise ValueError("out must be a C-contiguous (>=k,9) float32 array")
+    hv = np.empty((k, 9), dtype=np.float64) if want_f64 else None
+    ns = ctypes.c_int64(0)
+    rc = lib.rfx_host_dlt_null_vectors(xy.ctypes.data, k, out.ctypes.data, hv.ctypes.data if hv is not None else None,
+                                       1 if dedupe else 0, ctypes.byref(ns))
+    if rc == -3:
+        raise np.linalg.LinAlgError("SVD did not converge")          # what np.linalg.svd raises inside the reference
+    if rc != 0:
+        raise RuntimeError("rfx_host_dlt_null_vectors failed: %d" % rc)
+    return (out[:k], ns.value, hv) if want_f64 else (out[:k], ns.value)
+
+
+def null_vectors(X, Y):
+    """X, Y (k,4,3) float32 source / target samples (outil.Homography's arguments) -> (k,9) float64 = row 8 of Vh of numpy's full
+    SVD of every DLT system, in order -- through the native solver."""
+    X, Y = np.asarray(X, dtype=np.float32), np.asarray(Y, dtype=np.float32)
     k = X.shape[0]
-    X, Y = np.ascontiguousarray(X, dtype=np.float32), np.ascontiguousarray(Y, dtype=np.float32)
-    if k < min_parallel or os.environ.get("RFX_LAPACK_WORKERS") == "1":
-        return dlt_null_vectors(X, Y)                  # noqa: F821 -- defined by exec(_SOLVE_SRC)
-    n = start()
-    step = -(-k // n)
-    jobs = []
-    try:
-        for w, i in zip(_workers, range(0, k, step)):
-            m = min(step, k - i)
-            w.stdin.write(struct.pack("<q", m))
-            w.stdin.write(X[i:i + m].tobytes())
-            w.stdin.write(Y[i:i + m].tobytes())
-            w.stdin.flush()
-            jobs.append((w, m))
-        out = [np.frombuffer(w.stdout.read(m * 72), dtype=np.float64).reshape(-1, 9) for w, m in jobs]
-        if any(o.shape[0] != m for o, (_, m) in zip(out, jobs)):
-            raise RuntimeError("short read")
-    except Exception:  # noqa: BLE001 -- a dead worker must not lose the round: drop the pool, solve in-process (same bits)
-        stop()
-        return dlt_null_vectors(X, Y)                  # noqa: F821
-    return np.concatenate(out)
+    xy = np.ascontiguousarray(np.concatenate([X[:, :, :2].reshape(k, 8), Y[:, :, :2].reshape(k, 8)], axis=1))
+    return solve_rows(xy, want_f64=True)[2]
+
+
+def start(n=None):
+    """Load + bind the solver now (pipelines built in an exact mode call this so that the first round does not pay the dlopen)."""
+    load()
+    if n:
+        set_threads(n)
+    return _info["threads"]

@@ -64,6 +64,8 @@ SIGNATURES = {
                                     + [c_int, c_int, c_void_p]),
     "rfx_ransac_degenerate_list": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rfx_ransac_patch_h": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rfx_ransac_degenerate_gather": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
+    "rfx_ransac_patch_h_rows": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
     "rfx_dlt4_homography_flags": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rfx_ransac_h4_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 4
                               + [c_int, c_void_p]),
@@ -77,7 +79,7 @@ SIGNATURES = {
                               + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p]),
 }
 
-ABI_VERSION = 8     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
+ABI_VERSION = 9     # RFX_ABI_VERSION of the include/rfx_api.h these prototypes mirror
 
 _lib = None
 

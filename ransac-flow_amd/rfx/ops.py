@@ -815,30 +815,108 @@ def ransac_h4_batched(match1, match2, n, samples, tol, degenerate="device", info
         _call("rfx_ransac_h4_batched", odev, _p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl),
               _p(res), _p(ws), B)
         return bestH, inl.bool(), res
-    args = (_p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(bestH), _p(inl), _p(res), _p(ws), B)
-    _call("rfx_ransac_h4_batched_stage", odev, *args, 1)
-    idx = torch.empty((B, N), dtype=torch.int32, device=dev)
-    cnt = torch.empty(B, dtype=torch.int32, device=dev)
-    _call("rfx_ransac_degenerate_list", odev, _p(ws), cap, N, B, _p(idx), _p(cnt), N)
-    cnt_h = cnt.cpu()                                                      # the one sync of the exact mode
+    return ransac_h4_batched_finish(ransac_h4_batched_begin(match1, match2, n, samples, tol, _out=(bestH, inl, res, ws)), info=info)
+
+
+# ---- the exact mode's search, split at its one host wait so that a caller can put other work between the halves -------------
+
+_PINNED = {}           # (device index, stream) -> dict(off, xy, H): pinned exchange buffers of the exact mode, LRU-bounded
+
+
+def _exact_buffers(dev, B, rows):
+    """Pinned host buffers of one (device, stream): off (B+1) int32, xy (rows,16) f32, H (rows,9) f32 -- written by the gather kernels /
+    read by the patch kernel in place (device-visible, coherent memory), grown on demand, at most 8 sets kept."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ent = _PINNED.pop(key, None)
+    if ent is None or ent["off"].numel() < B + 1 or ent["xy"].shape[0] < rows:
+        rows = max(rows, ent["xy"].shape[0] if ent is not None else 0)
+        nb = max(B + 1, ent["off"].numel() if ent is not None else 0)
+        ent = dict(off=torch.zeros(nb, dtype=torch.int32).pin_memory(), xy=torch.empty((rows, 16), dtype=torch.float32).pin_memory(),
+                   H=torch.empty((rows, 9), dtype=torch.float32).pin_memory())
+    _PINNED[key] = ent                       # most recently used last
+    while len(_PINNED) > 8:
+        _PINNED.pop(next(iter(_PINNED)))
+    return ent
+
+
+class _ExactSearch:
+    __slots__ = ("odev", "args", "bestH", "inl", "res", "ws", "idx", "cnt", "off", "buf", "event", "B", "N", "cap", "gather_args", "t_begin")
+
+
+def ransac_h4_batched_begin(match1, match2, n, samples, tol, _out=None):
+    """First half of ransac_h4_batched(degenerate="lapack"): stage 1 (pack + DLT with rank flags) and rfx_ransac_degenerate_gather --
+    the flagged samples of all pairs, one 64-byte row each, written by the device straight into pinned host memory -- then an event
+    on the launch stream.  Nothing waits here: the caller may enqueue more device work (or run another batch's host work) before
+    ransac_h4_batched_finish."""
+    match1, match2 = _dev(match1, "match1"), _dev(match2, "match2")
+    n = _dev(n, "n", torch.int32)
+    samples = _dev(samples, "samples", torch.int64)
+    B, cap, _ = match1.shape
+    N = samples.shape[1]
+    if samples.shape[0] != B or n.shape[0] != B:
+        raise ValueError("batch sizes differ")
+    from . import _lapack
+    _lapack.load()
+    lib = _lib.load()
+    dev = match1.device
+    c = _ExactSearch()
+    if _out is None:
+        c.bestH = torch.empty((B, 3, 3), dtype=torch.float32, device=dev)
+        c.inl = torch.empty((B, cap), dtype=torch.uint8, device=dev)
+        c.res = torch.empty((B, 4), dtype=torch.int32, device=dev)
+        c.ws = torch.empty(lib.rfx_ransac_batched_ws_bytes(cap, N, B), dtype=torch.uint8, device=dev)
+    else:
+        c.bestH, c.inl, c.res, c.ws = _out
+    c.odev = _one_device(match1, match2, n, samples)
+    c.B, c.N, c.cap = B, N, cap
+    c.args = (_p(match1), _p(match2), _p(n), cap, _p(samples), N, float(tol), _p(c.bestH), _p(c.inl), _p(c.res), _p(c.ws), B)
+    c.gather_args = (match1, match2, n, samples)                           # kept alive until finish
+    _call("rfx_ransac_h4_batched_stage", c.odev, *c.args, 1)
+    c.idx = torch.empty((B, N), dtype=torch.int32, device=dev)
+    c.cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    c.off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    c.buf = _exact_buffers(dev, B, min(B * N, max(1 << 16, B * N // 8)))
+    _exact_gather(c)
+    return c
+
+
+def _exact_gather(c):
+    m1, m2, n, smp = c.gather_args
+    _call("rfx_ransac_degenerate_gather", c.odev, _p(c.ws), _p(m1), _p(m2), _p(n), c.cap, _p(smp), c.N, c.B, _p(c.idx), _p(c.cnt),
+          _p(c.off), _p(c.buf["off"]), _p(c.buf["xy"]), int(c.buf["xy"].shape[0]))
+    c.event = torch.cuda.Event()
+    c.event.record(torch.cuda.current_stream(c.odev))
+
+
+def ransac_h4_batched_finish(c, info=None):
+    """Second half: wait for the gather (the exact mode's ONE host wait), re-solve the flagged systems with the host's LAPACK
+    (rfx/_lapack.py -> librfxhost.so: numpy's own dgesdd on std::threads, utils/outil.py:68-87), patch them in
+    (rfx_ransac_patch_h_rows reads the pinned result rows in place), stage 2 (count + select).  Must run under the stream
+    ransac_h4_batched_begin ran under.  ``info`` (dict) receives n_degenerate per pair, n_solved, host_ms."""
+    import time
+    from . import _lapack
+    c.event.synchronize()
+    B = c.B
+    off = c.buf["off"].numpy()
+    total = int(off[B])
+    if total > c.buf["xy"].shape[0]:                                          # more flagged samples than rows: grow, gather again
+        c.buf = _exact_buffers(c.odev, B, total)
+        _exact_gather(c)
+        c.event.synchronize()
+        off = c.buf["off"].numpy()
+    t0 = time.perf_counter()
+    n_solved = 0
+    if total > 0:
+        _, n_solved = _lapack.solve_rows(c.buf["xy"].numpy()[:total], out=c.buf["H"].numpy())
+        _call("rfx_ransac_patch_h_rows", c.odev, _p(c.ws), c.cap, c.N, B, _p(c.idx), _p(c.cnt), _p(c.off), _p(c.buf["H"]),
+              int(c.buf["H"].shape[0]))
     if info is not None:
-        info["n_degenerate"] = cnt_h.tolist()
-    kmax = int(cnt_h.max())
-    if kmax > 0:
-        sel = idx[:, :kmax].long().clamp_(0, N - 1)                        # (B,kmax); rows beyond cnt[b] are ignored below
-        smp = torch.gather(samples, 1, sel[:, :, None].expand(-1, -1, 4))  # (B,kmax,4)
-        smp = torch.where(smp < 0, smp + n.long()[:, None, None], smp).clamp_(0, cap - 1)
-        bi = torch.arange(B, device=dev)[:, None, None]
-        X, Y = match1[bi, smp].cpu().numpy(), match2[bi, smp].cpu().numpy()    # (B,kmax,4,3)
-        valid = torch.arange(kmax)[None, :] < cnt_h[:, None].long()        # (B,kmax)
-        rows = valid.numpy().reshape(-1)
-        Hp = torch.zeros((B * kmax, 3, 3), dtype=torch.float32)
-        Hp[torch.from_numpy(rows)] = torch.from_numpy(lapack_dlt(X.reshape(-1, 4, 3)[rows], Y.reshape(-1, 4, 3)[rows]))
-        Hp = Hp.view(B, kmax, 9).to(dev)
-        idxc = idx[:, :kmax].contiguous()
-        _call("rfx_ransac_patch_h", odev, _p(ws), cap, N, B, _p(idxc), _p(cnt), _p(Hp), kmax)
-    _call("rfx_ransac_h4_batched_stage", odev, *args, 2)
-    return bestH, inl.bool(), res
+        info["n_degenerate"] = (off[1:B + 1] - off[:B]).tolist()
+        info["n_solved"] = n_solved
+        info["host_ms"] = (time.perf_counter() - t0) * 1e3
+    _call("rfx_ransac_h4_batched_stage", c.odev, *c.args, 2)
+    c.gather_args = None
+    return c.bestH, c.inl.bool(), c.res
 
 
 # ------------------------------------------------------------------------------------------------ multi-homography rounds (multih.hip)
@@ -917,6 +995,13 @@ class MultiHRecords:
         self.width = r4(self.off_d2 + 2 * hd2 * wd2 * max_h)
         self.rec = torch.zeros((B, self.width), dtype=torch.float32, device=device)
         self.rec[:, 1] = 1.0
+
+    def rows(self, lo, hi):
+        """The records of pairs [lo, hi) as a MultiHRecords of their own over the SAME storage (a lock-step group of the batch)."""
+        import copy
+        r = copy.copy(self)
+        r.B, r.rec = hi - lo, self.rec[lo:hi]
+        return r
 
     def views(self):
         """(nbH (B,), status (B,), H (B,max_h,3,3), flowDown8 (B,max_h,2,h8,w8), matchDown8 (B,max_h,2,h8,w8), flowD2 or None)."""

@@ -76,7 +76,7 @@ def cell_coords(n_rows, n_cols, device):
 
 class AlignPipeline:
     def __init__(self, sds, nbScale=7, nbIter=1000, tolerance=0.05, minSize=640, scaleR=1.2, variant="A",
-                 device="cuda", kernelSize=7, draw="device", seed=0, degenerate="auto", score_chunk=None):
+                 device="cuda", kernelSize=7, draw="device", seed=0, degenerate="lapack", score_chunk=None):
         """``draw``: where the RANSAC index draw of utils/outil.py:120 happens when no explicit ``samples`` / ``sample_fn`` is
         given.  "device" (default; the reference draws on ``match1.device``, i.e. on the GPU in a GPU run): Philox4x32-10 on
         the device keyed by (``seed``, call counter, pair, hypothesis) -- no host sync for nbMatch, no CPU draw + upload.
@@ -91,10 +91,12 @@ class AlignPipeline:
             raise ValueError("draw must be 'device' or 'host'")
         if degenerate not in ("auto", "device", "lapack"):
             raise ValueError("degenerate must be 'auto', 'device' or 'lapack'")
-        # rank-deficient 4-point samples (ops.ransac_h4_batched): "lapack" = re-solved by the host's LAPACK like the reference
-        # does for every hypothesis (one more sync per RANSAC call); "auto" = lapack whenever the draw comes from the host
-        # (explicit samples / sample_fn / draw="host": the modes in which a CPU run of the reference can be compared bit for bit,
-        # and which sync for the match counts anyway), device otherwise (the throughput mode: no host round trip)
+        # rank-deficient 4-point samples (ops.ransac_h4_batched): "lapack" (default since round 6: the EXACT mode) = re-solved by the
+        # host's LAPACK like the reference does for every hypothesis -- the flagged samples go to pinned memory, librfxhost.so runs
+        # numpy's own dgesdd on them on std::threads, one more host wait per RANSAC call, hidden under other device work by the
+        # lock-step drivers (multi_h_batched: 0.985x of the "device" mode on BASELINE config 3); "device" = the Householder sweep's own
+        # null vector for those samples (no host round trip; a valid vector of the 2-D null space, not LAPACK's pick);
+        # "auto" (rounds 4-5's default) = lapack whenever the draw comes from the host, device otherwise
         self.degenerate = degenerate
         if degenerate == "lapack" or (degenerate == "auto" and draw == "host"):
             from . import _lapack
@@ -661,13 +663,21 @@ class AlignPipeline:
                             for b, n in zip(active, n_host)]).to(self.dev, non_blocking=True)
 
     def multi_h_batched(self, prep, maxCoarse=10, maskRegionTh=0.01, It_bg=None, feats=None, sample_fn=None, records=None,
-                        want_lists=True, trace=None, pair_ids=None, draw_epoch=0):
+                        want_lists=True, trace=None, pair_ids=None, draw_epoch=0, split=None):
         """multi_h() for every pair of the batch in lock-step: round k computes the k-th homography of all pairs that are
         still active.  A round is device work end to end -- rfx_filter_matches_f32 (mask -> keep map -> ordered compaction of
         the cached matches), the index draw (device mode), rfx_ransac_h4_batched, the warp, PredFlowMask over the active
         pairs, rfx_multih_accept_f32 (gain, accept rule, mask update, result-record store) -- and ONE host readback: the
-        accept flags, from which the host builds the next round's active list.  Semantics per pair =
+        accept flags, from which the host builds the next round's active list (the exact mode, degenerate="lapack", has a second
+        wait per round: the flagged 4-point samples, re-solved by the host's LAPACK).  Semantics per pair =
         evaluation/evalHpatch/evaluation.py:184-243.
+        ``split``: the rounds of the batch as this many independent lock-step groups (contiguous slices of the batch), each on its
+        own HIP stream, driven from this one host thread as coroutines (_multi_h_rounds yields at its host waits; _drive_rounds
+        resumes the group whose event is due): while one group waits for the host -- accept flags, the LAPACK stage -- the other
+        groups' kernels keep the GPU busy, and the small launches of one group's late rounds share the chip with another's.
+        Per pair the arithmetic is unchanged (every kernel computes a pair independently; device draws are keyed by absolute
+        pair position / id).  None = RFX_MULTIH_SPLIT or 2 for device draws with B >= 16, else 1; forced to 1 with host draws /
+        ``sample_fn`` (the CPU generator is consumed in pair order) and with ``trace``.
         ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; costs a second sync per round).
         ``pair_ids``: absolute ids of the batch's pairs for the device draw (see _draw_epoch): with them a pair's homographies
         are the same alone, in any batch and under any sharding.
@@ -680,58 +690,135 @@ class AlignPipeline:
         dev = self.dev
         B = prep["B"]
         h, w = prep["ItTensor"].shape[2], prep["ItTensor"].shape[3]
-        rt, ct = feats["rt"], feats["ct"]
         idx1, idx2, cnt = self._mutual_batched(feats, B)
-        featt = ops.l2norm(self.feat(prep["ItTensor"]))
-        bg = None if It_bg is None else It_bg.to(dev).float().contiguous()
-        Mask = torch.zeros((B, h, w), dtype=torch.float32, device=dev)
-        nbH = torch.zeros(B, dtype=torch.int32, device=dev)
-        outs = [dict(H=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
-        nb = [0] * B
-        eye = torch.eye(3, device=dev)
-        active = list(range(B))
+        host_draw = sample_fn is not None or self.draw == "host"
+        if split is None:
+            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (2 if B >= 16 else 1)
+        if host_draw or trace is not None or ops.Profiler.active() is not None and os.environ.get("RFX_MULTIH_SPLIT_PROFILED", "0") != "1":
+            split = 1
+        split = max(1, min(int(split), B))
         ids, epoch = self._draw_epoch(pair_ids, "multi_h", draw_epoch)
+        if ids is None and split > 1:
+            ids = torch.arange(B, dtype=torch.int32, device=dev)       # the key of pair b stays its batch position b
+        st = dict(prep=prep, feats=feats, idx1=idx1, idx2=idx2, cnt=cnt, h=h, w=w, B=B, ids=ids, epoch=epoch,
+                  bg=None if It_bg is None else It_bg.to(dev).float().contiguous(),
+                  Mask=torch.zeros((B, h, w), dtype=torch.float32, device=dev), nbH=torch.zeros(B, dtype=torch.int32, device=dev),
+                  outs=[dict(H=[], flowDown8=[], matchDown8=[]) for _ in range(B)], nb=[0] * B, records=records,
+                  eye=torch.eye(3, device=dev), degenerate=self._degenerate_mode(host_draw),
+                  featt=None if split > 1 or self._degenerate_mode(host_draw) == "lapack" else ops.l2norm(self.feat(prep["ItTensor"])))
+        bounds = [(B * k // split, B * (k + 1) // split) for k in range(split)]
+        gens = [self._multi_h_rounds(st, lo, hi, maxCoarse, maskRegionTh, sample_fn, want_lists, trace) for lo, hi in bounds]
+        self._drive_rounds(gens)
+        outs, Mask = st["outs"], st["Mask"]
+        for b in range(B):
+            outs[b]["mask"] = Mask[b]
+            outs[b]["nbH"] = st["nb"][b]
+            outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
+        return outs
+
+    def _drive_rounds(self, gens):
+        """Run lock-step round generators to completion from this host thread: generator k runs under stream k (the caller's
+        stream for k = 0, pipeline-owned side streams after), yields a HIP event whenever it needs the host to see device results,
+        and is resumed -- round robin -- once that event has completed.  One generator: the plain sequential loop."""
+        main = torch.cuda.current_stream(self.dev)
+        if len(gens) > 1:
+            pool = self.__dict__.setdefault("_round_streams", [])
+            while len(pool) < len(gens) - 1:
+                pool.append(torch.cuda.Stream(device=self.dev))
+            streams = [main] + pool[:len(gens) - 1]
+            for s in streams[1:]:
+                s.wait_stream(main)
+        else:
+            streams = [main]
+        import collections
+        live = collections.deque((g, s, None) for g, s in zip(gens, streams))
+        while live:
+            g, s, ev = live.popleft()
+            if ev is not None:
+                ev.synchronize()
+            with torch.cuda.stream(s):
+                try:
+                    ev = next(g)
+                except StopIteration:
+                    continue
+            live.append((g, s, ev))
+        for s in streams[1:]:
+            main.wait_stream(s)
+
+    def _multi_h_rounds(self, st, lo, hi, maxCoarse, maskRegionTh, sample_fn, want_lists, trace):
+        """The rounds of pairs [lo, hi) of a batch as a generator (see multi_h_batched / _drive_rounds): yields a recorded HIP event
+        at every host wait.  All launches go to the stream that is current while the generator runs."""
+        dev = self.dev
+        prep, feats, B, h, w = st["prep"], st["feats"], st["B"], st["h"], st["w"]
+        G = hi - lo
+        whole = lo == 0 and hi == B
+        cut = (lambda t: t) if whole else (lambda t: None if t is None else t[lo:hi])
+        idx1, idx2, cnt = cut(st["idx1"]), cut(st["idx2"]), cut(st["cnt"])
+        Mask, nbH, bg, ids = cut(st["Mask"]), cut(st["nbH"]), cut(st["bg"]), cut(st["ids"])
+        IsT, ItT = cut(prep["IsTensor"]), cut(prep["ItTensor"])
+        rt, ct = feats["rt"], feats["ct"]
+        R = st["records"]
+        if R is not None and not whole:
+            R = R.rows(lo, hi)
+        featt = cut(st["featt"])
+        outs, nb, eye, degen, epoch = st["outs"], st["nb"], st["eye"], st["degenerate"], st["epoch"]
+        acc_host = torch.empty(G, dtype=torch.int32).pin_memory()
+        active = list(range(G))
         rnd = 0
         while active:
-            full = len(active) == B
-            A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
+            full = len(active) == G
+            A = None if full else torch.tensor(active, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
             M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
                                                feats["Wt"])
-            smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
+            smp = self._round_draws([lo + k for k in active], n_dev, sample_fn, A, ids, epoch, rnd)
             rnd += 1
-            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol,
-                                                    degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
+            if degen == "lapack":
+                # the exact mode: stage 1 + the flagged samples into pinned memory, then -- first round only -- the target's
+                # FeatureExtractor pass (independent of the search) BEHIND the gather, so that the host's LAPACK stage runs
+                # while the GPU works; the other rounds hide it under another group's kernels (split > 1)
+                search = ops.ransac_h4_batched_begin(M1, M2, n_dev, smp, self.tol)
+                if featt is None:
+                    featt = ops.l2norm(self.feat(ItT))
+                yield search.event
+                info = {} if getattr(self, "exact_log", None) is not None else None
+                bestH, inl, res = ops.ransac_h4_batched_finish(search, info=info)
+                if info is not None:
+                    self.exact_log.append(dict(info, round=rnd - 1, lo=lo, active=len(active)))
+            else:
+                if featt is None:
+                    featt = ops.l2norm(self.feat(ItT))
+                bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol, degenerate=degen)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
             flowCoarse = ops.warp_grid(Hs, h, w)
-            Is = prep["IsTensor"] if full else prep["IsTensor"].index_select(0, A)
+            Is = IsT if full else IsT.index_select(0, A)
             pm = self.pred_flow_mask(Is, featt if full else featt.index_select(0, A), flowCoarse)
             mask_before = (Mask if full else Mask.index_select(0, A)).clone() if trace is not None else None
             accept, gain = ops.multih_accept(pm["match"], Mask, bg, A, res, n_dev, nbH, maskRegionTh, 0, bestH=bestH,
                                              flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
-                                             match21Down8=pm["match21Down8"], records=records)
+                                             match21Down8=pm["match21Down8"], records=R)
             if trace is not None:
-                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=pm["match"][:, 0],
-                                  accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp,
-                                  round=rnd - 1))
+                trace.append(dict(active=[lo + k for k in active], mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm,
+                                  match=pm["match"][:, 0], accept=accept, gain=gain,
+                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp, round=rnd - 1))
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
-            acc = accept.cpu().tolist()                                                 # the round's ONE sync
+            acc_host[:len(active)].copy_(accept, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            yield ev                                                                    # the round's host readback: accept flags
+            acc = acc_host[:len(active)].tolist()
             nxt = []
-            for k, b in enumerate(active):
+            for k, m in enumerate(active):
                 if not acc[k]:
                     continue
+                b = lo + m
                 if want_lists:
                     outs[b]["H"].append(bestH[k])
                     outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
                     outs[b]["matchDown8"].append(md2[k:k + 1])
                 nb[b] += 1
                 if nb[b] <= maxCoarse:
-                    nxt.append(b)
+                    nxt.append(m)
             active = nxt
-        for b in range(B):
-            outs[b]["mask"] = Mask[b]
-            outs[b]["nbH"] = nb[b]
-            outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
-        return outs
 
     # ---------------------------------------------------------------- YFCC / Corr driver shape (variant C; VERDICT r4 #4)
     def pred_flow_mask_cycle(self, IsTensor, featt, flowCoarse):
@@ -832,7 +919,7 @@ class AlignPipeline:
             bg = None if all(cand[chosen[b]]["bg"] is None for b in members) else torch.stack(
                 [cand[chosen[b]]["bg"][b] if cand[chosen[b]]["bg"] is not None else torch.ones((h, w), device=dev) for b in members])
             fA, IsT = featA.index_select(0, gi), IsT_all.index_select(0, gi)
-            gids = None if ids is None else ids.index_select(0, gi)
+            gids = gi.int() if ids is None else ids.index_select(0, gi)     # absolute batch positions when no ids were given
             featt = ops.l2norm(self.feat(ItT))
             Mask = torch.zeros((G, h, w), dtype=torch.float32, device=dev)
             nbH = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -855,7 +942,7 @@ class AlignPipeline:
                 gc["featB_sel"] = sel(fB)
                 act_pairs = [members[m] for m in active]
                 n_dev, bestH, res = search(gc, sel(fA), keep, len(active), lambda cnt: self._round_draws(
-                    act_pairs, cnt, sample_fn, None, None if gids is None else sel(gids), ep_loop, rnd))
+                    act_pairs, cnt, sample_fn, None, sel(gids), ep_loop, rnd))
                 rnd += 1
                 Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
                 pm = self.pred_flow_mask_cycle(sel(IsT), sel(featt), ops.warp_grid(Hs, h, w))

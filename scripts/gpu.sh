@@ -1,9 +1,9 @@
 #!/bin/bash
 # ONE parametrised GPU-box script (replaces the per-experiment gpu_r0N_*.sh wrappers of earlier rounds).
 #   gpurun --timeout 1800 -- 'bash scripts/gpu.sh <step> [<step> ...]'     outputs under gpurun_out/$TAG (default r05)
-# steps: ref tests smoke bench sweeps_full kernels_ab newtests bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
+# steps: exact_probe hosttest ref tests smoke bench sweeps_full kernels_ab newtests bench_nocpu feature_error[_qs|_ev] profile pmc c2 c4 c5 sweeps mmprobe ubench_corr ubench_conv ubench_mnn
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-TAG=${TAG:-r05}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+TAG=${TAG:-r06}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 for step in "$@"; do
   echo "=== $step ($(date +%T))"
   case $step in
@@ -47,6 +47,8 @@ for step in "$@"; do
     sweeps_dev) # device-vs-reference first-homography sweeps only (the reference-vs-reference figures of the same seeds are on file)
                 timeout 900 python tests/run_parity_sweep.py qs ${QS_N:-128} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_qs_${QS_N:-128}.json $OUT/parity_sweep_qs_${QS_N:-128}pairs${SUFFIX:-}.json
                 timeout 1200 python tests/run_parity_sweep.py ev ${EV_N:-160} 2>&1 | tail -1 | cut -c1-1200; cp gpurun_out/parity_sweep_ev_${EV_N:-160}.json $OUT/parity_sweep_ev_${EV_N:-160}pairs${SUFFIX:-}.json ;;
+    exact_probe) timeout 900 python scripts/exact_mode_probe.py --steps ${PROBE_STEPS:-5} --split ${PROBE_SPLIT:-2} --out $OUT/exact_mode_probe${SUFFIX:-}.json 2>&1 | tail -12 | cut -c1-1500 ;;
+    hosttest)   timeout 300 python -m pytest tests/test_oracle.py -x -q -k "native_lapack or exports" 2>&1 | tail -3 ;;
     mmprobe)    timeout 120 python scripts/mm_blocking_probe.py --out $OUT/mm_blocking_probe.json 2>&1 | tail -8 ;;
     ubench_corr) timeout 600 python scripts/ubench/corr_bench.py ${CORR_ARGS:-} 2>&1 | tail -30 ;;
     ubench_conv) timeout 600 python scripts/ubench/conv_bench.py ${CONV_ARGS:-} 2>&1 | tail -40 ;;

@@ -384,3 +384,42 @@ def test_record_overflow_is_flagged_not_silent(dev):
     assert float(RH[0, 1, 0, 0]) == 2.0                                  # the slots hold homographies 1 and 2; the third was not stored
     with pytest.raises(ValueError):
         ops.multih_accept(match, torch.zeros((B, h, 2 * w), device=dev)[:, :, ::2], None, None, res, n, nbH, 0.01, 0)
+
+
+def test_lock_step_groups_on_streams_give_the_one_group_records_bit_for_bit(dev):
+    """multi_h_batched(split=k): the rounds of the batch as k lock-step groups on k HIP streams, driven as coroutines from one
+    host thread (the exact mode's LAPACK stage and the accept readback of one group hide under the other groups' kernels).
+    Every kernel computes a pair independently and the device draws are keyed by absolute pair id / position, so the records
+    -- homography counts, homographies, /8 flows and matchability maps -- are the one-group driver's bit for bit: in the
+    exact mode ("lapack", the default) and in the device-null-vector mode, with and without ``pair_ids``, for group counts
+    that do and do not divide the batch."""
+    sds = dict(trunk=weights.resnet50_trunk_sd(0), feat=weights.feature_extractor_sd(1), flow=weights.net_flow_coarse_sd(2),
+               match=weights.net_matchability_sd(3, last_std=3.0))
+    seeds = [3, 4, 5, 6, 7]
+    pairs = [synth.make_pair(240, 320, seed=s, homography=True) for s in seeds]
+    for degen in ("lapack", "device"):
+        pipe = AlignPipeline(sds, nbScale=3, nbIter=2000, tolerance=0.05, minSize=240, scaleR=1.2, variant="B", device=dev, seed=5,
+                             degenerate=degen)
+        raw = pipe.upload_raw(pairs)
+
+        def run(split, ids):
+            pipe.reseed(5)
+            pipe.exact_log = []
+            R = ops.MultiHRecords(len(seeds), 30, 40, dev)
+            outs = pipe.multi_h_batched(pipe.prepare_device(*raw), maxCoarse=4, maskRegionTh=0.01, records=R, pair_ids=ids, split=split)
+            torch.cuda.synchronize()
+            return R.rec.clone(), outs, list(pipe.exact_log)
+        for ids in (seeds, None):
+            one, outs1, log1 = run(1, ids)
+            assert int(one[:, 0].sum()) >= len(seeds) + 2 and len({int(x) for x in one[:, 0]}) >= 2     # rounds happen, groups shrink unevenly
+            for k in (2, 3, 5):
+                rec, outs, logk = run(k, ids)
+                assert torch.equal(rec, one), (degen, ids is None, k)
+                for a, b in zip(outs, outs1):
+                    assert a["nbH"] == b["nbH"] and torch.equal(a["mask"], b["mask"])
+                    assert all(torch.equal(x, y) for x, y in zip(a["H"], b["H"]))
+                if degen == "lapack":
+                    assert {r["lo"] for r in logk} == {len(seeds) * g // k for g in range(k)}          # every group ran its own host stage
+                    assert sum(sum(r["n_degenerate"]) for r in logk) == sum(sum(r["n_degenerate"]) for r in log1)
+            assert (degen == "lapack") == bool(log1)
+        pipe.exact_log = None

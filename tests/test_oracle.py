@@ -355,16 +355,24 @@ def test_config1_coarse_to_fine_matches_reference_golden():
 
 
 def test_library_exports_every_declared_symbol():
+    from rfx import _lapack
     hdr = open(os.path.join(ROOT, "include", "rfx_api.h")).read()
     declared = set(re.findall(r"\b(rfx_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    if not os.path.exists(_lib.LIB_PATH):
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(_lapack.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
+    # the host half of the exact mode: include/rfx_host_api.h <-> librfxhost.so <-> rfx/_lapack.py
+    hh = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "rfx_host_api.h")).read(), flags=re.S)
+    host_declared = set(re.findall(r"\b(rfx_host_[a-z0-9_]+)\s*\(", hh))
+    assert host_declared == set(_lapack.SIGNATURES), (host_declared ^ set(_lapack.SIGNATURES))
+    hl = _lapack.load()
+    for name in host_declared:
+        assert hasattr(hl, name), name
     assert lib.rfx_version().decode().startswith("rfx ")
     assert lib.rfx_mutual_nn_ws_bytes(8531, 1200) > 0 and lib.rfx_ransac_ws_bytes(900, 1000) > 0
 
@@ -591,34 +599,60 @@ def test_host_sgemm_probe_and_score_chunk_resolution():
         assert float((tot != mm).mean()) <= 1e-4
 
 
-def test_lapack_worker_processes_return_the_in_process_bits():
-    """The exact mode's host stage (ops.lapack_dlt -> rfx/_lapack.py): numpy's batched SVD is a serial loop, so large batches of
-    flagged 4-point samples are dealt to persistent worker PROCESSES -- per system the same ``np.linalg.svd(A)[2][:, 8]``
-    (utils/outil.py:84-86) of the same numpy build on the same data.  Pinned here: the workers' null vectors equal the in-process
-    call bit for bit, on general systems AND on rank-deficient ones (three points collinear in both images: the 2-D null space
-    whose LAPACK pick is rounding noise -- exactly the systems the exact mode exists for), in order, for ragged slice sizes; a
-    dead worker degrades to the in-process solve."""
+def _degenerate_lattice_samples(k, seed=0, n_rows=30, n_cols=40):
+    """4-point samples on the feature-cell lattice (getWHTensor coordinates): half general, half with three points collinear in BOTH
+    images (the rank-deficient systems the exact mode exists for), some repeated (late rounds draw few distinct samples)."""
+    rng = np.random.RandomState(seed)
+
+    def pts(m):
+        r = ((rng.randint(0, n_rows, (m, 4)).astype(np.float32) + np.float32(0.5)) / np.float32(n_rows) - np.float32(0.5)) * 2
+        c = ((rng.randint(0, n_cols, (m, 4)).astype(np.float32) + np.float32(0.5)) / np.float32(n_cols) - np.float32(0.5)) * 2
+        return np.stack([c, r, np.ones_like(c)], axis=2).astype(np.float32)
+    X, Y = pts(k), pts(k)
+    h = k // 2
+    X[:h, 2, :2] = 0.5 * (X[:h, 0, :2] + X[:h, 1, :2])
+    Y[:h, 2, :2] = 0.5 * (Y[:h, 0, :2] + Y[:h, 1, :2])
+    X[h:h + k // 8], Y[h:h + k // 8] = X[0], Y[0]
+    return X, Y
+
+
+def test_native_lapack_helper_equals_numpy_svd_bit_for_bit():
+    """The exact mode's host stage (ops.ransac_h4_batched_finish -> rfx/_lapack.py -> librfxhost.so, include/rfx_host_api.h): the
+    flagged 4-point samples are re-solved by the dgesdd numpy's own svd gufunc binds (resolved through numpy.linalg._umath_linalg's
+    handle), called with numpy's argument set on a pool of std::threads.  Pinned here against ``np.linalg.svd(A)[2][:, 8]``
+    (utils/outil.py:84-86) ITSELF, bit for bit in float64 and after the float32 cast: on general systems AND on rank-deficient
+    ones (the 2-D null space whose LAPACK pick is rounding noise), with and without the duplicate cache, at 1 / 3 / 8 solver
+    threads, for ragged sizes around the pool's block sizes, and for the row layout the device gather writes."""
     from rfx import ops, _lapack
-    rng = np.random.RandomState(0)
-    k = 1201
-    X, Y = rng.rand(k, 4, 3).astype(np.float32), rng.rand(k, 4, 3).astype(np.float32)
-    X[:500, 2] = 0.5 * (X[:500, 0] + X[:500, 1])
-    Y[:500, 2] = 0.5 * (Y[:500, 0] + Y[:500, 1])
-    X[..., 2] = Y[..., 2] = 1.0
-    serial = np.concatenate([ops.lapack_dlt(X[i:i + 300], Y[i:i + 300]) for i in range(0, k, 300)])    # < 768 systems: in-process
-    _lapack.stop()
-    os.environ["RFX_LAPACK_WORKERS"] = "3"
+    inf = _lapack.info()
+    assert inf["int_bits"] in (32, 64) and "gesdd" in inf["symbol"], inf
+    X, Y = _degenerate_lattice_samples(4999)
+    ref = _lapack.dlt_null_vectors(X, Y)                                            # numpy, in process: the reference's expression
+    A = np.zeros((3, 8, 9))
+    for i in range(4):                                                              # and the restatement against the formula, once
+        u, v, u_, v_ = Y[:3, i, 0], Y[:3, i, 1], X[:3, i, 0], X[:3, i, 1]
+        A[:, 2 * i, 3:] = np.stack([-u, -v, -np.ones(3), v_ * u, v_ * v, v_], axis=1)
+        A[:, 2 * i + 1, :3] = np.stack([u, v, np.ones(3)], axis=1)
+        A[:, 2 * i + 1, 6:] = np.stack([-u_ * u, -u_ * v, -u_], axis=1)
+    assert np.array_equal(np.linalg.svd(A)[2][:, 8], ref[:3])
+    xy = np.ascontiguousarray(np.concatenate([X[:, :, :2].reshape(-1, 8), Y[:, :, :2].reshape(-1, 8)], axis=1))
     try:
-        assert _lapack.start() == 3 and _lapack.start() == 3
-        par = ops.lapack_dlt(X, Y)
-        assert par.dtype == np.float32 and np.array_equal(par, serial)
-        _lapack._workers[1].kill()
-        _lapack._workers[1].wait()
-        assert np.array_equal(ops.lapack_dlt(X, Y), serial) and not _lapack._workers      # fell back, pool dropped
-        assert np.array_equal(ops.lapack_dlt(X, Y), serial) and len(_lapack._workers) == 3  # and comes back on the next call
+        for threads in (1, 3, 8):
+            assert _lapack.set_threads(threads) == threads
+            for dedupe in (False, True):
+                for k in (1, 63, 64, 1025, 4999):
+                    H, n_solved, hv = _lapack.solve_rows(xy[:k], dedupe=dedupe, want_f64=True)
+                    assert np.array_equal(hv.view(np.int64), ref[:k].view(np.int64)), (threads, dedupe, k)
+                    assert H.dtype == np.float32 and np.array_equal(H, ref[:k].astype(np.float32))
+                    assert n_solved <= k and (dedupe and k == 4999) == (n_solved < k)
+        out = np.zeros((6000, 9), np.float32)                                       # a caller-owned (pinned) result buffer
+        assert _lapack.solve_rows(xy, out=out)[0].base is out and np.array_equal(out[:4999], ref.astype(np.float32))
     finally:
-        os.environ.pop("RFX_LAPACK_WORKERS", None)
-        _lapack.stop()
+        _lapack.set_threads(_lapack.default_threads())
+    assert np.array_equal(ops.lapack_dlt(X, Y), ref.reshape(-1, 3, 3).astype(np.float32))
+    assert _lapack.solve_rows(np.zeros((0, 16), np.float32))[0].shape == (0, 9)
+    with pytest.raises(ValueError):
+        _lapack.solve_rows(xy[:, :8])
 
 
 def test_l2norm_order_is_atens():
