@@ -486,6 +486,31 @@ int rfx_multih_accept_f32(const float* match, float* mask, const float* bg, cons
                           int wd2, float* rec, long long rec_stride, int max_h, int off_H, int off_flow, int off_match,
                           int off_d2, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Sky segmentation forward pass: SegNet.getSky (segNet/segEval.py:23-43) = ResNet-50-dilated encoder
+ * (segNet/segModel.py:156-215: layer3 / layer4 with dilation 2 / 4 instead of stride) + PPM decoder (:218-265) over five
+ * scales, averaged, arg-max, (pred == segId).  Called once per target image by CoarseAlign.skyFromSeg
+ * (evaluation/evalHpatch/coarseAlignFeatMatch.py:63-64,152-153; evaluation/evalHpatch/evaluation.py:177-180).
+ * The convolutions run on the convolution family above plus ONE more geometry:
+ *
+ * rfx_conv2d_dilated_f32: rfx_conv2d_f32 with `dilation` > 1 (segModel.py:196-205: 3x3, dilation = padding = 2 or 4):
+ *     out[n,m,oh,ow] = act(scale[m] * sum in[n,c,oh*s-p+kh*d,ow*s-p+kw*d] * w[m,c,kh,kw] + shift[m] + residual)
+ * wT as for rfx_conv2d_f32; ktab holds the DILATED offsets: (c<<8)|((kh*d)<<4)|(kw*d), (KH-1)*d + 1 <= 15.  Same kernels, same
+ * summation order as rfx_conv2d_f32 (the gather adds the table's offsets to the window origin as they are).
+ * ------------------------------------------------------------------------------------------ */
+int rfx_conv2d_dilated_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                           const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                           int Win, int Cout, int KH, int KW, int stride, int pad, int dilation, int act, void* stream);
+/* nn.AdaptiveAvgPool2d((Hout, Wout)) on NC planes (segModel.py:227): window [floor(o*In/Out), ceil((o+1)*In/Out)), row-major sum / count. */
+int rfx_adaptive_avgpool2d_f32(const float* in, float* out, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
+/* scores[n,c,p] = (accumulate ? scores[n,c,p] : 0) + softmax_c(logits[n,:,p]) / div      (segModel.py:258 + segEval.py:34-35:
+ * ``scores = scores + pred_tmp / 5``); logits / scores (N,C,HW). */
+int rfx_softmax_accum_f32(const float* logits, float* scores, int N, int C, long long HW, float div, int accumulate, void* stream);
+/* torch.max(scores, dim=1) -> mask[n,p] = (pred == id) (complement != 0: 1 - that), float32 (segEval.py:37-43); pred (N,HW) int32
+ * optional (NULL: not stored).  First maximum wins. */
+int rfx_argmax_mask_f32(const float* scores, int N, int C, long long HW, int id, int complement, float* mask, int32_t* pred,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

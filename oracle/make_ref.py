@@ -42,6 +42,11 @@ MODULES = [
     "evaluation/evalKITTI/coarseAlignFeatMatch.py", "evaluation/evalKITTI/evaluation.py", "evaluation/evalKITTI/getResults.py",
     "evaluation/evalCorr/getResults.py", "evaluation/evalCorr/coarseAlignFeatMatch.py", "evaluation/evalCorr/evaluation.py",
     "evaluation/evalYFCC/coarseAlignFeatMatch.py", "evaluation/evalYFCC/evaluation.py",
+    # SURVEY.md 8f4 (round 6): the sky-segmentation forward pass and the vendored Synchronized-BatchNorm package its model imports
+    "segNet/segModel.py", "segNet/segData.py", "segNet/segEval.py",
+    "segNet/lib/nn/__init__.py", "segNet/lib/nn/modules/__init__.py", "segNet/lib/nn/modules/batchnorm.py",
+    "segNet/lib/nn/modules/comm.py", "segNet/lib/nn/modules/replicate.py",
+    "segNet/lib/nn/parallel/__init__.py", "segNet/lib/nn/parallel/data_parallel.py",
 ]
 # scripts whose functions / loops ref_loader extracts (the module level of these parses argv and walks a dataset)
 EXTRACT = [

@@ -176,6 +176,7 @@ def _install_stubs():
             return Image.fromarray(arr)
 
     tvt.ToTensor, tvt.Normalize, tvt.Compose, tvt.ToPILImage = ToTensor, Normalize, Compose, ToPILImage
+    tvt.transforms = tvt                 # segNet/segData.py:2 ``from torchvision.transforms import transforms``
     tv.models, tv.transforms = tvm, tvt
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.models"] = tvm
@@ -267,6 +268,45 @@ def load():
                         CoarseAlignA=caA.CoarseAlign, CoarseAlignB=caB.CoarseAlign,
                         kornia_geometry=sys.modules["kornia.geometry"]))
     return _loaded
+
+
+_seg = {}
+
+
+def load_seg():
+    """The reference's sky-segmentation modules on the CPU: segNet/segModel.py, segData.py, segEval.py and the
+    vendored Synchronized-BatchNorm package they import (segNet/lib/nn) -> dict(segModel, segData, segEval).  One more stub besides
+    load()'s three: the vendored package reads ``collections.Mapping / Sequence`` (segNet/lib/nn/parallel/data_parallel.py), names
+    Python 3.10 only keeps in ``collections.abc`` -- aliased here; with them the reference's own modules import unchanged.
+    ``sys.modules["segEval"]`` becomes the REFERENCE's module (load()'s stubs seat an empty placeholder for scripts that never
+    build a SegNet), so a CPU run of evaluation/evalHpatch/evaluation.py --segNet resolves ``import segEval`` to it."""
+    if _seg:
+        return _seg
+    if not os.path.isfile(ref_path("segNet/segModel.py")):
+        raise RuntimeError("reference segNet not available under %s" % REF_ROOT)
+    _install_stubs()
+    import collections
+    import collections.abc
+    import importlib.util
+    for n in ("Mapping", "Sequence", "Iterable", "Callable", "MutableMapping"):
+        if not hasattr(collections, n):
+            setattr(collections, n, getattr(collections.abc, n))
+    seg_dir = os.path.join(REF_ROOT, "segNet")
+    if seg_dir not in sys.path:
+        sys.path.insert(0, seg_dir)          # ``from lib.nn import SynchronizedBatchNorm2d`` (segNet/segModel.py:5)
+
+    def _imp(name, rel):
+        spec = importlib.util.spec_from_file_location(name, ref_path(rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    with contextlib.redirect_stdout(io.StringIO()):
+        segModel = _imp("segModel", "segNet/segModel.py")
+        segData = _imp("segData", "segNet/segData.py")
+        segEval = _imp("segEval", "segNet/segEval.py")
+    _seg.update(segModel=segModel, segData=segData, segEval=segEval)
+    return _seg
 
 
 def script_functions(rel_path, names):

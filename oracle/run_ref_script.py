@@ -12,6 +12,8 @@ with the outputs of the reference's own CPU run of the same command on the same 
 
 ``--rfx-ransac-seed S``: reseed the CPU generator with S + k before the k-th ``outil.RANSAC`` call (utils/outil.py:120 draws
 from it), so that the device run -- whose drop-in RANSAC draws from the same generator -- sees the same hypotheses.
+``RFX_SEG_ENCODER / RFX_SEG_DECODER=<.pth>``: the sky-segmentation checkpoints of a ``--segNet`` run (the reference reads them from two
+fixed paths inside its own tree).
 ``RFX_TRUNK_WEIGHTS=<.pth>``: the ResNet-50 trunk weights behind ``models.resnet50(pretrained=True)`` (no ImageNet weights
 offline), shared with the drop-in.
 """
@@ -45,6 +47,17 @@ def main():
             n[0] += 1
             return real(*a, **k)
         outil.RANSAC = ransac
+    if "--segNet" in rest:
+        # evaluation/evalHpatch/evaluation.py --segNet: ``import segEval`` must resolve to the reference's own module, and its two
+        # hard-wired checkpoint paths (evaluation/evalHpatch/coarseAlignFeatMatch.py:63: ../../model/pretrained/*.pth, inside the
+        # read-only reference tree) to the files RFX_SEG_ENCODER / RFX_SEG_DECODER name -- the same override the drop-in honours
+        S = ref_loader.load_seg()
+        real_seg = S["segEval"].SegNet
+
+        class SegNet(real_seg):
+            def __init__(self, encoderPth, decoderPth, *a, **k):
+                super().__init__(os.environ.get("RFX_SEG_ENCODER", encoderPth), os.environ.get("RFX_SEG_DECODER", decoderPth), *a, **k)
+        S["segEval"].SegNet = SegNet
     if os.path.basename(os.path.dirname(script)) == "evalYFCC":
         # evaluation/evalYFCC/evaluation.py:143 hard-codes ``use_cuda=True`` and its CoarseAlign then builds small tensors with
         # ``torch.device("cuda")`` (evalYFCC/coarseAlignFeatMatch.py:154-155,161,176) -- next to ``.cuda()`` (identity here) the one

@@ -504,18 +504,21 @@ extern "C" int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float*
     return rfx_conv3x3_s2_launch(in, wP, scale, shift, residual, out, N, Cin, H, W, Cout, act, tm, rfx_stream(stream));
 }
 
-extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
-                              const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
-                              int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
+// dil = 1: rfx_conv2d_f32.  dil > 1 (rfx_conv2d_dilated_f32): the gather adds the ktab's (kh, kw) fields to the window origin
+// as they are, so a dilated convolution is the SAME kernel with a table that holds kh*dil / kw*dil -- only the output size and the
+// 4-bit field limit know about the dilation.
+static int conv2d_impl(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                       const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                       int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int act, void* stream) {
     if (!in || !wT || !ktab || !out) return RFX_E_ARG;
-    if (N <= 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    if (N <= 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || dil <= 0)
         return RFX_E_ARG;
-    if (KH > 15 || KW > 15 || Cin >= (1 << 22)) return RFX_E_LIMIT;
+    if ((KH - 1) * dil + 1 > 15 || (KW - 1) * dil + 1 > 15 || Cin >= (1 << 22)) return RFX_E_LIMIT;
     ConvArgs a;
     a.in = in; a.wT = wT; a.ktab = ktab; a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.stride = stride; a.pad = pad; a.act = act;
-    a.Hout = (Hin + 2 * pad - KH) / stride + 1;
-    a.Wout = (Win + 2 * pad - KW) / stride + 1;
+    a.Hout = (Hin + 2 * pad - ((KH - 1) * dil + 1)) / stride + 1;
+    a.Wout = (Win + 2 * pad - ((KW - 1) * dil + 1)) / stride + 1;
     if (a.Hout <= 0 || a.Wout <= 0) return RFX_E_ARG;
     if ((long long)Cin * Hin * Win > 0x7fffffffLL) return RFX_E_LIMIT;
     const int K = Cin * KH * KW;
@@ -551,4 +554,18 @@ extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* k
             return one ? launch_conv<1, 2, true, false>(a, st) : launch_conv<1, 2, false, false>(a, st);
         default: return one ? launch_conv<1, 1, true, false>(a, st) : launch_conv<1, 1, false, false>(a, st);
     }
+}
+
+extern "C" int rfx_conv2d_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                              const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                              int Win, int Cout, int KH, int KW, int stride, int pad, int act, void* stream) {
+    return conv2d_impl(in, wT, ktab, scale, shift, residual, out, N, Cin, Hin, Win, Cout, KH, KW, stride, pad, 1, act, stream);
+}
+
+extern "C" int rfx_conv2d_dilated_f32(const float* in, const float* wT, const int32_t* ktab, const float* scale,
+                                      const float* shift, const float* residual, float* out, int N, int Cin, int Hin,
+                                      int Win, int Cout, int KH, int KW, int stride, int pad, int dilation, int act,
+                                      void* stream) {
+    if (dilation == 1) return RFX_E_ARG;      // the undilated geometries belong to rfx_conv2d_f32 / rfx_conv3x3_f32
+    return conv2d_impl(in, wT, ktab, scale, shift, residual, out, N, Cin, Hin, Win, Cout, KH, KW, stride, pad, dilation, act, stream);
 }

@@ -137,8 +137,32 @@ class _CoarseBase:
             self.featt = self._feat(self.It)
             self.Wt, self.Ht = outil.getWHTensor(self.featt)
 
+    # evaluation/evalHpatch/coarseAlignFeatMatch.py:63-64: the reference builds its SegNet in the constructor from two fixed
+    # checkpoint paths (relative to the script's directory) whenever ``segNet`` is true -- which is also the signature's default.
+    # Here the same two files are read when they exist; otherwise the network is built at the first skyFromSeg call (and a missing
+    # checkpoint surfaces there as the FileNotFoundError the reference raises at construction): callers that never ask for a sky mask
+    # (quick_start, the --segNet-less evaluation runs) need no segmentation weights.  RFX_SEG_ENCODER / RFX_SEG_DECODER override the paths.
+    SEG_ENCODER_PTH = '../../model/pretrained/ade20k_resnet50dilated_encoder.pth'
+    SEG_DECODER_PTH = '../../model/pretrained/ade20k_resnet50dilated_decoder.pth'
+
+    def _init_seg(self, segNet, segId, segFg, eager=False):
+        self._seg_args, self.segNet = (segId, segFg) if segNet else None, None
+        enc = os.environ.get("RFX_SEG_ENCODER", self.SEG_ENCODER_PTH)
+        if segNet and (eager or os.path.isfile(enc)):
+            self._build_seg()
+
+    def _build_seg(self):
+        import segEval
+        self.segNet = segEval.SegNet(os.environ.get("RFX_SEG_ENCODER", self.SEG_ENCODER_PTH),
+                                     os.environ.get("RFX_SEG_DECODER", self.SEG_DECODER_PTH), self._seg_args[0], self._seg_args[1])
+
     def skyFromSeg(self, path):
-        raise NotImplementedError("segNet sky masking is outside the hot path (SURVEY.md section 2, #14)")
+        """:152-153 -> SegNet.getSky (segNet/segEval.py:23-43), forward pass on the device (rfx/segnet.py)."""
+        if getattr(self, "_seg_args", None) is None:
+            raise AttributeError("'CoarseAlign' object has no attribute 'segNet'")      # what the reference says for segNet=False
+        if self.segNet is None:
+            self._build_seg()
+        return self.segNet.getSky(path)
 
     def _mask_to_feature_res(self, Mt):
         """1 - Mt -> bilinear resize to the feature grid (align_corners=False) -> > 0.5."""
@@ -192,6 +216,7 @@ class CoarseAlignC(CoarseAlignA):
         if not use_cuda:
             raise RuntimeError("use_cuda=False: the MI355X path has no CPU fallback")
         self._init_common(nbScale, nbIter, tolerance, transform, minSize, imageNet, scaleR, trunk_state_dict, device)
+        self._init_seg(segNet, segId, segFg)
 
 
 class CoarseAlignB(_CoarseBase):
@@ -202,6 +227,7 @@ class CoarseAlignB(_CoarseBase):
     def __init__(self, nbScale, nbIter, tolerance, transform, minSize, segId, segFg, scaleR=2, imageNet=True, segNet=True,
                  trunk_state_dict=None, device="cuda"):
         self._init_common(nbScale, nbIter, tolerance, transform, minSize, imageNet, scaleR, trunk_state_dict, device)
+        self._init_seg(segNet, segId, segFg)
 
     def setPair(self, Is_org, It_org):
         with torch.no_grad():

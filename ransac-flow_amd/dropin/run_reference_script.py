@@ -10,7 +10,7 @@ The reference's scripts import the hot path by bare module name after ``sys.path
 of this directory into ``sys.modules`` under exactly those names (so the script's own imports resolve to
 them), picks the CoarseAlign variant from the script's directory, installs small stand-ins for packages the
 script imports but this image lacks (kornia's HomographyWarper -> librfx warp_grid kernel; torchvision
-transforms; scipy.misc.imresize; segEval), optionally rebinds ``torch.nn.functional.grid_sample`` /
+transforms; scipy.misc.imresize), seats the ``segEval`` drop-in, optionally rebinds ``torch.nn.functional.grid_sample`` /
 ``interpolate`` / ``normalize`` to the librfx kernels for float32 HIP tensors (``RFX_PATCH_FUNCTIONAL=1``,
 default on), and then runs the script with ``runpy`` from its own directory.  ``RFX_RANSAC_SEED=S`` makes the RANSAC draws
 reproducible (see ``seed_ransac_calls``).  A byte-compiled deployment of the reference tree (``align2images.pyc``) runs as is.
@@ -124,7 +124,9 @@ def install_misc_shims():
         sm.imresize = imresize
         sys.modules["scipy.misc"] = sm
         scipy.misc = sm
-    sys.modules.setdefault("segEval", types.ModuleType("segEval"))
+    # ``import segEval`` after sys.path.append('../../segNet') (evaluation/evalHpatch/coarseAlignFeatMatch.py:22-23): the drop-in
+    # of this directory (SegNet.getSky on the device, rfx/segnet.py)
+    sys.modules["segEval"] = importlib.import_module("segEval")
     try:
         import skimage.measure  # noqa: F401
     except ImportError:

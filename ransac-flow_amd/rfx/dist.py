@@ -49,6 +49,45 @@ def gather_records(rec, dist=None, force=False):
     return out
 
 
+class PipelinedGather:
+    """The step's ONE all_gather, overlapped with the next step's compute (round 6).  ``push(rec)`` starts the collective for this
+    step's record block asynchronously (``async_op=True``: ProcessGroupNCCL runs it on its own stream behind the work already queued
+    on the caller's stream; 54 MB per rank and step at 64 pairs, ~4-8 ms at N = 8 over xGMI) and hands back the PREVIOUS step's
+    gathered block, whose collective is waited for only now -- so the gather of step k rides under the trunk pass of step k+1.
+    Two blocks are in flight at most (the one being gathered, the one being filled): ``rec`` must be a tensor the caller does not
+    write again (bench.py's step allocates a fresh MultiHRecords per step).  ``flush()`` waits for the last one.
+    Single process (``dist`` None / world of one rank without ``force``): no collective, same push / flush protocol."""
+
+    def __init__(self, dist=None, force=False):
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force)) else None
+        self._pending = None          # (work handle or None, output tensor, input kept alive)
+
+    def _start(self, rec):
+        if self.dist is None:
+            return (None, rec, rec)
+        world = self.dist.get_world_size()
+        rec = rec.contiguous()
+        out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        return (self.dist.all_gather_into_tensor(out, rec, async_op=True), out, rec)
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        work, out, _ = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()               # nccl: the caller's stream waits for the collective; gloo: the host does
+        return out
+
+    def push(self, rec):
+        prev = self._finish()
+        self._pending = self._start(rec)
+        return prev
+
+    def flush(self):
+        return self._finish()
+
+
 def unshard_order(n_items, world):
     """Permutation that maps the rank-major gathered order back to stream order for round-robin sharding
     (equal shard sizes): gathered[k] is item perm[k]."""

@@ -142,11 +142,15 @@ def _p(t):
 class ConvPlan:
     """Packed weights + folded BatchNorm of one convolution (see rfx_conv2d_f32 in include/rfx_api.h)."""
 
-    def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5):
-        # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None
+    def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5, dilation=1, bias=None):
+        # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None;
+        # dilation > 1: rfx_conv2d_dilated_f32 (the sky-segmentation encoder, segNet/segModel.py:196-205); bias: the convolution's own
+        # bias (segModel.py:243,245: the classifier convolutions), only without bn
         w = weight.detach().float().cpu()
         self.Cout, self.Cin, self.KH, self.KW = w.shape
-        self.stride, self.pad, self.act = stride, pad, act
+        self.stride, self.pad, self.act, self.dilation = stride, pad, act, int(dilation)
+        if bias is not None and bn is not None:
+            raise ValueError("ConvPlan: a convolution bias together with a BatchNorm is not folded here")
         # rfx_conv3x3_f32's k_chunk: 0 = the library's rule (chunks for K >= 2048); 4 = chunks of 4 K steps whatever K is -- set by
         # the nets on the 3x3 convolution of a Bottleneck tail, so that the two-kernel form equals the fused kernel bit for bit
         self.k_chunk = 0
@@ -157,7 +161,8 @@ class ConvPlan:
         self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
         self._wq = None
         self.wP = None
-        if self.KH == 3 and self.KW == 3 and pad == 1 and self.Cin >= 8 and (stride == 1 or (stride == 2 and self.Cin % 8 == 0)):
+        if (self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1 and self.Cin >= 8
+                and (stride == 1 or (stride == 2 and self.Cin % 8 == 0))):
             # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]; a Cin that is not a multiple of 8
             # (the 49-channel correlation volume) gets zero rows for the missing channels of its last K step
             Kp = (self.Cin + 7) // 8 * 72
@@ -168,7 +173,8 @@ class ConvPlan:
         k = torch.arange(K)
         c, r = k // (self.KH * self.KW), k % (self.KH * self.KW)
         ktab = torch.full((Kpad,), -1, dtype=torch.int32)
-        ktab[:K] = ((c << 8) | ((r // self.KW) << 4) | (r % self.KW)).int()
+        # the gather adds these offsets to the window origin as they are: a dilated convolution stores kh*d / kw*d
+        ktab[:K] = ((c << 8) | (((r // self.KW) * self.dilation) << 4) | ((r % self.KW) * self.dilation)).int()
         # per 32-k block: [16 even k | 16 odd k] (the order in which one MFMA lane-half consumes them)
         ktab = ktab.view(-1, 16, 2).permute(0, 2, 1).reshape(-1).contiguous()
         dev = device or "cuda"
@@ -179,6 +185,8 @@ class ConvPlan:
             alpha = bn["weight"].detach().float().cpu() * invstd
             beta = bn["bias"].detach().float().cpu() - bn["running_mean"].detach().float().cpu() * alpha
             self.scale, self.shift = alpha.to(dev), beta.to(dev)
+        elif bias is not None:
+            self.scale, self.shift = torch.ones(self.Cout, dtype=torch.float32).to(dev), bias.detach().float().cpu().to(dev)
         else:
             self.scale = self.shift = None
 
@@ -192,7 +200,8 @@ class ConvPlan:
         return self._wq
 
     def out_hw(self, H, W):
-        return (H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1
+        eh, ew = (self.KH - 1) * self.dilation + 1, (self.KW - 1) * self.dilation + 1
+        return (H + 2 * self.pad - eh) // self.stride + 1, (W + 2 * self.pad - ew) // self.stride + 1
 
     def __call__(self, x, residual=None, act=None):
         x = _dev(x, "conv input")
@@ -205,6 +214,11 @@ class ConvPlan:
         if res is not None and res.shape != out.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(res.shape), tuple(out.shape)))
         lib = _lib.load()
+        if self.dilation != 1:
+            _call("rfx_conv2d_dilated_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift),
+                  _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad, self.dilation,
+                  self.act if act is None else act)
+            return out
         kid0 = 0
         if self.wP is not None:
             kid0 = (lib.rfx_conv3x3_kernel_id(N, self.Cin, self.Cout, Ho, Wo, self.k_chunk) if self.stride == 1 else
@@ -334,6 +348,43 @@ def stem_conv7_maxpool(x, plan):
         Profiler.active().conv.append((257, 2.0 * N * Hc * Wc * plan.Cout * 147, e0, e1, (N, 3, H, W, plan.Cout, 7, 2),
                       4.0 * (N * 3 * H * W + N * plan.Cout * Hp * Wp)))
     return out
+
+
+def adaptive_avgpool2d(x, size):
+    """nn.AdaptiveAvgPool2d(size) (segNet/segModel.py:227)."""
+    x = _dev(x, "adaptive_avgpool input")
+    N, C, H, W = x.shape
+    Ho, Wo = (int(size), int(size)) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    out = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _call("rfx_adaptive_avgpool2d_f32", x.device, _p(x), _p(out), N * C, H, W, Ho, Wo)
+    return out
+
+
+def softmax_accum(logits, scores=None, div=1.0):
+    """scores (+)= softmax(logits, dim=1) / div for (N,C,H,W) logits (segNet/segModel.py:258 + segNet/segEval.py:34-35); a new
+    tensor when ``scores`` is None, else updated IN PLACE."""
+    logits = _dev(logits, "logits")
+    N, C = logits.shape[0], logits.shape[1]
+    HW = logits.numel() // (N * C)
+    acc = scores is not None
+    if acc:
+        if not scores.is_contiguous() or scores.shape != logits.shape or scores.dtype != torch.float32 or not scores.is_cuda:
+            raise ValueError("scores must be a contiguous float32 device tensor of the logits' shape (updated in place)")
+    else:
+        scores = torch.empty_like(logits)
+    _call("rfx_softmax_accum_f32", _one_device(logits, scores), _p(logits), _p(scores), N, C, HW, float(div), 1 if acc else 0)
+    return scores
+
+
+def argmax_mask(scores, class_id, complement=False, want_pred=False):
+    """torch.max(scores, dim=1) -> float32 mask (N,H,W) = (pred == class_id) (``complement``: 1 - that) [, pred int32]
+    (segNet/segEval.py:37-43)."""
+    scores = _dev(scores, "scores")
+    N, C, H, W = scores.shape
+    mask = torch.empty((N, H, W), dtype=torch.float32, device=scores.device)
+    pred = torch.empty((N, H, W), dtype=torch.int32, device=scores.device) if want_pred else None
+    _call("rfx_argmax_mask_f32", scores.device, _p(scores), N, C, H * W, int(class_id), 1 if complement else 0, _p(mask), _p(pred))
+    return (mask, pred) if want_pred else mask
 
 
 def l2norm(x, out=None, out_batch_stride=0, out_chan_stride=0):

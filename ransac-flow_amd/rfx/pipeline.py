@@ -339,8 +339,8 @@ class AlignPipeline:
         # (largest level first) so that the launch tails of one level -- the /16 maps of the small levels have few
         # workgroups per layer -- overlap with the next level's kernels; every level still writes its own columns of featA.
         # Default: one stream per level for small batches (B <= 4: a layer of one level has too few workgroups to fill 256 CUs
-        # -- a single 480x640 pair drops from 15.9 to 10.6 ms), one stream otherwise (at batch 64 two streams give +2 %, but
-        # overlapping launches distort the per-kernel event timing bench.py's roofline is computed from).
+        # -- a single 480x640 pair drops from 15.9 to 10.6 ms), four streams otherwise; ONE stream under an ops.Profiler
+        # (overlapping launches would distort the per-kernel event timing bench.py's rooflines are computed from).
         # (measured, coarse stage of 480x640 pairs: B = 1 7.73 -> 6.83 ms, B = 2 10.15 -> 9.99 ms, B = 4 16.7 -> 18.3 ms: from four
         # pairs on the per-level batches are large enough for the 8-stream form to win)
         grouped = (B <= 2 and os.environ.get("RFX_GROUPED", "1") != "0" and ops.Profiler.active() is None
@@ -407,7 +407,9 @@ class AlignPipeline:
                     f.record_stream(main_s)
             ft_raw = fs[shared][B:] if shared is not None else fs[-1]
         env = os.environ.get("RFX_TRUNK_STREAMS")
-        nstream = max(1, int(env)) if env else (len(prep["src"]) if B <= 4 else 1)
+        # larger batches: 4 streams (round 6, profiles/r06_stream_sweep.txt: 1 / 2 / 4 / 8 streams = 113.6 / 113.0 / 114.6 / 114.8 pairs/s
+        # on config 3 with 3 lock-step groups) -- the tail of one level's layer overlaps another level's kernels
+        nstream = max(1, int(env)) if env else (len(prep["src"]) if B <= 4 else min(4, len(prep["src"])))
         if ops.Profiler.active() is not None:
             nstream = 1          # per-launch event timing: overlapping streams would charge one kernel with another's time
         main = torch.cuda.current_stream(self.dev)
@@ -676,8 +678,9 @@ class AlignPipeline:
         resumes the group whose event is due): while one group waits for the host -- accept flags, the LAPACK stage -- the other
         groups' kernels keep the GPU busy, and the small launches of one group's late rounds share the chip with another's.
         Per pair the arithmetic is unchanged (every kernel computes a pair independently; device draws are keyed by absolute
-        pair position / id).  None = RFX_MULTIH_SPLIT or 2 for device draws with B >= 16, else 1; forced to 1 with host draws /
-        ``sample_fn`` (the CPU generator is consumed in pair order) and with ``trace``.
+        pair position / id).  None = RFX_MULTIH_SPLIT or, for device draws, 3 groups from 48 pairs on, 2 from 16 (measured on config 3,
+        profiles/r06_stream_sweep.txt: 1 / 2 / 3 groups = 110.2 / 112.7 / 113.6 pairs/s), else 1; forced to 1 with host draws /
+        ``sample_fn`` (the CPU generator is consumed in pair order), with ``trace`` and under an ops.Profiler (per-launch events).
         ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; costs a second sync per round).
         ``pair_ids``: absolute ids of the batch's pairs for the device draw (see _draw_epoch): with them a pair's homographies
         are the same alone, in any batch and under any sharding.
@@ -693,7 +696,7 @@ class AlignPipeline:
         idx1, idx2, cnt = self._mutual_batched(feats, B)
         host_draw = sample_fn is not None or self.draw == "host"
         if split is None:
-            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (2 if B >= 16 else 1)
+            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (3 if B >= 48 else (2 if B >= 16 else 1))
         if host_draw or trace is not None or ops.Profiler.active() is not None and os.environ.get("RFX_MULTIH_SPLIT_PROFILED", "0") != "1":
             split = 1
         split = max(1, min(int(split), B))

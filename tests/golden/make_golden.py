@@ -482,6 +482,40 @@ def gen_kitti_loop():
     np.savez_compressed(os.path.join(HERE, "kitti_loop.npz"), **out)
 
 
+def gen_seg():
+    """the REFERENCE's SegNet.getSky (segNet/segEval.py:23-43 on segNet/segModel.py, imported by ref_loader.load_seg)
+    on one synthetic 96x128 image with seeded random-init weights (rfx/weights.py seg_encoder_sd(4) / seg_decoder_sd(5, logit_std=0.003: class scores that are not saturated), BN
+    statistics perturbed): the class map, the averaged class probabilities on a pixel lattice, and the two masks the scripts
+    use (segId of the most frequent class, segFg True / False)."""
+    import tempfile
+    S = ref_loader.load_seg()
+    enc, dec = weights.seg_encoder_sd(4, randomize_bn=True), weights.seg_decoder_sd(5, randomize_bn=True, logit_std=0.003)
+    I1, _ = synth.make_pair(96, 128, seed=3)
+    d = tempfile.mkdtemp()
+    pe, pd_, pi = os.path.join(d, "enc.pth"), os.path.join(d, "dec.pth"), os.path.join(d, "img.png")
+    torch.save(enc, pe)
+    torch.save(dec, pd_)
+    I1.save(pi)
+    sn = ref_loader.quiet(S["segEval"].SegNet, pe, pd_, 1, True)
+    with torch.no_grad():
+        IT = sn.dataset_test.getImg(pi)
+        seg_size = (IT["img_ori"].shape[0], IT["img_ori"].shape[1])
+        scores = torch.zeros(1, 150, *seg_size)
+        for img in IT["img_data"]:
+            scores = scores + sn.net(img, segSize=seg_size) / 5                   # segEval.py:30-35
+    pred = scores.max(dim=1)[1][0].numpy()
+    seg_id = int(np.bincount(pred.reshape(-1)).argmax())
+    sn.segId = seg_id
+    fg = sn.getSky(pi)
+    sn.segFg = False
+    bg = sn.getSky(pi)
+    assert np.array_equal(fg, 1 - (pred == seg_id)) and np.array_equal(bg, (pred == seg_id).astype(np.float32))
+    print("seg: %d classes predicted, segId %d covers %.2f" % (np.unique(pred).size, seg_id, bg.mean()))
+    np.savez_compressed(os.path.join(HERE, "seg.npz"), pred=pred.astype(np.uint8), scores_sub=scores[0, :, ::8, ::8].numpy(),
+                        seg_id=np.asarray(seg_id), mask_fg=fg.astype(np.uint8), mask_bg=bg.astype(np.uint8),
+                        sizes=np.asarray([x.shape[-2:] for x in IT["img_data"]]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
@@ -498,3 +532,4 @@ if __name__ == "__main__":
     gen_coarse_b()
     gen_multi_h()
     gen_kitti_loop()
+    gen_seg()

@@ -59,6 +59,54 @@ def test_shard_and_single_gather_world2():
     assert torch.equal(rdist.gather_records(g, None), g)       # single process: identity
 
 
+def _pipelined_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
+    import torch.distributed as dist
+    from rfx import dist as rdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = rdist.PipelinedGather(dist)
+    got = []
+    for step in range(4):                       # every step a FRESH block (as bench.py's step allocates one): [rank, step, row]
+        rec = torch.stack([torch.tensor([float(rank), float(step), float(i)]) for i in range(3)])
+        prev = pg.push(rec)
+        assert (prev is None) == (step == 0)
+        if prev is not None:
+            got.append(prev.clone())
+    got.append(pg.flush().clone())
+    assert pg.flush() is None
+    q.put((rank, torch.stack(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_returns_every_steps_block_one_step_late_world2():
+    """rfx.dist.PipelinedGather (bench.py's timed loop since round 6): the all_gather of step k is started asynchronously and
+    collected when step k+1 pushes -- every step's block arrives complete, rank-major, in step order, on both ranks; the last one
+    comes out of flush().  A single process runs the same protocol without a collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.equal(outs[0], outs[1]) and outs[0].shape == (4, 6, 3)
+    for step in range(4):
+        blk = outs[0][step]
+        assert blk[:, 1].eq(step).all() and blk[:, 0].tolist() == [0, 0, 0, 1, 1, 1] and blk[:, 2].tolist() == [0, 1, 2] * 2
+    sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
+    from rfx import dist as rdist
+    pg = rdist.PipelinedGather(None)
+    a, b = torch.ones(2, 3), torch.zeros(2, 3)
+    assert pg.push(a) is None and pg.push(b) is a and pg.flush() is b and pg.flush() is None
+
+
 def test_bench_rank_code_self_spawns_two_gloo_ranks():
     """bench.py's REAL rank code path -- `python bench.py --gpus 2` with no launcher environment must re-exec itself under
     torch.distributed.run, build the process group, run warm-up + timed steps between barriers, gather the records with the

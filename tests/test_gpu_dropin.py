@@ -245,7 +245,7 @@ def _reference_tree():
     return ref_loader
 
 
-def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16, tail=()):
+def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16, tail=(), extra_env=None):
     """One unchanged reference script, same command line twice: on the MI355X drop-ins (dropin/run_reference_script.py) and as
     the reference itself on this box's host cores (oracle/run_ref_script.py); the k-th RANSAC call of both runs draws from the
     CPU generator seeded with seed + k.  Returns the two output prefixes."""
@@ -258,7 +258,7 @@ def _run_both(rel_script, args, tmp_path, seed, out_flag, cpu_threads=16, tail=(
         out = str(tmp_path / ("out_" + side)) + ("/" if out_flag == "--outdir" else "")
         if out_flag == "--outdir" and not os.path.isdir(out):
             os.makedirs(out)
-        env = dict(os.environ, MPLBACKEND="Agg", RFX_TRUNK_WEIGHTS=str(trunk), RFX_REFERENCE_ROOT=rl.REF_ROOT)
+        env = dict(os.environ, MPLBACKEND="Agg", RFX_TRUNK_WEIGHTS=str(trunk), RFX_REFERENCE_ROOT=rl.REF_ROOT, **(extra_env or {}))
         if side == "gpu":
             env["RFX_RANSAC_SEED"] = str(seed)
             cmd = [sys.executable, os.path.join(DROPIN, "run_reference_script.py"), os.path.join(rl.REF_ROOT, rel_script)]
@@ -334,6 +334,62 @@ def test_unchanged_evalhpatch_script_on_a_synthetic_stream_vs_the_reference_cpu_
     # a scene whose cached match list differs by a float32 near-tie draws other samples (nMatch enters torch.randint) and may
     # stop at another homography count: tests/test_gpu_parity_sweep.py counts and bounds those; here at most one scene may
     assert same_nb >= 4 and exact >= 4, (same_nb, exact)
+
+
+def test_unchanged_evalhpatch_script_with_segnet_sky_masks_vs_the_reference_cpu_run(dev, tmp_path):
+    """SURVEY 8f4 / VERDICT r5 #7: ``evaluation/evalHpatch/evaluation.py --segNet`` ITSELF, unmodified -- per pair the script asks
+    ``coarseModel.skyFromSeg(target .ppm)`` (:177-180), thresholds the resized mask into It_bg and runs the multi-homography loop on
+    the foreground only -- with the segmentation forward pass on the device (dropin/segEval.py -> rfx/segnet.py) against the
+    reference's own SegNet on the host CPU.  Seeded random-init ade20k-shaped checkpoints (the script's class id 2 is given the
+    classifier rows of a class that covers part of these images, so that the mask is neither empty nor full) reach both runs through RFX_SEG_ENCODER / RFX_SEG_DECODER
+    (the reference reads two fixed paths inside its own tree).  Compared: the saved background maps (maskBG_*), then everything the
+    script saves per pair as in the test above."""
+    sds = {"netFeatCoarse": weights.feature_extractor_sd(1), "netCorr": {}, "netFlowCoarse": weights.net_flow_coarse_sd(2),
+           "netMatch": weights.net_matchability_sd(3, last_std=3.0)}
+    ck = tmp_path / "ck.pth"
+    torch.save(sds, str(ck))
+    enc, dec = weights.seg_encoder_sd(4, randomize_bn=True), weights.seg_decoder_sd(5, randomize_bn=True, logit_std=0.003)
+    for k in ("weight", "bias"):                                   # class 2 <-> class 61 (the runner-up on these images: ~10 % "sky")
+        t = dec["conv_last.4." + k]
+        t[[2, 61]] = t[[61, 2]].clone()
+    torch.save(enc, str(tmp_path / "seg_enc.pth"))
+    torch.save(dec, str(tmp_path / "seg_dec.pth"))
+    os.makedirs(str(tmp_path / "csv"))
+    scenes = (2, 3, 4)
+    for k in scenes:
+        obj = "v_synth%d" % k
+        os.makedirs(str(tmp_path / "img" / obj))
+        I1, I2 = synth.make_pair(240, 320, seed=40 + k, homography=True)
+        I1.save(str(tmp_path / "img" / obj / "1.ppm"))
+        I2.save(str(tmp_path / "img" / obj / ("%d.ppm" % k)))
+    for k in range(2, 7):                                          # the script walks hpatches_1_2 .. hpatches_1_6
+        rows = "%s,1,%d\n" % ("v_synth%d" % k, k) if k in scenes else ""
+        open(str(tmp_path / "csv" / ("hpatches_1_%d.csv" % k)), "w").write("obj,im1,im2\n" + rows)
+    args = ["--csv-path", str(tmp_path / "csv"), "--image-data-path", str(tmp_path / "img"), "--coarseIter", "1000", "--nbScale", "3",
+            "--minSize", "240", "--scaleR", "1.2", "--imageNet", "--resumePth", str(ck), "--segNet"]
+    g, c = _run_both("evaluation/evalHpatch/evaluation.py", args, tmp_path, 29, "--outDir",
+                     extra_env=dict(RFX_SEG_ENCODER=str(tmp_path / "seg_enc.pth"), RFX_SEG_DECODER=str(tmp_path / "seg_dec.pth")))
+    exact, bg_cover = 0, []
+    for k in scenes:
+        fg, fc = (sorted(os.listdir(os.path.join(d + "_Fine", str(k)))) for d in (g, c))
+        assert len(fg) == 3 and len(fc) == 3, (fg, fc)
+        bgn = [f for f in fg if f.startswith("maskBG_")][0], [f for f in fc if f.startswith("maskBG_")][0]
+        Bg, Bc = np.load(os.path.join(g + "_Fine", str(k), bgn[0])), np.load(os.path.join(c + "_Fine", str(k), bgn[1]))
+        assert Bg.dtype == bool and Bg.shape == Bc.shape
+        bg_cover.append(float(Bc.mean()))
+        d_bg = float((Bg != Bc).mean())
+        print("scene %d: foreground share %.3f (cpu), background maps differ on %.5f of the pixels" % (k, Bc.mean(), d_bg))
+        assert d_bg < 5e-3
+        if fg != fc:
+            print("scene %d: %s vs %s" % (k, fg, fc))
+            continue
+        name = [f for f in fg if f.startswith("flow_")][0]
+        Hg, Hc = (np.load(os.path.join(d + "_Coarse", str(k), name)) for d in (g, c))
+        Fg, Fc = (np.load(os.path.join(d + "_Fine", str(k), name)) for d in (g, c))
+        if d_bg == 0 and np.abs(Hg - Hc).max() <= 1e-5 and np.abs(Fg - Fc).max() < 1e-3:
+            exact += 1
+    assert 0.02 < min(bg_cover) and max(bg_cover) < 0.98, bg_cover          # the masks really cut something away
+    assert exact >= len(scenes) - 1, exact
 
 
 def test_unchanged_evalkitti_script_on_a_synthetic_stream_vs_the_reference_cpu_run(dev, tmp_path):

@@ -443,3 +443,35 @@ def test_rccl_transport_with_a_world_of_one_rank(dev):
     j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["gathered_records"] == 8 and j["config"]["aligned_ok_last_step"] == 8
     assert "nccl" in j["config"]["collective"]
+
+
+def test_two_rccl_ranks_give_every_pair_the_one_rank_record(dev, tmp_path):
+    """the first REAL N > 1 execution, wherever the box exposes >= 2 GPUs (skipped on the 1-GPU boxes of this pool):
+    ``bench.py --gpus 2`` spawns two RCCL ranks (one per GPU), every rank aligns its shard (pair i -> rank i mod 2) and the per-step
+    result records go through ONE pipelined all_gather over xGMI.  Checked: both ranks' records arrive (``ranks_seen_in_gather``), and
+    the record of every pair -- homography count, homographies, /8 flows, matchability maps -- equals, bit for bit, the record the
+    same pair gets in a 1-rank run of the same stream (device draws are keyed by the ABSOLUTE pair id, the exact mode's LAPACK
+    stage is per pair: nothing depends on the sharding)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device: profiles/r03_bench_2ranks_on_1gpu_rccl_refused.log)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-exact-leg", "--no-qs-leg", "--score-chunk", "256"]
+    two, one = str(tmp_path / "two.pt"), str(tmp_path / "one.pt")
+    o2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--dump-records", two] + common,
+                        capture_output=True, text=True, timeout=900, env=env)
+    assert o2.returncode == 0, o2.stderr[-2000:]
+    j2 = json.loads([ln for ln in o2.stdout.splitlines() if ln.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and j2["config"]["ranks_seen_in_gather"] == [0, 1] and j2["config"]["gathered_records"] == 8
+    assert j2["config"]["n_ranks_in_rccl"] == 2 and "nccl" in j2["config"]["collective"]
+    o1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "8", "--dump-records", one] + common,
+                        capture_output=True, text=True, timeout=900, env=env)
+    assert o1.returncode == 0, o1.stderr[-2000:]
+    d2, d1 = torch.load(two), torch.load(one)
+    assert sorted(d2["pair_ids"]) == list(range(8)) and d1["pair_ids"] == list(range(8))
+    keep = [c for c in range(d1["records"].shape[1]) if c != 2]            # column 2 = the producer's rank
+    for row, pid in enumerate(d2["pair_ids"]):
+        assert torch.equal(d2["records"][row, keep], d1["records"][pid, keep]), pid

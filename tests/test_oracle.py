@@ -351,6 +351,53 @@ def test_config1_coarse_to_fine_matches_reference_golden():
     assert np.abs(st["flow12"][:, ::8, ::8].numpy() - g["flow12_sub"]).max() < 1e-4
 
 
+# ---------------------------------------------------------------- sky segmentation
+
+
+def test_seg_restatement_matches_the_reference_golden():
+    """oracle/restate.py::seg_scores / seg_get_sky (SegNet.getSky of segNet/segEval.py:23-43 over segNet/segModel.py, restated) against
+    tests/golden/seg.npz -- the REFERENCE's own output (make_golden.py::gen_seg): class map, averaged class probabilities, both masks.
+    Equal to the last bit on the authoring machine; another CPU's convolution kernels round differently, hence the small tolerance."""
+    g = np.load(os.path.join(GOLD, "seg.npz"))
+    enc, dec = weights.seg_encoder_sd(4, randomize_bn=True), weights.seg_decoder_sd(5, randomize_bn=True, logit_std=0.003)
+    I1, _ = synth.make_pair(96, 128, seed=3)
+    assert [list(s[::-1]) for s in restate.seg_test_sizes(128, 96)] == g["sizes"].tolist()
+    sc = restate.seg_scores(enc, dec, I1)
+    assert float((sc[0, :, ::8, ::8] - torch.from_numpy(g["scores_sub"])).abs().max()) < 1e-4
+    pred = sc.max(dim=1)[1][0].numpy()
+    assert (pred != g["pred"]).mean() < 1e-3
+    seg_id = int(g["seg_id"])
+    same = pred == g["pred"]
+    assert np.array_equal(restate.seg_get_sky(enc, dec, I1, seg_id, True)[same], g["mask_fg"].astype(np.float32)[same])
+    assert np.array_equal(restate.seg_get_sky(enc, dec, I1, seg_id, False)[same], g["mask_bg"].astype(np.float32)[same])
+
+
+@pytest.mark.reference
+def test_seg_restatement_matches_live_reference(tmp_path):
+    """The same restatement against the live reference (segNet/segEval.py's SegNet, imported by oracle/ref_loader.load_seg under the
+    collections.abc aliases its vendored Synchronized-BatchNorm package needs) on a fresh image and fresh weights: bit-equal scores."""
+    import ref_loader
+    S = ref_loader.load_seg()
+    enc, dec = weights.seg_encoder_sd(14), weights.seg_decoder_sd(15, logit_std=0.002)
+    img, _ = synth.make_pair(72, 104, seed=9)
+    pe, pd_, pi = str(tmp_path / "e.pth"), str(tmp_path / "d.pth"), str(tmp_path / "i.png")
+    torch.save(enc, pe)
+    torch.save(dec, pd_)
+    img.save(pi)
+    sn = ref_loader.quiet(S["segEval"].SegNet, pe, pd_, 2, False)
+    with torch.no_grad():
+        IT = sn.dataset_test.getImg(pi)
+        seg_size = (IT["img_ori"].shape[0], IT["img_ori"].shape[1])
+        sc = torch.zeros(1, 150, *seg_size)
+        for x in IT["img_data"]:
+            sc = sc + sn.net(x, segSize=seg_size) / 5
+    assert [tuple(x.shape[-2:])[::-1] for x in IT["img_data"]] == restate.seg_test_sizes(104, 72)
+    assert torch.equal(restate.seg_scores(enc, dec, img), sc)
+    for fg in (True, False):
+        sn.segFg = fg
+        assert np.array_equal(sn.getSky(pi), restate.seg_get_sky(enc, dec, img, 2, fg))
+
+
 # ---------------------------------------------------------------- C ABI surface
 
 
@@ -798,7 +845,7 @@ def test_kernel_resources_are_what_design_says():
     out of librfx.so's code objects and locates each scratch instruction relative to the MFMA loops): the occupancy each hot kernel
     was tiled for is the occupancy the register and LDS budgets grant, the DLT kernel keeps its fp64 matrices in registers, and no
     kernel pays a spill per K step beyond one scratch instruction per 36 MFMAs (the two known cases: the chunked stride-2 3x3 kernel
-    and the 128-channel fused Bottleneck tail, both at the 256-VGPR cap).  profiles/r05_kernel_resources.tsv is this table."""
+    and the 128-channel fused Bottleneck tail, both at the 256-VGPR cap).  profiles/r06_kernel_resources.tsv is this table."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
     kr = importlib.util.module_from_spec(spec)
@@ -839,7 +886,7 @@ def test_kernel_resources_are_what_design_says():
         if row["kernel"] in mix:
             assert all(str(mix[row["kernel"]][c]) == row[c] for c in ("mfma", "ds_read", "ds_write", "vmem_load", "barrier")), row
     # the committed table is the table of this build
-    path = os.path.join(ROOT, "profiles", "r05_kernel_resources.tsv")
+    path = os.path.join(ROOT, "profiles", "r06_kernel_resources.tsv")
     lines = [l.rstrip("\n").split("\t") for l in open(path) if not l.startswith("#")]
     assert lines[0] == kr.COLS
     committed = {l[1]: dict(zip(kr.COLS, l)) for l in lines[1:]}
