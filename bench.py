@@ -553,14 +553,16 @@ def rooflines(prof, elapsed, rank, cfg="3", dev=None):
                 "frac": round(cb / cd / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": cb, "launches": len(prof.corr),
                 "avg_launch_us": round(cd * 1e6, 2),
                 "traffic_note": "PMC per-launch traffic of this kernel: profiles/ (static, separate --pmc passes)"}
-        if dev is not None:
-            # `achieved` / `frac` by KERNEL duration (back-to-back launches between one event pair); the per-launch event interval of
-            # the timed region (one 150 us kernel + its launch overhead) stays beside it
-            b2b = corr_back_to_back(dev, cb, bidir=False)
-            corr.update(event_interval_us=corr["avg_launch_us"], frac_by_event_interval=corr["frac"], achieved=b2b["achieved"], frac=b2b["frac"],
-                        avg_launch_us=b2b["kernel_us"], duration_source="%d launches back to back between one HIP event pair on the launch "
-                        "stream, rotating input sets of the timed shape (%d pairs x 256 x 60 x 80); the timed region's per-launch event "
-                        "interval (event_interval_us) brackets one kernel plus ~18 us of launch overhead" % (b2b["launches"], b2b["pairs"]))
+        kus = prof.corr_durations()[0] if hasattr(prof, "corr_durations") else []
+        if len(kus) == len(prof.corr):
+            # `achieved` / `frac` by KERNEL duration: the start / stop events hipExtLaunchKernelGGL attaches to the dispatch itself
+            # (rfx_corr_timing; the timestamps rocprofv3 reads), same launches, same timed region.  The interval between two events
+            # recorded AROUND a launch (event_interval_us) also brackets ~18 us of command-processor work per 150 us kernel.
+            kd = sum(kus) / len(kus) * 1e-6
+            corr.update(event_interval_us=corr["avg_launch_us"], frac_by_event_interval=corr["frac"], achieved=round(cb / kd / 1e9, 1),
+                        frac=round(cb / kd / 1e9 / PEAK_HBM_GBS, 4), avg_launch_us=round(kd * 1e6, 2),
+                        duration_source="dispatch-level start/stop events of every launch of the timed region (hipExtLaunchKernelGGL, "
+                                        "rfx_corr_timing): the kernel's own duration, as rocprofv3 --kernel-trace reports it")
         trc, srcc = pmc_traffic("corr7_dma_kernel", "qs" if cfg == "qs" else cfg)
         if trc is not None and cfg == "qs":
             corr["traffic"] = round(trc)
@@ -586,47 +588,23 @@ def rooflines(prof, elapsed, rank, cfg="3", dev=None):
         fd = sum(e0.elapsed_time(e1) * 1e-3 for _, _, e0, e1 in full) / len(full)
         bid["full_batch_launches"] = {"launches": len(full), "bytes_per_launch": top, "avg_launch_us": round(fd * 1e6, 2),
                                       "achieved": round(top / fd / 1e9, 1), "frac": round(top / fd / 1e9 / PEAK_HBM_GBS, 4)}
-        if dev is not None:
-            b2b = corr_back_to_back(dev, top, bidir=True)
+        kusb = prof.corr_durations()[1] if hasattr(prof, "corr_durations") else []
+        if len(kusb) == nb:
+            kd = sum(kusb) / nb * 1e-6
+            bid.update(event_interval_us=bid["avg_launch_us"], frac_by_event_interval=bid["frac"], achieved=round(mb / kd / 1e9, 1),
+                       frac=round(mb / kd / 1e9 / PEAK_HBM_GBS, 4), avg_launch_us=round(kd * 1e6, 2),
+                       duration_source="dispatch-level start/stop events (rfx_corr_timing), every launch of the timed region")
+            bid["per_direction_accounting"].update(achieved=round(pb / kd / 1e9, 1), frac=round(pb / kd / 1e9 / PEAK_HBM_GBS, 4))
+            fk = [u for u, x in zip(kusb, prof.corr_bidir) if x[0] == top]
+            fkd = sum(fk) / len(fk) * 1e-6
             bid["full_batch_launches"].update(event_interval_us=bid["full_batch_launches"]["avg_launch_us"],
-                                              frac_by_event_interval=bid["full_batch_launches"]["frac"], kernel_us_back_to_back=b2b["kernel_us"],
-                                              achieved=b2b["achieved"], frac=b2b["frac"], avg_launch_us=b2b["kernel_us"],
-                                              per_direction_frac=round(2 * (2 * 256 + 49) / (2 * 256 + 98) * b2b["frac"], 4))
+                                              frac_by_event_interval=bid["full_batch_launches"]["frac"], avg_launch_us=round(fkd * 1e6, 2),
+                                              achieved=round(top / fkd / 1e9, 1), frac=round(top / fkd / 1e9 / PEAK_HBM_GBS, 4))
         if corr is None:
             corr = bid
         else:
             corr["bidir"] = bid
     return roof, corr
-
-
-def corr_back_to_back(dev, bytes_per_launch, bidir, launches=30, sets=3):
-    """Duration of ONE correlation launch without the ~18 us of launch overhead a per-launch event pair brackets around a 150 us
-    kernel (VERDICT r5 Weak #2: the BENCH line read 0.515 where rocprofv3's kernel duration gave 0.577): ``launches`` launches back
-    to back between ONE event pair on the launch stream, on ``sets`` rotating input sets of the timed batch's shape (3 x 630 MB at
-    64 pairs: larger than the 256 MB Infinity Cache, as in the pipeline, where x / y were just written by the L2-norm kernel).
-    The per-launch figure still contains one kernel boundary (~1.5 us)."""
-    import torch
-    from rfx import ops
-    per_px = (2 * 256 + (98 if bidir else 49)) * 4.0
-    N = max(1, int(round(bytes_per_launch / (per_px * 60 * 80))))
-    g = torch.Generator(device=dev).manual_seed(11)
-    data = [(torch.nn.functional.normalize(torch.randn(N, 256, 60, 80, device=dev, generator=g), dim=1),
-             torch.nn.functional.normalize(torch.randn(N, 256, 60, 80, device=dev, generator=g), dim=1)) for _ in range(sets)]
-    out = torch.empty((2 * N if bidir else N, 49, 60, 80), device=dev)
-    run = (lambda x, y: ops.corr_neigh_bidir(x, y, out=out)) if bidir else (lambda x, y: ops.corr_neigh(x, y))
-    for k in range(6):
-        run(*data[k % sets])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st = torch.cuda.current_stream(dev)
-    e0.record(st)
-    for k in range(launches):
-        run(*data[k % sets])
-    e1.record(st)
-    e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / launches
-    nb = per_px * N * 60 * 80
-    return {"pairs": N, "launches": launches, "kernel_us": round(us, 2), "bytes_per_launch": nb, "achieved": round(nb / us / 1e3, 1),
-            "frac": round(nb / us / 1e3 / PEAK_HBM_GBS, 4)}
 
 
 class _NoProf:

@@ -126,7 +126,10 @@ int rfx_conv3x3_f32(const float* in, const float* wP, const float* scale, const 
                     float* out, int N, int Cin, int H, int W, int Cout, int act, int k_chunk, void* stream);
 int rfx_conv3x3_kernel_id(int N, int Cin, int Cout, int H, int W, int k_chunk);
 /* The same for stride 2 (pad 1, Cin % 8 == 0): out (N, Cout, (H-1)/2+1, (W-1)/2+1); wP as above.  Bit-identical to
- * rfx_conv2d_f32 on the same geometry. */
+ * rfx_conv2d_f32 on the same geometry for K = 9 Cin < 1152 ONLY: from Cin = 128 on (K >= 1152) this kernel sums in chunks of 288
+ * products (conv3x3_s2_kernel<TM, 4>: bit 14 of the kernel id), the implicit-GEMM kernel behind rfx_conv2d_f32 in ONE chain -- the two
+ * then differ in the last bit, and so do trunk features when the host mirror is switched to the generic kernel (RFX_CONV_S2=0 /
+ * RFX_CONV_DIRECT=0 are A/B switches for experiments, not product settings: they change the sums). */
 int rfx_conv3x3_s2_f32(const float* in, const float* wP, const float* scale, const float* shift, const float* residual,
                        float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 
@@ -249,6 +252,13 @@ int rfx_corr_neigh_variant_f32(const float* x, const float* y, float* out, int N
  * pointers (the host mirror pads other widths with rfx_copy_cols_f32); K must be 7. */
 int rfx_corr_neigh_bidir_f32(const float* x, const float* y, float* out_xy, float* out_yx, int N, int C, int H, int W, int K,
                              void* stream);
+/* Kernel-duration capture for the roofline of THIS kernel (bench.py): while a host thread has it enabled, every correlation launch of
+ * that thread is issued with hipExtLaunchKernelGGL and a library-owned start / stop event pair attached to the dispatch itself (the
+ * timestamps rocprofv3 reads; an event pair recorded around a launch also brackets ~18 us of command-processor work).
+ * rfx_corr_timing(enable) returns the previous setting; rfx_corr_timing_collect waits for the captured launches, writes their
+ * durations in microseconds in launch order (up to cap; us_out may be NULL), releases the events and returns how many there were. */
+int rfx_corr_timing(int enable);
+int rfx_corr_timing_collect(float* us_out, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * Warping (kornia HomographyWarper.warp_grid: quick_start/align2images.py:61,65;

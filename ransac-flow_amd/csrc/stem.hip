@@ -188,14 +188,26 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // ResNet-50 stem (model/resnet50.py:115-120, forward :157-160 as sliced by quick_start/coarseAlignFeatMatch.py:38-41):
 //     conv7x7(3 -> 64, stride 2, pad 3) -> BatchNorm (folded) -> ReLU -> MaxPool2d(3, stride 2, pad 1)
-// Same scheme: a workgroup owns 4 x 16 pooled outputs for 32 channels, computes the 9 x 33 conv outputs under them on
-// the MFMA from a 3 x 23 x 71 input patch in LDS (k = c*49 + kh*7 + kw, 147 padded to 148, same order and pairing as
+// Same scheme: a workgroup owns TH x 16 = 5 x 16 pooled outputs for 32 channels, computes the 11 x 33 conv outputs under them on
+// the MFMA from a 3 x 27 x 71 input patch in LDS (k = c*49 + kh*7 + kw, 147 padded to 148, same order and pairing as
 // the implicit-GEMM kernel -> bit-identical accumulators), keeps them in LDS after BN + ReLU and pools from there.
 // The stride-2 taps of 32 consecutive conv pixels would hit every second LDS word (2-way bank conflicts): the patch
 // rows are stored de-interleaved, [even columns | odd columns], so a lane's tap (kh, kw) sits at
 // parity(kw)*36 + px + kw/2 and consecutive pixels read consecutive words.
+// Round 6 (scripts/ubench/stem_bench.py, profiles/r06_stem7_variants.json; 64 images per level, TFLOP/s at 960x1280 .. 240x320):
+//   TH = 4 pooled rows (9 x 33 conv outputs = 10 MFMA sub-tiles on 4 waves: 3 + 3 + 2 + 2), BN vectors in registers   54-55 (round 5)
+//   TH = 4, BN vectors in LDS (32 registers less)                                                                      50-55
+//   TH = 5 (11 x 33 conv outputs = 12 sub-tiles: 3 per wave, 83 % instead of 67 % useful MFMA slots)                   56-62  <- default
+//   one workgroup walking both 32-channel groups over the staged patch (RFX_STEM7_CGLOOP=1: half the patch loads)      40-50: the
+//     two inlined group bodies keep 150 registers spilled around the barriers (rolled sub-tile loops); kept for experiments only
+#ifndef RFX_STEM7_CGLOOP
+#define RFX_STEM7_CGLOOP 0
+#endif
+#ifndef RFX_STEM7_TH
+#define RFX_STEM7_TH 5      // experiments: make exp NAME=stem4 SRC=stem DEFS=-DRFX_STEM7_TH=4
+#endif
 namespace r50 {
-constexpr int TH = 4, TW = 16;
+constexpr int TH = RFX_STEM7_TH, TW = 16;
 constexpr int CR = 2 * TH + 1, CC = 2 * TW + 1;    // 9 x 33 conv outputs
 constexpr int PR = 2 * CR + 5, PCW = 2 * CC + 5;   // 23 x 71 input patch
 constexpr int PHALF = 36, PST = 2 * PHALF + 2;     // de-interleaved row: 36 even + 36 odd columns (+2: the 9 lanes of the column
@@ -231,14 +243,17 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = lane >> 5, lcol = lane & 31;
     int bid = (int)bx;
-    const int cg = bid % a.chGroups; bid /= a.chGroups;
+    // RFX_STEM7_CGLOOP (default since round 6): ONE workgroup per pooled tile walks the Cout / 32 channel groups over the SAME staged
+    // input patch (the patch load + its barrier were paid once per channel group before: 2x for the 64-channel stem)
+    const int cg_first = RFX_STEM7_CGLOOP ? 0 : bid % a.chGroups;
+    const int cg_last = RFX_STEM7_CGLOOP ? a.chGroups : cg_first + 1;
+    if (!RFX_STEM7_CGLOOP) bid /= a.chGroups;
     const int tw = bid % a.tilesW; bid /= a.tilesW;
     const int th = bid % a.tilesH;
     const int n = bid / a.tilesH;
     const int oh0 = th * TH, ow0 = tw * TW;
     const int cy0 = 2 * oh0 - 1, cx0 = 2 * ow0 - 1;          // first conv row / column under the tile
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
-    const int m0 = cg * MCH;
     const size_t HW = (size_t)a.H * a.W;
 
     // ---- input patch: all loads first (20 per thread), masks at store time
@@ -262,15 +277,20 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         }
     }
     float af[KKS];
-#pragma unroll
-    for (int kk = 0; kk < KKS; ++kk) af[kk] = a.wT[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
-    float sc[16], sh[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = m0 + 4 * lrow + (r & 3) + 8 * (r >> 2);
-        sc[r] = a.scale ? a.scale[ch] : 1.0f;
-        sh[r] = a.shift ? a.shift[ch] : 0.0f;
+    // folded-BN vectors of every channel group in LDS (round 6: 32 registers less across the MFMA loop -- with the channel-group
+    // loop the kernel sat at the 256-register cap and spilled 112)
+    __shared__ float s_bn[2][128];
+    for (int c = t; c < a.Cout && c < 128; c += 256) {
+        s_bn[0][c] = a.scale ? a.scale[c] : 1.0f;
+        s_bn[1][c] = a.shift ? a.shift[c] : 0.0f;
     }
+    auto load_weights = [&](int m0) {
+        const float* wl = a.wT;
+        asm volatile("" : "+s"(wl) :: "memory");     // opaque per call: the loads of the NEXT channel group must not be hoisted into this one
+#pragma unroll
+        for (int kk = 0; kk < KKS; ++kk) af[kk] = wl[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
+    };
+    if (!RFX_STEM7_CGLOOP) load_weights(cg_first * MCH);          // in flight while the patch goes to LDS
     {
         int c = c_0, pr = pr_0, pc = pc_0;
 #pragma unroll
@@ -283,8 +303,18 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
     }
     __syncthreads();
 
-    // ---- conv on the MFMA, BN + ReLU -> LDS
+    // One channel group (32 channels) from the staged patch: MFMA phase -> C tile -> pooling -> global.  A generic lambda inlined
+    // once per group (two groups for the 64-channel stem) rather than a run-time loop: as a loop the three sub-tile passes stay
+    // rolled, the scheduler hoists their 74 operand reads on top of the 74 weight registers and the kernel spills ~100 registers.
+    auto channel_group = [&](const int cg, const bool first) {
+    const int m0 = cg * MCH;
     const float* pf = &P[0][0][0];
+    if (RFX_STEM7_CGLOOP) {
+        if (!first) __syncthreads();                           // everyone is done pooling from C
+        load_weights(m0);
+        asm volatile("" : "+v"(pf));                           // the patch is invariant across groups: keep its reads in THIS group
+    }
+    // ---- conv on the MFMA, BN + ReLU -> LDS
     for (int s = wave; s < NSUB; s += 4) {
         const bool pv = s < CR || lcol < CR;
         const int py = s < CR ? s : (lcol < CR ? lcol : 0), px = s < CR ? lcol : CC - 1;
@@ -302,7 +332,8 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         if (pv) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = fmaf(acc[r], sc[r], sh[r]);
+                const int chl = m0 + 4 * lrow + (r & 3) + 8 * (r >> 2);
+                float v = fmaf(acc[r], s_bn[0][chl], s_bn[1][chl]);
                 v = v > 0.0f ? v : 0.0f;
                 C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][(px & 1) * CHALF + (px >> 1)] = v;
             }
@@ -329,6 +360,14 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             }
         }
         a.out[(((size_t)n * a.Cout + m0 + ch) * a.Hp + oh) * a.Wp + ow] = m;
+    }
+    };   // channel_group
+    if (RFX_STEM7_CGLOOP && a.chGroups == 2) {
+        channel_group(0, true);
+        channel_group(1, false);
+    } else {
+#pragma unroll 1
+        for (int cg = cg_first; cg < cg_last; ++cg) channel_group(cg, cg == cg_first);
     }
 }
 
@@ -369,13 +408,14 @@ extern "C" int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, co
                                             float* out, int N, int H, int W, int Cout, void* stream) {
     if (!in || !wT || !out || N <= 0 || H < 1 || W < 1 || Cout <= 0) return RFX_E_ARG;
     if (Cout % r50::MCH != 0) return RFX_E_ARG;
+    if (Cout > 128) return RFX_E_LIMIT;                    // folded-BN vectors staged in LDS (s_bn)
     Stem7Args a;
     a.in = in; a.wT = wT; a.scale = scale; a.shift = shift; a.out = out;
     a.N = N; a.H = H; a.W = W; a.Cout = Cout; a.Mpad = (Cout + 127) / 128 * 128;
     a.Hc = (H + 6 - 7) / 2 + 1; a.Wc = (W + 6 - 7) / 2 + 1;
     a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
     a.tilesH = (a.Hp + r50::TH - 1) / r50::TH; a.tilesW = (a.Wp + r50::TW - 1) / r50::TW; a.chGroups = Cout / r50::MCH;
-    const long long nwg = (long long)N * a.tilesH * a.tilesW * a.chGroups;
+    const long long nwg = (long long)N * a.tilesH * a.tilesW * (RFX_STEM7_CGLOOP ? 1 : a.chGroups);
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
     if (rfx_group_recording()) return rfx_group_record(&stem7_group_launch, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL(stem7_conv_maxpool_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);

@@ -45,6 +45,8 @@ SIGNATURES = {
     "rfx_corr_neigh_f32": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "rfx_corr_neigh_variant_f32": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "rfx_corr_neigh_bidir_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "rfx_corr_timing": (c_int, [c_int]),
+    "rfx_corr_timing_collect": (c_int, [c_void_p, c_int]),
     "rfx_warp_grid_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "rfx_grid_sample_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     "rfx_compose_flow_f32": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),

@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only: every function takes ``torch
 live on a HIP device, passes ``data_ptr()`` / sizes / that device's current torch stream to the C entry point
 (``_call``: device-guarded) and returns freshly allocated output tensors.  No op has a CPU or eager-PyTorch fallback.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -58,15 +59,33 @@ class Profiler:
 
     def __init__(self):
         self.conv, self.corr, self.corr_bidir = [], [], []
+        self.corr_kernel_us = None      # kernel durations of the correlation launches in launch order (corr_durations())
+        self._corr_order = []           # "one" / "bidir" per captured launch
 
     def __enter__(self):
         self._prev = getattr(Profiler._tls, "active", None)
         Profiler._tls.active = self
+        # the correlation launches of this thread carry dispatch-level start / stop events from here on (rfx_corr_timing)
+        self._prev_timing = _lib.load().rfx_corr_timing(1)
+        _lib.load().rfx_corr_timing_collect(None, 0)          # drop captures nobody collected
         return self
 
     def __exit__(self, *exc):
         Profiler._tls.active = self._prev
+        _lib.load().rfx_corr_timing(self._prev_timing)
         return False
+
+    def corr_durations(self):
+        """Kernel durations (us) of the captured correlation launches: (one-direction list, bidir list), each in launch order.
+        Call after the profiled region (synchronises on the captured events)."""
+        if self.corr_kernel_us is None:
+            n = len(self._corr_order)
+            buf = (ctypes.c_float * max(n, 1))()
+            got = _lib.load().rfx_corr_timing_collect(buf, n)
+            us = [float(buf[i]) for i in range(n)] if got == n else []      # a launch that bypassed the DMA kernels: no pairing possible
+            self.corr_kernel_us = ([u for u, k in zip(us, self._corr_order) if k == "one"],
+                                   [u for u, k in zip(us, self._corr_order) if k == "bidir"])
+        return self.corr_kernel_us
 
     @staticmethod
     def active():
@@ -423,7 +442,8 @@ def resize_bilinear(x, size, align_corners=False):
     return out
 
 
-_LANCZOS_TABLES = {}
+_LANCZOS_TABLES = collections.OrderedDict()      # (sizes, device) -> coefficient tables, LRU-bounded: a stream of variable-size images
+_LANCZOS_MAX = 64                                # must not grow it for ever (a table set is a few KB)
 
 
 def lanczos_resize_u8(img, out_w, out_h):
@@ -439,6 +459,12 @@ def lanczos_resize_u8(img, out_w, out_h):
     if tabs is None:
         tabs = {k: torch.from_numpy(p[k]).to(img.device) for k in ("bounds_h", "kk_h", "bounds_v", "kk_v")}
         _LANCZOS_TABLES[key] = tabs
+        while len(_LANCZOS_TABLES) > _LANCZOS_MAX:
+            # the evicted tensors stay alive for as long as a kernel that reads them is queued (stream-ordered allocator); a captured
+            # HIP graph that baked their addresses in holds its own references (pipeline._features_graphed keeps `prep`)
+            _LANCZOS_TABLES.popitem(last=False)
+    else:
+        _LANCZOS_TABLES.move_to_end(key)
     lib = _lib.load()
     cur, curH = img, H
     if p["need_h"]:
@@ -496,6 +522,7 @@ def corr_neigh(x, y, K=7, variant=None):
     _call("rfx_corr_neigh_variant_f32", _one_device(x, y), _p(x), _p(y), _p(out), N, C, H, W, K, v)
     if e0 is not None:
         Profiler.active().corr.append(((2 * C + K * K) * 4.0 * N * H * W, e0, Profiler.end(e0)))  # algorithmic bytes
+        Profiler.active()._corr_order.append("one")
     return out
 
 
@@ -528,6 +555,7 @@ def corr_neigh_bidir(x, y, K=7, out=None):
     if e0 is not None:
         Profiler.active().corr_bidir.append(((2 * C + 2 * K * K) * 4.0 * N * H * W, 2 * (2 * C + K * K) * 4.0 * N * H * W, e0,
                                              Profiler.end(e0)))
+        Profiler.active()._corr_order.append("bidir")
     return out[:N], out[N:]
 
 
@@ -686,7 +714,8 @@ DEFAULT_SCORE_CHUNK = 256        # products per accumulation chunk of a mutual-N
 def resolve_score_chunk(spec=None):
     """The score chunk of ONE pipeline / drop-in module -> (products per chunk, where the value came from).  ``spec``:
       None      -> the environment variable RFX_SCORE_CHUNK if set (same grammar), else the fixed default of 256 products;
-      an int    -> that many products per chunk (a positive multiple of 32), or <= 0: ONE fma chain over all products (-1);
+      an int    -> that many products per chunk (a positive multiple of 32); 0 = the library default of 256 (what 0 means in
+                   rfx_api.h and ops.mutual_nn, one convention in every layer); < 0: ONE fma chain over all products (-1);
       "default" -> 256;
       "host"    -> the K blocking of THIS host's sgemm (host_sgemm_k_block: ~0.3-2 s of host arithmetic, cached per process), which
                    makes the device's scores equal the reference's torch.mm on this host bit for bit (the parity modes: drop-in
@@ -708,7 +737,9 @@ def resolve_score_chunk(spec=None):
             return DEFAULT_SCORE_CHUNK, "fallback (no K blocking reproduced this host's torch.mm: fixed 256 products)"
         spec = int(spec)
     spec = int(spec)
-    if spec <= 0:
+    if spec == 0:
+        return DEFAULT_SCORE_CHUNK, "%s = 0 (the library default: fixed 256 products)" % src
+    if spec < 0:
         return -1, "%s (one chain)" % src
     if spec % 32:
         raise ValueError("score_chunk must be a multiple of 32 products, got %d" % spec)
@@ -1009,14 +1040,17 @@ def filter_matches(idx1, idx2, count, active, mask, bg, rt, ct, xa, ya, xb, yb, 
     return (m1, m2, n, kept) if want_kept else (m1, m2, n)
 
 
-def keep_mask(mask, bg, active, rt, ct, n=None, hw=None):
+def keep_mask(mask, bg, active, rt, ct, n=None, hw=None, device=None):
     """The (a, rt*ct) 0/1 keep map of variant A / C's getCoarse for the active pairs (rfx_keep_mask_f32): what the per-call
-    mutual matching takes as its column mask.  ``mask`` (B,h,w) float32 or None (nothing explained yet; then ``n`` = number of
-    pairs and ``hw`` = (h, w) are required and a zero mask is used when a background map is given)."""
+    mutual matching takes as its column mask.  ``mask`` (B,h,w) float32 or None (nothing explained yet: a zero mask is used when
+    a background map ``bg`` is given; without ``bg`` either, ``n`` = number of pairs, ``hw`` = (h, w) and ``device`` are
+    required)."""
     bgd = _dev(bg, "bg") if bg is not None else None
     act = _dev(active, "active", torch.int32) if active is not None else None
     if mask is None:
-        dev_ = bgd.device if bgd is not None else hw[2]
+        if bgd is None and (n is None or hw is None or device is None):
+            raise ValueError("keep_mask without a mask and without a background map needs n, hw = (h, w) and device")
+        dev_ = bgd.device if bgd is not None else torch.device(device)
         h, w = (bgd.shape[1], bgd.shape[2]) if bgd is not None else (int(hw[0]), int(hw[1]))
         B = bgd.shape[0] if bgd is not None else int(n)
         m = torch.zeros((B, h, w), dtype=torch.float32, device=dev_) if bgd is not None else None

@@ -10,6 +10,7 @@ hypotheses.  Semantics per pair are the reference's (variant A: ResizeMaxSize, o
 Host-side work that stays on the CPU: PIL LANCZOS pyramid + ToTensor/Normalize.
 ``prepare()`` does it and uploads; everything after runs on the device.
 """
+import collections
 import os
 
 import numpy as np
@@ -45,18 +46,24 @@ def pil_to_tensor(pil):
     return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().float().div(255)
 
 
-_CELL_COORDS = {}
+_CELL_COORDS = collections.OrderedDict()
+_CELL_COORDS_MAX = 64
 
 
 def cell_coords_cached(n_rows, n_cols, device):
     """cell_coords() memoised per (shape, device): the grids are constants of the map size (a dozen tiny ATen launches per
-    pyramid level and step otherwise).  Entries are NEVER evicted: captured HIP graphs (_features_graphed,
-    prepare_and_features) bake these tensors' addresses into their kernels and replay against them; two float32 vectors of one
-    value per cell (38 KB for a 60x80 map) per distinct map shape is nothing against 288 GB."""
+    pyramid level and step otherwise).  LRU-bounded (64 shapes: a stream of variable-size pairs must not grow it for ever).
+    Captured HIP graphs (_features_graphed, prepare_and_features) bake these tensors' addresses into their kernels: the feature
+    dict a capture returns carries the tensors it read (``_coord_refs``), so an evicted entry stays alive for as long as a graph
+    that replays against it does."""
     key = (n_rows, n_cols, str(device))
     v = _CELL_COORDS.get(key)
     if v is None:
         v = _CELL_COORDS[key] = cell_coords(n_rows, n_cols, device)
+        while len(_CELL_COORDS) > _CELL_COORDS_MAX:
+            _CELL_COORDS.popitem(last=False)
+    else:
+        _CELL_COORDS.move_to_end(key)
     return v
 
 
@@ -448,7 +455,7 @@ class AlignPipeline:
         rt, ct = ft.shape[2], ft.shape[3]
         Wt, Ht = cell_coords_cached(rt, ct, self.dev)
         return dict(featA=featA, featB=ft.view(B, 1024, rt * ct), nA=nA, ldA=ldA, nB=rt * ct, WA=torch.cat(Ws), HA=torch.cat(Hs),
-                    Wt=Wt, Ht=Ht, rt=rt, ct=ct)
+                    Wt=Wt, Ht=Ht, rt=rt, ct=ct, _coord_refs=(Ws, Hs))
 
     def coarse(self, prep, feats=None, samples=None, maskB=None, sample_fn=None, pair_ids=None, draw_epoch=0):
         """Per pair: mutual NN -> matches -> RANSAC.  Index draw (utils/outil.py:120): ``samples`` = list of (nbIter,4) int64

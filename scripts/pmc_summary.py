@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel, per-launch summary of rocprofv3 --pmc passes (evidence helper; scripts/gpu.sh step `pmc`).
 
-    python scripts/pmc_summary.py --dirs gpurun_out/r04/pmc_3_* --cmd "python bench.py --config 3 ..." --out profiles/r04_pmc_summary_config3.json
+    python scripts/pmc_summary.py --dirs gpurun_out/rNN/pmc_3_* --cmd "python bench.py --config 3 ..." --out profiles/rNN_pmc_summary_config3.json
 
 Every directory holds ONE pass (--pmc <group> --kernel-trace: counters are collected in their own runs, as gpurun requires).
 FETCH_SIZE / WRITE_SIZE arrive in KB; bytes = x 1024.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports

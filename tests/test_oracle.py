@@ -617,7 +617,7 @@ def test_host_sgemm_probe_and_score_chunk_resolution():
         assert ops.resolve_score_chunk(None) == (256, "default (fixed 256 products)")          # the FALLBACK is pinned: 256
         assert ops.resolve_score_chunk("default")[0] == 256
         assert ops.resolve_score_chunk(192) == (192, "argument") and ops.resolve_score_chunk("384")[0] == 384
-        assert ops.resolve_score_chunk(0)[0] == -1 and ops.resolve_score_chunk(-5)[0] == -1    # one chain
+        assert ops.resolve_score_chunk(0)[0] == 256 and ops.resolve_score_chunk(-5)[0] == -1    # 0 = the library default in EVERY layer (rfx_api.h, ops.mutual_nn); < 0 = one chain
         with pytest.raises(ValueError):
             ops.resolve_score_chunk(100)
         v, src = ops.resolve_score_chunk("host")
