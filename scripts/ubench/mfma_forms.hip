@@ -5,6 +5,8 @@
 //   B  both pipes: per CU, WM waves run the 32x32x2 loop and WV waves run a v_fmac_f32 loop (independent chains)
 //        -> matrix TFLOP/s, vector TFLOP/s and their sum, against each alone
 //   C  both pipes inside ONE wave: per loop trip 1 MFMA 32x32x2 + NV independent v_fmac_f32 (NV = 0, 8, 16, 24, 32)
+//   D  the clock the chip sustains under each loop: s_memtime ticks of one wave / wall time of the launch (the 157.3 TFLOP/s peak
+//        assumes 2.4 GHz; a sustained fp32 MFMA stream runs below that, MI355X_MICROARCH.md "DVFS give-back")
 // hipcc --offload-arch=gfx950 -O3 mfma_forms.hip -o mfma_forms.bin && ./mfma_forms.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -15,7 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr double GHZ = 2.4;
 
 template <int F>
-__global__ __launch_bounds__(256) void form_kernel(float* out, int iters) {
+__global__ __launch_bounds__(512) void form_kernel(float* out, int iters) {
     const float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)(threadIdx.x & 7);
     float s = 0.f;
     if constexpr (F == 0) {          // 32x32x2: 4096 FLOP
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(1024) void mix_kernel(float* out, int iters, int wm
 
 // C: one wave issues both: 1 MFMA + NV fmacs per trip (independent chains)
 template <int NV>
-__global__ __launch_bounds__(256) void both_kernel(float* out, int iters) {
+__global__ __launch_bounds__(512) void both_kernel(float* out, int iters) {
     const float a = (float)threadIdx.x * 1e-3f, b = 2.0f;
     f32x16 acc[4] = {};
     float v[32];
@@ -116,6 +118,32 @@ static int g_blocks, g_threads, g_wm, g_nv;
 template <int F> static void launch_form(float* o, int it) { hipLaunchKernelGGL(form_kernel<F>, dim3(g_blocks), dim3(g_threads), 0, 0, o, it); }
 static void launch_mix(float* o, int it) { hipLaunchKernelGGL(mix_kernel, dim3(g_blocks), dim3(g_threads), 0, 0, o, it, g_wm, g_nv); }
 template <int NV> static void launch_both(float* o, int it) { hipLaunchKernelGGL(both_kernel<NV>, dim3(g_blocks), dim3(g_threads), 0, 0, o, it); }
+
+// D: the MFMA-only / VALU-only loop with the shader clock read around it by lane 0 of every wave (max over waves taken on the host)
+template <int MODE>
+__global__ __launch_bounds__(256) void clock_kernel(float* out, unsigned long long* ticks, int iters) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    if constexpr (MODE == 0) {
+        const float a = (float)threadIdx.x * 1e-3f, b = 2.0f;
+        f32x16 acc[4] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) for (int r = 0; r < 16; ++r) s += acc[u][r];
+    } else {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (float)(threadIdx.x + q);
+        for (int it = 0; it < iters * 8; ++it)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = __builtin_fmaf(v[q], 1.0000001f, 1e-7f);
+        for (int q = 0; q < 16; ++q) s += v[q];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
 
 int main() {
     float* out; hipMalloc(&out, (size_t)4096 * 1024 * 4);
@@ -155,6 +183,29 @@ int main() {
             printf("C NV=%2d waves/SIMD=%d  %.3f ms  %.1f cyc/trip/SIMD  matrix %.1f TF + vector %.1f TF = %.1f TF\n", nv[f], wps, ms, cyc,
                    trips * 4096 / ms / 1e9, trips * nv[f] * 128 / ms / 1e9, trips * (4096 + nv[f] * 128) / ms / 1e9);
         }
+    }
+    printf("# D: sustained clock (s_memtime ticks of the slowest wave / wall time), 256 workgroups x 4 waves, long launches\n");
+    {
+        unsigned long long* ticks; hipMalloc(&ticks, 1024 * 8);
+        unsigned long long host[1024];
+        for (int mode = 0; mode < 2; ++mode) {
+            const int it = 400000;                       // ~0.5 s: long enough for the power management to settle
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(clock_kernel<0>, dim3(256), dim3(256), 0, 0, out, ticks, it);
+                else hipLaunchKernelGGL(clock_kernel<1>, dim3(256), dim3(256), 0, 0, out, ticks, it);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(host, ticks, 1024 * 8, hipMemcpyDeviceToHost);
+            unsigned long long mx = 0;
+            for (int i = 0; i < 1024; ++i) mx = host[i] > mx ? host[i] : mx;
+            const double flop = mode == 0 ? (double)it * 4 * 4096 * 4 * 256 : (double)it * 8 * 16 * 128 * 4 * 256;
+            printf("D %-12s %.1f ms  %.1f TFLOP/s  s_memtime ticks %llu -> %.3f GHz if one tick is one shader cycle (%.1f ticks per MFMA / per 16 fmac)\n",
+                   mode == 0 ? "MFMA 32x32x2" : "v_fmac_f32", ms, flop / ms / 1e9, mx, mx / (ms * 1e6), (double)mx / ((double)it * (mode == 0 ? 4 : 8)));
+        }
+        hipFree(ticks);
     }
     hipFree(out);
     return 0;
