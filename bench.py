@@ -244,6 +244,11 @@ def parse_args():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal WITHOUT a GPU: the real rank code (self-spawn, process group, barriers, all_gather, "
                          "max-over-ranks timing, JSON) around a CPU stand-in step that fabricates records; value is meaningless")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling runs (rocprofv3 --kernel-trace / --pmc): ONE lock-step group and ONE trunk stream, one timed pass under "
+                         "the per-launch events -- no kernel overlaps another, so rocprofv3's per-kernel durations are the ones the "
+                         "rooflines are computed from (the product path overlaps kernels of different streams, which stretches every "
+                         "overlapped kernel's begin-to-end time)")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0: torch.save the last step's gathered record block + the absolute pair id of every row (N-rank vs 1-rank "
                          "equality checks: a pair's record does not depend on the sharding)")
@@ -255,6 +260,9 @@ def parse_args():
     args.height = args.height or dflt[0]
     args.width = args.width or dflt[1]
     args.batch = args.batch or dflt[2]
+    if args.single_stream:
+        args.split = 1
+        os.environ["RFX_TRUNK_STREAMS"] = "1"
     return args
 
 
@@ -672,7 +680,7 @@ def main():
         torch.manual_seed(123 + rank)
     log("workload built (config %s, rank %d/%d)" % (args.config, rank, world))
     unprofiled = None
-    if not args.dry_run and args.config in ("2", "3", "4"):
+    if not args.dry_run and args.config in ("2", "3", "4") and not (args.single_stream and args.config != "2"):
         # config 2: single-pair latency is launch-bound: the product path replays the trunk as ONE HIP graph, which cannot carry the
         # profiler's per-launch events.  configs 3 / 4: the multi-homography rounds run as two lock-step groups on two HIP streams
         # (multi_h_batched split=2) whose kernels overlap -- a per-launch event interval would charge a kernel with its neighbour's
@@ -714,6 +722,8 @@ def main():
                            collective=("all_gather_into_tensor over %s, %d rank(s)" % (backend, world)) if dist is not None else "none (single process)",
                            score_chunk_products=score_chunk, score_chunk_source=score_chunk_source,
                            ransac_draw="host (torch.randint, CPU generator)" if args.host_draw else "device (Philox4x32-10)",
+                           streams=("single stream, one lock-step group (--single-stream: profiling run)" if args.single_stream else
+                                    "product path: trunk levels on 4 HIP streams, multi-homography rounds as lock-step groups on streams"),
                            rank_deficient_samples=("host LAPACK (exact mode: librfxhost.so runs numpy's own dgesdd on the flagged samples)"
                                                    if (args.degenerate == "lapack" or (args.degenerate == "auto" and args.host_draw))
                                                    else "device null vector"),

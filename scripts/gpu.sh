@@ -19,8 +19,8 @@ for step in "$@"; do
     c2)         timeout 300 python bench.py --config 2 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_c2.log 2> $OUT/bench_c2.err; python scripts/bench_digest.py $OUT/bench_c2.log ;;
     c4)         timeout 600 python bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c4.log 2> $OUT/bench_c4.err; python scripts/bench_digest.py $OUT/bench_c4.log ;;
     c5)         timeout 600 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c5.log 2> $OUT/bench_c5.err; python scripts/bench_digest.py $OUT/bench_c5.log ;;
-    profile)    for c in ${CONFIGS:-3}; do rm -rf $OUT/prof_$c; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$c -o k -- python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-exact-leg --no-qs-leg > $OUT/prof_$c.log 2>&1; f=$(find $OUT/prof_$c -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/rocprofv3_kernel_stats_config$c.csv; head -12 "$f" | cut -c1-150; find $OUT/prof_$c -name "*.csv" ! -name "*stats*" -delete; done ;;
-    pmc)        for c in ${CONFIGS:-3}; do for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do n=$(echo $grp | tr ' ' '_' | cut -c1-24); rm -rf $OUT/pmc_${c}_$n; timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_${c}_$n -o p -- python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-qs-leg --no-exact-leg > $OUT/pmc_${c}_$n.log 2>&1; tail -1 $OUT/pmc_${c}_$n.log | cut -c1-160; done; python scripts/pmc_summary.py --dirs $OUT/pmc_${c}_* --cmd "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --config $c --steps 1 --warmup 1 --no-cpu-baseline --no-qs-leg --no-exact-leg" --out $OUT/pmc_summary_config$c.json 2>&1 | tail -12; find $OUT -path "*pmc_${c}_*" -name "*.csv" -delete; done ;;
+    profile)    for c in ${CONFIGS:-3}; do rm -rf $OUT/prof_$c; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$c -o k -- python bench.py --config $c --steps 5 --warmup 2 --single-stream --no-cpu-baseline --no-exact-leg --no-qs-leg > $OUT/prof_$c.log 2>&1; f=$(find $OUT/prof_$c -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/rocprofv3_kernel_stats_config$c.csv; head -12 "$f" | cut -c1-150; find $OUT/prof_$c -name "*.csv" ! -name "*stats*" -delete; done ;;
+    pmc)        for c in ${CONFIGS:-3}; do for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do n=$(echo $grp | tr ' ' '_' | cut -c1-24); rm -rf $OUT/pmc_${c}_$n; timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_${c}_$n -o p -- python bench.py --config $c --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-qs-leg --no-exact-leg > $OUT/pmc_${c}_$n.log 2>&1; tail -1 $OUT/pmc_${c}_$n.log | cut -c1-160; done; python scripts/pmc_summary.py --dirs $OUT/pmc_${c}_* --cmd "rocprofv3 --pmc <group> --kernel-trace -- python bench.py --config $c --steps 1 --warmup 1 --single-stream --no-cpu-baseline --no-qs-leg --no-exact-leg" --out $OUT/pmc_summary_config$c.json 2>&1 | tail -12; find $OUT -path "*pmc_${c}_*" -name "*.csv" -delete; done ;;
     ubench_mnn) timeout 600 python scripts/ubench/mnn_bench.py --out $OUT/mnn_forms.json 2>&1 | tail -5 ;;
     sweeps)     # full 64-pair first-homography sweeps (device vs reference) + the reference against itself on the same box
                 for c in ${SWEEP_CFGS:-qs ev}; do timeout 1200 python tests/run_parity_sweep.py $c 64 2>&1 | tail -1 | cut -c1-900; cp gpurun_out/parity_sweep_${c}_64.json $OUT/parity_sweep_${c}_64pairs.json

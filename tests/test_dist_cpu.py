@@ -161,17 +161,17 @@ def test_committed_profiles_carry_the_kernel_names_bench_prints():
     """The driver's line names its dominant kernel with bench.kernel_name(kernel id) and reads that kernel's HBM traffic from the
     committed PMC summary (bench.pmc_traffic): both are only worth something while the committed rocprofv3 / PMC evidence was
     taken with the SAME kernel instances (round 3's qs summary predated a template-argument change and went stale).  Every
-    instance with a share of the config-3 step must be found, by the name bench prints, in profiles/r05_rocprofv3_kernel_stats_
-    config3.csv and in profiles/r05_pmc_summary_config3.json; the kernel ids come from the committed bench line itself."""
+    instance with a share of the config-3 step must be found, by the name bench prints, in profiles/r06_rocprofv3_kernel_stats_
+    config3.csv and in profiles/r06_pmc_summary_config3.json; the kernel ids come from the committed bench line itself."""
     import csv
     import json
     sys.path.insert(0, ROOT)
     import bench
-    line = [l for l in open(os.path.join(ROOT, "profiles", "r05_bench_default.log")) if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(ROOT, "profiles", "r06_bench_default.log")) if l.startswith("{")][-1]
     roof = json.loads(line)["roofline"]
-    rows = [ln for ln in open(os.path.join(ROOT, "profiles", "r05_rocprofv3_kernel_stats_config3.csv")) if not ln.startswith("#")]   # "# command" line
+    rows = [ln for ln in open(os.path.join(ROOT, "profiles", "r06_rocprofv3_kernel_stats_config3.csv")) if not ln.startswith("#")]   # "# command" line
     stats = [r["Name"].replace(" ", "") for r in csv.DictReader(rows)]
-    pmc = [k.replace(" ", "") for k in json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_summary_config3.json")))["kernels"]]
+    pmc = [k.replace(" ", "") for k in json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_summary_config3.json")))["kernels"]]
     checked = 0
     for kid, o in roof["conv_kernels"].items():
         if o["time_share"] < 0.02:
@@ -183,4 +183,4 @@ def test_committed_profiles_carry_the_kernel_names_bench_prints():
     assert checked >= 8
     assert roof["kernel"].replace(" ", "") == bench.kernel_name(16416).replace(" ", "")     # the chunked 128-channel direct 3x3 instance
     t, src = bench.pmc_traffic(roof["kernel"], "3")
-    assert abs(t - roof["traffic"]) < 0.02 * t and src.endswith("r05_pmc_summary_config3.json")    # (the summary was re-taken once more after the line)
+    assert abs(t - roof["traffic"]) < 0.02 * t and src.endswith("r06_pmc_summary_config3.json")    # (the summary was re-taken once more after the line)

@@ -103,6 +103,22 @@ def test_signatures_match_reference(dropin):
     for meth in ("setSource", "setTarget", "getCoarse", "skyFromSeg"):
         assert hasattr(ca.CoarseAlignA, meth)
     assert hasattr(ca.CoarseAlignB, "setPair")
+    # segNet/segEval.py: SegNet(encoderPth, decoderPth, segId=1, segFg=True) / getSky(imgPath) -- same leading parameters,
+    # same defaults (the drop-in adds device= at the end); a CoarseAlign built with segNet=False has no sky mask, like the reference's
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_rfx_dropin_segEval_probe", os.path.join(DROPIN, "segEval.py"))
+    se = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, DROPIN)
+    try:
+        spec.loader.exec_module(se)
+    finally:
+        sys.path.remove(DROPIN)
+    rs = ref_loader.load_seg()["segEval"].SegNet
+    ref_params = inspect.signature(rs.__init__).parameters
+    our_params = inspect.signature(se.SegNet.__init__).parameters
+    assert list(our_params)[:len(ref_params)] == list(ref_params)
+    assert all(our_params[k].default == ref_params[k].default for k in ref_params)
+    assert str(inspect.signature(se.SegNet.getSky)) == str(inspect.signature(rs.getSky))
 
 
 @pytest.mark.reference
