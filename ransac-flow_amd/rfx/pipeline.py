@@ -216,6 +216,15 @@ class AlignPipeline:
         nw, nh = resize_dims(tw, th, self.minSize, mode)
         return ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, nw, nh), IMAGENET_MEAN, IMAGENET_STD)
 
+    def _trunk(self, x):
+        """self.trunk(x), optionally in sub-batches of RFX_TRUNK_CHUNK images (experiment knob, round 6: does a working set that fits
+        the 256 MB Infinity Cache make the layer-to-layer re-reads cheaper than the smaller launches cost?).  Every sample is
+        computed independently: bit-identical."""
+        ch = int(os.environ.get("RFX_TRUNK_CHUNK", "0"))
+        if ch <= 0 or x.shape[0] <= ch:
+            return self.trunk(x)
+        return torch.cat([self.trunk(x[i:i + ch]) for i in range(0, x.shape[0], ch)], dim=0)
+
     # ---------------------------------------------------------------- coarse stage
     def features(self, prep):
         """ResNet-50 conv4 features of every pyramid level and of the target, L2-normalised, written into
@@ -438,10 +447,10 @@ class AlignPipeline:
                 if ft_raw is None and x.shape == tgt.shape:
                     # the pyramid level of scale 1 has the target's size: one trunk pass over both (twice the batch, one
                     # launch tail less per layer); every sample is computed independently, bit-identical to two passes
-                    f2 = self.trunk(torch.cat((x, tgt), dim=0))
+                    f2 = self._trunk(torch.cat((x, tgt), dim=0))
                     f, ft_raw = f2[:B], f2[B:]
                 else:
-                    f = self.trunk(x)
+                    f = self._trunk(x)
                 ops.l2norm(f, out=featA[:, :, offs[i]:], out_batch_stride=1024 * ldA, out_chan_stride=ldA)
                 if nstream > 1:
                     ev = torch.cuda.Event()

@@ -361,6 +361,36 @@ def test_corr_neigh_tile_variants_are_bit_identical(dev, shape):
         ops.corr_neigh(x, y, variant=77)
 
 
+def test_corr_kernel_durations_from_dispatch_level_events(dev):
+    """rfx_corr_timing / ops.Profiler.corr_durations (bench.py's roofline_corr since round 6): inside a Profiler every correlation
+    launch carries a start / stop event attached to the DISPATCH (hipExtLaunchKernelGGL) -- the kernel's own duration, as
+    rocprofv3 --kernel-trace reports it -- next to the event pair recorded AROUND the launch, whose interval also brackets the command
+    processor's work.  Checked: one duration per launch and kind, in order; positive; never longer than the interval around the same
+    launch; same results with and without the capture; nothing captured outside a Profiler."""
+    from rfx import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    x = F.normalize(torch.randn(16, 256, 60, 80, generator=g), dim=1).to(dev)
+    y = F.normalize(torch.randn(16, 256, 60, 80, generator=g), dim=1).to(dev)
+    plain = ops.corr_neigh(x, y)
+    assert lib.rfx_corr_timing_collect(None, 0) == 0                 # no capture outside a Profiler
+    with ops.Profiler() as prof:
+        a = ops.corr_neigh(x, y)
+        b12, b21 = ops.corr_neigh_bidir(x, y)
+        c = ops.corr_neigh(x[:4], y[:4])
+    torch.cuda.synchronize()
+    one, bid = prof.corr_durations()
+    assert len(one) == 2 and len(bid) == 1 and len(prof.corr) == 2 and len(prof.corr_bidir) == 1
+    assert torch.equal(a, plain) and torch.equal(b12, plain) and torch.equal(c, plain[:4])
+    iv_one = [e0.elapsed_time(e1) * 1e3 for _, e0, e1 in prof.corr]
+    iv_bid = [e0.elapsed_time(e1) * 1e3 for _, _, e0, e1 in prof.corr_bidir]
+    for k, iv in zip(one + bid, iv_one + iv_bid):
+        assert 5.0 < k <= iv + 1.0, (k, iv)                            # microseconds; the interval brackets the kernel
+    assert one[1] < one[0]                                            # 4 pairs vs 16
+    assert prof.corr_durations() == (one, bid)                        # collected once, cached
+    assert lib.rfx_corr_timing(0) == 0 and lib.rfx_corr_timing_collect(None, 0) == 0     # switched off again on exit
+
+
 def test_corr_neigh_golden(dev):
     g = gold("nets.npz")
     out = ops.corr_neigh(torch.from_numpy(g["fine_fa"]).to(dev), torch.from_numpy(g["fine_fb"]).to(dev)).cpu()
