@@ -227,11 +227,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline + parity sweep)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-pairs", type=int, default=None, help="pairs of the batch covered by the parity sweep (default: all)")
-    ap.add_argument("--parity-budget", type=float, default=110.0, help="wall-clock bound of the headline's parity sweep, seconds")
-    ap.add_argument("--timed-parity-budget", type=float, default=100.0,
+    ap.add_argument("--parity-budget", type=float, default=95.0, help="wall-clock bound of the headline's parity sweep, seconds")
+    ap.add_argument("--timed-parity-budget", type=float, default=85.0,
                     help="wall-clock bound of the sweep over the TIMED mode (device draws replayed on the reference), seconds")
-    ap.add_argument("--qs-parity-budget", type=float, default=60.0, help="wall-clock bound of the quick_start leg's parity sweep")
-    ap.add_argument("--stability-budget", type=float, default=70.0, help="wall-clock bound of the reference-vs-reference sweep")
+    ap.add_argument("--qs-parity-budget", type=float, default=50.0, help="wall-clock bound of the quick_start leg's parity sweep")
+    ap.add_argument("--stability-budget", type=float, default=55.0, help="wall-clock bound of the reference-vs-reference sweep")
     ap.add_argument("--no-qs-leg", "--no-config3-leg", dest="no_qs_leg", action="store_true",
                     help="default run: skip the quick_start leg (extra.quick_start)")
     ap.add_argument("--host-prep", action="store_true",

@@ -203,6 +203,11 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 #ifndef RFX_STEM7_CGLOOP
 #define RFX_STEM7_CGLOOP 0
 #endif
+// experiments only (scripts/ubench/stem_bench.py; WRONG RESULTS): RFX_STEM7_DBG removes one phase to price it
+//   1 no pooling / output stores   2 no patch loads from global memory   3 no MFMA phase   4 no weight (A fragment) loads
+#ifndef RFX_STEM7_DBG
+#define RFX_STEM7_DBG 0
+#endif
 #ifndef RFX_STEM7_TH
 #define RFX_STEM7_TH 5      // experiments: make exp NAME=stem4 SRC=stem DEFS=-DRFX_STEM7_TH=4
 #endif
@@ -270,7 +275,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             const int gy = iy0 + pr, gx = ix0 + pc;
             const bool ok = c < 3 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
             pok |= ok ? (1u << u) : 0u;
-            pv_[u] = inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
+            pv_[u] = RFX_STEM7_DBG == 2 ? (float)u : inn[ok ? (size_t)c * HW + (size_t)gy * a.W + gx : 0];
             pc += 256 % PCW; pr += 256 / PCW;
             if (pc >= PCW) { pc -= PCW; ++pr; }
             if (pr >= PR) { pr -= PR; ++c; }
@@ -288,7 +293,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         const float* wl = a.wT;
         asm volatile("" : "+s"(wl) :: "memory");     // opaque per call: the loads of the NEXT channel group must not be hoisted into this one
 #pragma unroll
-        for (int kk = 0; kk < KKS; ++kk) af[kk] = wl[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
+        for (int kk = 0; kk < KKS; ++kk) af[kk] = RFX_STEM7_DBG == 4 ? (float)(kk + lcol) : wl[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
     };
     if (!RFX_STEM7_CGLOOP) load_weights(cg_first * MCH);          // in flight while the patch goes to LDS
     {
@@ -315,7 +320,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         asm volatile("" : "+v"(pf));                           // the patch is invariant across groups: keep its reads in THIS group
     }
     // ---- conv on the MFMA, BN + ReLU -> LDS
-    for (int s = wave; s < NSUB; s += 4) {
+    for (int s = wave; s < NSUB && RFX_STEM7_DBG != 3; s += 4) {
         const bool pv = s < CR || lcol < CR;
         const int py = s < CR ? s : (lcol < CR ? lcol : 0), px = s < CR ? lcol : CC - 1;
         const int pbase = 2 * py * PST + px;
@@ -343,7 +348,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
 
     // ---- MaxPool2d(3, stride 2, pad 1): -inf padding = positions outside the conv map are skipped; the values are ReLU
     // outputs, so the unsigned-integer max is the NaN-propagating float max and 0 its identity (see umaxf above)
-    for (int o = t; o < MCH * TH * TW; o += 256) {
+    for (int o = t; o < MCH * TH * TW && RFX_STEM7_DBG != 1; o += 256) {
         const int owl = o % TW, ohl = (o / TW) % TH, ch = o / (TW * TH);
         const int oh = oh0 + ohl, ow = ow0 + owl;
         if (oh >= a.Hp || ow >= a.Wp) continue;
