@@ -208,6 +208,15 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 #ifndef RFX_STEM7_DBG
 #define RFX_STEM7_DBG 0
 #endif
+// RFX_STEM7_ROWSTAGE=1 (experiment, round 6): patch staging by wave-uniform rows -- 690 fewer vector-ALU instructions per wave (444
+// instead of 1135 before the first barrier), bit-identical, and NO change in the kernel's time (62.1 vs 62.1 TFLOP/s): the staging
+// phase's VALU work does not hold the other workgroup's MFMA phase back.  Off: the element-wise form stays the product path.
+#ifndef RFX_STEM7_ROWSTAGE
+#define RFX_STEM7_ROWSTAGE 0
+#endif
+#ifndef RFX_STEM7_UNROLL
+#define RFX_STEM7_UNROLL 0
+#endif
 #ifndef RFX_STEM7_TH
 #define RFX_STEM7_TH 5      // experiments: make exp NAME=stem4 SRC=stem DEFS=-DRFX_STEM7_TH=4
 #endif
@@ -220,7 +229,10 @@ constexpr int PHALF = 36, PST = 2 * PHALF + 2;     // de-interleaved row: 36 eve
 // conv-output tile in LDS, rows de-interleaved by column parity as well ([17 even | 17 odd at +17], row stride 40): the
 // pooling pass reads columns 2*ow + j of 16 consecutive pooled outputs as CONSECUTIVE words, and the four pooled rows of a
 // wavefront lie 2*CST = 80 words = 16 banks apart -> every bank is hit exactly twice by the 64 lanes (the minimum).
-constexpr int CHALF = 17, CST = 40;
+#ifndef RFX_STEM7_CST
+#define RFX_STEM7_CST 40
+#endif
+constexpr int CHALF = 17, CST = RFX_STEM7_CST;
 // MFMA sub-tiles are ROW-ALIGNED (round 4): sub-tile s < 9 = conv row s, columns 0..31 (32 consecutive LDS words per tap: no
 // bank conflict); sub-tile 9 = column 32 of the nine rows (9 live lanes).  The old numbering p = s*32 + lcol over the 9 x 33
 // map made most sub-tiles straddle two rows that land 2*PST = 16 banks apart on overlapping banks: 2-way conflicts on the B
@@ -261,8 +273,32 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
     const size_t HW = (size_t)a.H * a.W;
 
-    // ---- input patch: all loads first (20 per thread), masks at store time
+    // ---- input patch -> registers.  RFX_STEM7_ROWSTAGE (round 6): by ROWS -- wave w takes patch rows w, w+4, .. (3 x PR rows of PCW <= 71
+    // columns: lane = column, lanes 0..PCW-65 a second one), so that the row's base address, its validity and its LDS row are
+    // wave-uniform (scalar ALU) and a load costs ONE vector instruction besides itself (the border select).  The element-wise form
+    // (element t + 256u of the patch) spent ~20 vector-ALU instructions per element on index arithmetic, bounds and 64-bit addresses;
+    // every fp32 VALU instruction takes ~4 cycles out of the matrix pipe's time (profiles/r06_mfma_forms_and_pipe_concurrency.txt, C).
     const float* inn = a.in + (size_t)n * 3 * HW;
+#if RFX_STEM7_ROWSTAGE
+    constexpr int NROW = (3 * PR + 3) / 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int gx0 = ix0 + lane, gx1 = ix0 + lane + 64;
+    const bool cok0 = (unsigned)gx0 < (unsigned)a.W;
+    const bool has1 = lane + 64 < PCW;
+    const bool cok1 = has1 && (unsigned)gx1 < (unsigned)a.W;
+    const int gxc0 = cok0 ? gx0 : 0, gxc1 = cok1 ? gx1 : 0;
+    const int lc0 = (lane & 1) * PHALF + (lane >> 1), lc1 = (lane & 1) * PHALF + ((lane + 64) >> 1);
+    float pv0[NROW], pv1[NROW];
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) {
+        const int row = wave_u + 4 * j;                       // = c * PR + pr, wave-uniform
+        const int c = row / PR, pr = row - c * PR, gy = iy0 + pr;
+        const bool rok = row < 3 * PR && (unsigned)gy < (unsigned)a.H;
+        const float* rp = inn + (size_t)(row < 3 * PR ? c : 0) * HW + (size_t)(rok ? gy : 0) * a.W;
+        pv0[j] = RFX_STEM7_DBG == 2 ? (float)j : rp[gxc0];
+        pv1[j] = RFX_STEM7_DBG == 2 ? (float)j : rp[gxc1];
+    }
+#else
     constexpr int NP = (3 * PR * PCW + 255) / 256;
     float pv_[NP];
     unsigned pok = 0;
@@ -281,6 +317,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             if (pr >= PR) { pr -= PR; ++c; }
         }
     }
+#endif
     float af[KKS];
     // folded-BN vectors of every channel group in LDS (round 6: 32 registers less across the MFMA loop -- with the channel-group
     // loop the kernel sat at the 256-register cap and spilled 112)
@@ -296,6 +333,29 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         for (int kk = 0; kk < KKS; ++kk) af[kk] = RFX_STEM7_DBG == 4 ? (float)(kk + lcol) : wl[(size_t)(2 * kk + lrow) * a.Mpad + m0 + lcol];
     };
     if (!RFX_STEM7_CGLOOP) load_weights(cg_first * MCH);          // in flight while the patch goes to LDS
+#if RFX_STEM7_ROWSTAGE
+    {
+        float* pflat = &P[0][0][0];
+#pragma unroll
+        for (int j = 0; j < NROW; ++j) {
+            const int row = wave_u + 4 * j;
+            if (row < 3 * PR) {                                // wave-uniform
+                const bool rok = (unsigned)(iy0 + row - (row / PR) * PR) < (unsigned)a.H;
+                pflat[row * PST + lc0] = (rok && cok0) ? pv0[j] : 0.0f;
+            }
+        }
+        if (has1) {                                            // ONE exec-mask region for the few lanes that own a second column
+#pragma unroll
+            for (int j = 0; j < NROW; ++j) {
+                const int row = wave_u + 4 * j;
+                if (row < 3 * PR) {
+                    const bool rok = (unsigned)(iy0 + row - (row / PR) * PR) < (unsigned)a.H;
+                    pflat[row * PST + lc1] = (rok && cok1) ? pv1[j] : 0.0f;
+                }
+            }
+        }
+    }
+#else
     {
         int c = c_0, pr = pr_0, pc = pc_0;
 #pragma unroll
@@ -306,6 +366,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             if (pr >= PR) { pr -= PR; ++c; }
         }
     }
+#endif
     __syncthreads();
 
     // One channel group (32 channels) from the staged patch: MFMA phase -> C tile -> pooling -> global.  A generic lambda inlined
@@ -320,6 +381,9 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         asm volatile("" : "+v"(pf));                           // the patch is invariant across groups: keep its reads in THIS group
     }
     // ---- conv on the MFMA, BN + ReLU -> LDS
+#if RFX_STEM7_UNROLL
+#pragma unroll
+#endif
     for (int s = wave; s < NSUB && RFX_STEM7_DBG != 3; s += 4) {
         const bool pv = s < CR || lcol < CR;
         const int py = s < CR ? s : (lcol < CR ? lcol : 0), px = s < CR ? lcol : CC - 1;
@@ -330,7 +394,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
 #pragma unroll
         for (int kk = 0; kk < KKS; ++kk) {
             const int off = lrow ? koff(2 * kk + 1) : koff(2 * kk);
-            float b = pf[pbase + off];
+            float b = RFX_STEM7_DBG == 5 ? af[(kk + 1) % KKS] : pf[pbase + off];      // 5: no LDS operand reads
             if (kk == KKS - 1) b = lrow ? 0.0f : b;   // k = 147: padded tap
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], b, acc, 0, 0, 0);
         }

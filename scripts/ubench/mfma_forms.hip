@@ -54,6 +54,20 @@ __global__ __launch_bounds__(512) void form_kernel(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// A1: ONE accumulator per wave (every MFMA depends on the one before: the stem kernels' sub-tile loop), 32x32x2
+__global__ __launch_bounds__(512) void chain_kernel(float* out, int iters) {
+    const float a = (float)threadIdx.x * 1e-3f, b = 2.0f;
+    f32x16 acc = {};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+static void launch_chain(float* o, int it) { extern int g_blocks_, g_threads_; hipLaunchKernelGGL(chain_kernel, dim3(g_blocks_), dim3(g_threads_), 0, 0, o, it); }
+int g_blocks_ = 256, g_threads_ = 256;
+
 // B: waves [0, WM) of a workgroup run MFMAs, waves [WM, WM+WV) run fmacs; one workgroup per CU
 __global__ __launch_bounds__(1024) void mix_kernel(float* out, int iters, int wm, int nv_per_trip) {
     const int wave = threadIdx.x >> 6;
@@ -161,6 +175,15 @@ int main() {
             printf("A %-28s waves/SIMD=%d  %.3f ms  %.1f cyc/instr/SIMD  %.1f FLOP/clk/SIMD  %.1f TFLOP/s\n", names[f], wps, ms, cyc, flop[f] / cyc,
                    flop[f] * n_per_simd * 4 * 256 / ms / 1e9);
         }
+    }
+    printf("# A1: one DEPENDENT accumulator chain per wave (v_mfma_f32_32x32x2_f32)\n");
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        g_blocks_ = 256; g_threads_ = 256 * wps;
+        if (g_threads_ > 512) { g_blocks_ = 256 * (wps / 2); g_threads_ = 512; }     // 4 waves/SIMD = two 512-thread workgroups per CU
+        const float ms = timed(launch_chain, out, iters);
+        const double n_per_simd = (double)iters * 4 * wps;
+        printf("A1 waves/SIMD=%d  %.3f ms  %.1f cyc/instr/SIMD  %.1f TFLOP/s\n", wps, ms, ms * 1e-3 * GHZ * 1e9 / n_per_simd,
+               4096.0 * n_per_simd * 4 * 256 / ms / 1e9);
     }
     printf("# B: separate waves on one CU: WM matrix waves (32x32x2) + WV vector waves (v_fmac_f32), one workgroup per CU\n");
     const int cfgs[][2] = {{4, 0}, {0, 4}, {0, 8}, {4, 4}, {4, 8}, {8, 8}, {4, 12}};
