@@ -248,7 +248,16 @@ __host__ __device__ constexpr int koff(int k) {    // patch offset of tap k = c*
 struct Stem7Args {
     const float* in; const float* wT; const float* scale; const float* shift; float* out;
     int N, H, W, Cout, Mpad, Hc, Wc, Hp, Wp, tilesH, tilesW, chGroups;
+#ifdef RFX_TRACE
+    long long* trace;      // experiments only (make trace): 6 shader-clock stamps per workgroup (scripts/dbg/stem_trace.py)
+#endif
 };
+#ifdef RFX_TRACE
+extern "C" long long* rfx_debug_trace_ptr();
+#define RFX_STAMP7(i) do { if (threadIdx.x == 0 && a.trace) a.trace[(size_t)bx * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RFX_STAMP7(i)
+#endif
 
 __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, const unsigned bx) {
     constexpr int TH = r50::TH, TW = r50::TW, CR = r50::CR, CC = r50::CC, PR = r50::PR, PCW = r50::PCW, PHALF = r50::PHALF,
@@ -273,6 +282,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
     const size_t HW = (size_t)a.H * a.W;
 
+    RFX_STAMP7(0);
     // ---- input patch -> registers.  RFX_STEM7_ROWSTAGE (round 6): by ROWS -- wave w takes patch rows w, w+4, .. (3 x PR rows of PCW <= 71
     // columns: lane = column, lanes 0..PCW-65 a second one), so that the row's base address, its validity and its LDS row are
     // wave-uniform (scalar ALU) and a load costs ONE vector instruction besides itself (the border select).  The element-wise form
@@ -367,7 +377,9 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         }
     }
 #endif
+    RFX_STAMP7(1);
     __syncthreads();
+    RFX_STAMP7(2);
 
     // One channel group (32 channels) from the staged patch: MFMA phase -> C tile -> pooling -> global.  A generic lambda inlined
     // once per group (two groups for the 64-channel stem) rather than a run-time loop: as a loop the three sub-tile passes stay
@@ -408,7 +420,9 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
             }
         }
     }
+    RFX_STAMP7(3);
     __syncthreads();
+    RFX_STAMP7(4);
 
     // ---- MaxPool2d(3, stride 2, pad 1): -inf padding = positions outside the conv map are skipped; the values are ReLU
     // outputs, so the unsigned-integer max is the NaN-propagating float max and 0 its identity (see umaxf above)
@@ -430,6 +444,7 @@ __device__ __forceinline__ void stem7_conv_maxpool_body(const Stem7Args& a, cons
         }
         a.out[(((size_t)n * a.Cout + m0 + ch) * a.Hp + oh) * a.Wp + ow] = m;
     }
+    RFX_STAMP7(5);
     };   // channel_group
     if (RFX_STEM7_CGLOOP && a.chGroups == 2) {
         channel_group(0, true);
@@ -486,6 +501,9 @@ extern "C" int rfx_stem_conv7x7_maxpool_f32(const float* in, const float* wT, co
     a.tilesH = (a.Hp + r50::TH - 1) / r50::TH; a.tilesW = (a.Wp + r50::TW - 1) / r50::TW; a.chGroups = Cout / r50::MCH;
     const long long nwg = (long long)N * a.tilesH * a.tilesW * (RFX_STEM7_CGLOOP ? 1 : a.chGroups);
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+#ifdef RFX_TRACE
+    a.trace = rfx_debug_trace_ptr();
+#endif
     if (rfx_group_recording()) return rfx_group_record(&stem7_group_launch, &a, sizeof(a), (unsigned)nwg);
     hipLaunchKernelGGL(stem7_conv_maxpool_kernel, dim3((unsigned)nwg), dim3(256), 0, rfx_stream(stream), a);
     RFX_LAUNCH_CHECK();
