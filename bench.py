@@ -529,11 +529,28 @@ def rooflines(prof, elapsed, rank, cfg="3", dev=None):
             a = agg.setdefault((v,) + shp, [0, 0.0, 0.0])
             a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1) * 1e-3
         rows = sorted(((k, c, f, t) for k, (c, f, t) in agg.items()), key=lambda r: -r[3])
+        def workgroups(key):
+            """Workgroups of one launch where the grid is the tile count (the direct 3x3 kernels: kernel-id bit 5; patch shape from
+            bits 6-7 / 11, 128-channel tiles unless bits 0-1 say 64); the k-major 1x1 kernel is persistent (512 workgroups)."""
+            kid, N, Cin, H, W, Cout, kk, stride = key
+            if kid & 1024:
+                return 512
+            if not (kid & 32) or (kid & 512):
+                return None
+            ph, pw = (16, 16) if kid & 2048 else {0: (8, 16), 1: (16, 8), 2: (32, 4)}[(kid >> 6) & 3]
+            bm = 64 if (kid & 3) else 128
+            return N * -(-H // ph) * -(-W // pw) * -(-Cout // bm)
         with open(os.environ["RFX_BENCH_DUMP"], "w") as fh:
-            fh.write("variant,N,Cin,H,W,Cout,k,stride,calls,total_ms,TFLOPs,share\n")
+            fh.write("# per kernel instance and shape over the profiled pass (one stream): N = images of the launch (64 = a full round or a trunk "
+                     "level, smaller = a shrinking multi-homography round); workgroups per launch and their remainder over the 512 resident "
+                     "slots (256 CUs x 2) where the grid is the tile count\n")
+            fh.write("variant,kernel,N,Cin,H,W,Cout,k,stride,calls,total_ms,TFLOPs,share,workgroups,waves_of_512,last_wave_fill\n")
             tot = sum(r[3] for r in rows)
             for k, c, f, t in rows:
-                fh.write(",".join(str(x) for x in k) + ",%d,%.3f,%.1f,%.3f\n" % (c, t * 1e3, f / t / 1e12, t / tot))
+                wg = workgroups(k)
+                extra = ",,," if wg is None else ",%d,%.2f,%.2f" % (wg, wg / 512.0, (wg % 512) / 512.0 if wg % 512 else 1.0)
+                fh.write("%d,\"%s\"," % (k[0], kernel_name(k[0])) + ",".join(str(x) for x in k[1:]) + ",%d,%.3f,%.1f,%.3f%s\n"
+                         % (c, t * 1e3, f / t / 1e12, t / tot, extra))
     dom = max(by, key=lambda k: by[k][2])           # the kernel instance with the most GPU time
     n, f, t, b = by[dom]
     tot_f, tot_t = sum(g[1] for g in by.values()), sum(g[2] for g in by.values())
