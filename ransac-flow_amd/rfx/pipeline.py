@@ -694,8 +694,9 @@ class AlignPipeline:
         resumes the group whose event is due): while one group waits for the host -- accept flags, the LAPACK stage -- the other
         groups' kernels keep the GPU busy, and the small launches of one group's late rounds share the chip with another's.
         Per pair the arithmetic is unchanged (every kernel computes a pair independently; device draws are keyed by absolute
-        pair position / id).  None = RFX_MULTIH_SPLIT or, for device draws, 3 groups from 48 pairs on, 2 from 16 (measured on config 3,
-        profiles/r06_stream_sweep.txt: 1 / 2 / 3 groups = 110.2 / 112.7 / 113.6 pairs/s), else 1; forced to 1 with host draws /
+        pair position / id).  None = RFX_MULTIH_SPLIT or, for device draws, 3 groups from 12 pairs on, 2 from 8 (measured,
+        profiles/r06_stream_sweep.txt: config 3, 64 pairs: 1 / 2 / 3 / 4 / 6 groups = 110.2 / 112.7 / 115.3 / 115.4 / 115.6 pairs/s;
+        config 4, 16 pairs, 50 000 hypotheses: 2 / 3 / 4 groups = 56.1 / 57.4 / 56.2), else 1; forced to 1 with host draws /
         ``sample_fn`` (the CPU generator is consumed in pair order), with ``trace`` and under an ops.Profiler (per-launch events).
         ``sample_fn(b, n, nbIter)`` -> (nbIter,4) int64 CPU tensor: explicit draws (parity mode; costs a second sync per round).
         ``pair_ids``: absolute ids of the batch's pairs for the device draw (see _draw_epoch): with them a pair's homographies
@@ -712,7 +713,7 @@ class AlignPipeline:
         idx1, idx2, cnt = self._mutual_batched(feats, B)
         host_draw = sample_fn is not None or self.draw == "host"
         if split is None:
-            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (3 if B >= 48 else (2 if B >= 16 else 1))
+            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (3 if B >= 12 else (2 if B >= 8 else 1))
         if host_draw or trace is not None or ops.Profiler.active() is not None and os.environ.get("RFX_MULTIH_SPLIT_PROFILED", "0") != "1":
             split = 1
         split = max(1, min(int(split), B))
@@ -738,7 +739,7 @@ class AlignPipeline:
     def _drive_rounds(self, gens):
         """Run lock-step round generators to completion from this host thread: generator k runs under stream k (the caller's
         stream for k = 0, pipeline-owned side streams after), yields a HIP event whenever it needs the host to see device results,
-        and is resumed -- round robin -- once that event has completed.  One generator: the plain sequential loop."""
+        and is resumed once that event has completed -- whichever group is ready first.  One generator: the plain sequential loop."""
         main = torch.cuda.current_stream(self.dev)
         if len(gens) > 1:
             pool = self.__dict__.setdefault("_round_streams", [])
@@ -749,10 +750,12 @@ class AlignPipeline:
                 s.wait_stream(main)
         else:
             streams = [main]
-        import collections
-        live = collections.deque((g, s, None) for g, s in zip(gens, streams))
+        live = [(g, s, None) for g, s in zip(gens, streams)]
         while live:
-            g, s, ev = live.popleft()
+            # the group whose event has already completed goes first (its host work -- the LAPACK stage, the next round's
+            # launches -- then runs under the other groups' queued kernels); none ready: wait for the one that yielded first
+            k = next((i for i, (_, _, ev) in enumerate(live) if ev is None or ev.query()), 0)
+            g, s, ev = live.pop(k)
             if ev is not None:
                 ev.synchronize()
             with torch.cuda.stream(s):
