@@ -415,7 +415,7 @@ def build_workload(args, dev, rank, world, score_chunk=None):
         R = ops.MultiHRecords(B, h_r // 8, w_r // 8, dev, max_h=11, hd2=h_d2 // 8, wd2=w_d2 // 8)
         R.rec[:, 2] = float(rank)
         pipe.multi_h_kitti_batched(raw_all[0], raw_all[1], fineSize=650, maskRegionTh=0.005, cc_th=0.01, records=R, want_lists=False,
-                                   pair_ids=seeds)
+                                   pair_ids=seeds, split=args.split)
         return R.rec
     wl = ("BASELINE config 5: %d evalKITTI-shaped %dx%d pairs per GPU per step (coarseSize 800 -> 2640x800 target, 3 scales "
           "x1.2, nA = 25 747, coarseIter 50 000; fineSize 650: two-resolution fine pass, cycle-checked matchability, "

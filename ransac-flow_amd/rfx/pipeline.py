@@ -777,12 +777,15 @@ class AlignPipeline:
         cut = (lambda t: t) if whole else (lambda t: None if t is None else t[lo:hi])
         idx1, idx2, cnt = cut(st["idx1"]), cut(st["idx2"]), cut(st["cnt"])
         Mask, nbH, bg, ids = cut(st["Mask"]), cut(st["nbH"]), cut(st["bg"]), cut(st["ids"])
-        IsT, ItT = cut(prep["IsTensor"]), cut(prep["ItTensor"])
+        IsT, ItT = cut(prep.get("IsTensor")), cut(prep.get("ItTensor"))
         rt, ct = feats["rt"], feats["ct"]
         R = st["records"]
         if R is not None and not whole:
             R = R.rows(lo, hi)
         featt = cut(st["featt"])
+        kitti = st.get("kitti")
+        if kitti is not None:
+            kitti = dict(kitti, tensor_s=cut(kitti["tensor_s"]), tensor_d2=cut(kitti["tensor_d2"]), tensor_resize=cut(kitti["tensor_resize"]))
         outs, nb, eye, degen, epoch = st["outs"], st["nb"], st["eye"], st["degenerate"], st["epoch"]
         acc_host = torch.empty(G, dtype=torch.int32).pin_memory()
         active = list(range(G))
@@ -799,7 +802,7 @@ class AlignPipeline:
                 # FeatureExtractor pass (independent of the search) BEHIND the gather, so that the host's LAPACK stage runs
                 # while the GPU works; the other rounds hide it under another group's kernels (split > 1)
                 search = ops.ransac_h4_batched_begin(M1, M2, n_dev, smp, self.tol)
-                if featt is None:
+                if featt is None and kitti is None:
                     featt = ops.l2norm(self.feat(ItT))
                 yield search.event
                 info = {} if getattr(self, "exact_log", None) is not None else None
@@ -807,21 +810,34 @@ class AlignPipeline:
                 if info is not None:
                     self.exact_log.append(dict(info, round=rnd - 1, lo=lo, active=len(active)))
             else:
-                if featt is None:
+                if featt is None and kitti is None:
                     featt = ops.l2norm(self.feat(ItT))
                 bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol, degenerate=degen)
             Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
-            flowCoarse = ops.warp_grid(Hs, h, w)
-            Is = IsT if full else IsT.index_select(0, A)
-            pm = self.pred_flow_mask(Is, featt if full else featt.index_select(0, A), flowCoarse)
             mask_before = (Mask if full else Mask.index_select(0, A)).clone() if trace is not None else None
-            accept, gain = ops.multih_accept(pm["match"], Mask, bg, A, res, n_dev, nbH, maskRegionTh, 0, bestH=bestH,
-                                             flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
-                                             match21Down8=pm["match21Down8"], records=R)
+            if kitti is None:
+                flowCoarse = ops.warp_grid(Hs, h, w)
+                Is = IsT if full else IsT.index_select(0, A)
+                pm = self.pred_flow_mask(Is, featt if full else featt.index_select(0, A), flowCoarse)
+                match, flow_d2 = pm["match"][:, 0], None
+                accept, gain = ops.multih_accept(pm["match"], Mask, bg, A, res, n_dev, nbH, maskRegionTh, 0, bestH=bestH,
+                                                 flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
+                                                 match21Down8=pm["match21Down8"], records=R)
+            else:
+                # evaluation/evalKITTI/evaluation.py:279-336: the two-resolution fine pass, the small-component filter, accept mode 1
+                selk = (lambda t: t) if full else (lambda t: t.index_select(0, A))
+                flow_d2, pm, match = self.kitti_fine_round(Hs, selk(kitti["tensor_s"]), selk(kitti["tensor_d2"]), selk(kitti["tensor_resize"]),
+                                                           (h, w), kitti["cc_th"], kitti["remove_small_cc"])
+                accept, gain = ops.multih_accept(match, Mask, bg, A, res, n_dev, nbH, maskRegionTh, 1, bestH=bestH,
+                                                 flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
+                                                 match21Down8=pm["match21Down8"], flowD2=flow_d2, records=R)
             if trace is not None:
-                trace.append(dict(active=[lo + k for k in active], mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm,
-                                  match=pm["match"][:, 0], accept=accept, gain=gain,
-                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp, round=rnd - 1))
+                tr = dict(active=[lo + k for k in active], mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm,
+                          match=match, accept=accept, gain=gain, mask_after=(Mask if full else Mask.index_select(0, A)).clone(),
+                          samples=smp, round=rnd - 1)
+                if flow_d2 is not None:
+                    tr["flowD2"] = flow_d2
+                trace.append(tr)
             md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
             acc_host[:len(active)].copy_(accept, non_blocking=True)
             ev = torch.cuda.Event()
@@ -835,10 +851,20 @@ class AlignPipeline:
                 b = lo + m
                 if want_lists:
                     outs[b]["H"].append(bestH[k])
+                    if flow_d2 is not None:
+                        outs[b]["flowD2"].append(flow_d2[k:k + 1])
                     outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
                     outs[b]["matchDown8"].append(md2[k:k + 1])
                 nb[b] += 1
-                if nb[b] <= maxCoarse:
+                if kitti is None:
+                    if nb[b] <= maxCoarse:
+                        nxt.append(m)
+                elif st["records"] is not None and nb[b] >= st["records"].max_h:
+                    # the reference's ``while True`` has no round limit; a fixed-size record has: the pair stops at the record's
+                    # capacity and its record says so (status 4 = "capped by the driver": the reference might have gone on; a
+                    # truncated pair is distinguishable from one that ended on the accept test)
+                    st["records"].rec[b, 1] = 4.0
+                else:
                     nxt.append(m)
             active = nxt
 
@@ -1099,7 +1125,7 @@ class AlignPipeline:
         return flow_d2, pm, match
 
     def multi_h_kitti_batched(self, src_u8, tgt_u8, fineSize=650, maskRegionTh=0.005, cc_th=0.01, It_bg=None, sample_fn=None,
-                              remove_small_cc=None, records=None, want_lists=True, trace=None, pair_ids=None, draw_epoch=0):
+                              remove_small_cc=None, records=None, want_lists=True, trace=None, pair_ids=None, draw_epoch=0, split=None):
         """multi_h_kitti() for B pairs of ONE size in lock-step (src_u8 / tgt_u8: (B,H,W,3) uint8 on the device): round k
         computes the k-th homography of every pair that is still active -- one batched launch chain for the trunk features,
         the match filtering (rfx_filter_matches_f32), the index draw (device mode), RANSAC (rfx_ransac_h4_batched), the two
@@ -1120,61 +1146,33 @@ class AlignPipeline:
         tensor_s, _ = ops.u8_to_f32(src_u8)                                              # sources at their ORIGINAL size
         tensor_resize, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_r, h_r))
         tensor_d2, _ = ops.u8_to_f32(ops.lanczos_resize_u8(tgt_u8, w_d2, h_d2))
-        rt, ct = feats["rt"], feats["ct"]
         idx1, idx2, cnt = self._mutual_batched(feats, B)
-        bg = None if It_bg is None else It_bg.to(dev).float().contiguous()
-        Mask = torch.zeros((B, h_org, w_org), dtype=torch.float32, device=dev)
-        nbH = torch.zeros(B, dtype=torch.int32, device=dev)
-        outs = [dict(H=[], flowD2=[], flowDown8=[], matchDown8=[]) for _ in range(B)]
-        nb = [0] * B
-        eye = torch.eye(3, device=dev)
-        active = list(range(B))
+        host_draw = sample_fn is not None or self.draw == "host"
+        if split is None:
+            # measured at config 5 (B = 8): two groups of 4 hide the exact mode's host stage but run the fine passes at batch 4
+            # instead of 8 -- a wash (21.0 vs 21.1 pairs/s, profiles/r06_stream_sweep.txt); groups pay from 8 pairs per group on
+            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (2 if B >= 16 else 1)
+        if host_draw or trace is not None or remove_small_cc is not None or (
+                ops.Profiler.active() is not None and os.environ.get("RFX_MULTIH_SPLIT_PROFILED", "0") != "1"):
+            split = 1                         # (an injected host filter is called in pair order: one group)
+        split = max(1, min(int(split), B))
         ids, epoch = self._draw_epoch(pair_ids, "kitti", draw_epoch)
-        rnd = 0
-        while active:
-            full = len(active) == B
-            A = None if full else torch.tensor(active, dtype=torch.int32).to(dev, non_blocking=True)
-            sel = (lambda t: t) if full else (lambda t: t.index_select(0, A))
-            M1, M2, n_dev = ops.filter_matches(idx1, idx2, cnt, A, Mask, bg, rt, ct, feats["HA"], feats["WA"], feats["Ht"],
-                                               feats["Wt"])
-            smp = self._round_draws(active, n_dev, sample_fn, A, ids, epoch, rnd)
-            rnd += 1
-            bestH, inl, res = ops.ransac_h4_batched(M1, M2, n_dev, smp, self.tol,
-                                                    degenerate=self._degenerate_mode(sample_fn is not None or self.draw == "host"))
-            Hs = torch.where((res[:, 0] == 0)[:, None, None], bestH, eye)                # failed pairs: any finite warp
-            flow_d2, pm, match = self.kitti_fine_round(Hs, sel(tensor_s), sel(tensor_d2), sel(tensor_resize), (h_org, w_org),
-                                                       cc_th, remove_small_cc)
-            mask_before = (Mask if full else Mask.index_select(0, A)).clone() if trace is not None else None
-            accept, gain = ops.multih_accept(match, Mask, bg, A, res, n_dev, nbH, maskRegionTh, 1, bestH=bestH,
-                                             flowDown8=pm["flowDown8"], match12Down8=pm["match12Down8"],
-                                             match21Down8=pm["match21Down8"], flowD2=flow_d2, records=records)
-            if trace is not None:
-                trace.append(dict(active=list(active), mask_before=mask_before, n=n_dev, H=bestH, res=res, inlier=inl, pm=pm, match=match,
-                                  flowD2=flow_d2, accept=accept, gain=gain,
-                                  mask_after=(Mask if full else Mask.index_select(0, A)).clone(), samples=smp, round=rnd - 1))
-            md2 = torch.cat((pm["match12Down8"], pm["match21Down8"]), dim=1) if want_lists else None
-            acc = accept.cpu().tolist()                                                 # the round's ONE sync
-            nxt = []
-            for k, b in enumerate(active):
-                if not acc[k]:
-                    continue
-                if want_lists:
-                    outs[b]["H"].append(bestH[k])
-                    outs[b]["flowD2"].append(flow_d2[k:k + 1])
-                    outs[b]["flowDown8"].append(pm["flowDown8"][k:k + 1])
-                    outs[b]["matchDown8"].append(md2[k:k + 1])
-                nb[b] += 1
-                if records is not None and nb[b] >= records.max_h:
-                    # the reference's ``while True`` has no round limit; a fixed-size record has: the pair stops at the
-                    # record's capacity and its record says so (status 4 = "capped by the driver": the reference might have
-                    # gone on; a truncated pair is distinguishable from one that ended on the accept test)
-                    records.rec[b, 1] = 4.0
-                    continue
-                nxt.append(b)
-            active = nxt
+        if ids is None and split > 1:
+            ids = torch.arange(B, dtype=torch.int32, device=dev)
+        # the rounds are _multi_h_rounds' (the Hpatch driver's generator) with the KITTI fine pass / accept mode / stop rule: lock-step
+        # groups on streams, ready-first scheduling, the exact mode's host stage hidden under the other groups' kernels
+        st = dict(prep=dict(prep, IsTensor=None, ItTensor=None), feats=feats, idx1=idx1, idx2=idx2, cnt=cnt, h=h_org, w=w_org, B=B, ids=ids,
+                  epoch=epoch, bg=None if It_bg is None else It_bg.to(dev).float().contiguous(),
+                  Mask=torch.zeros((B, h_org, w_org), dtype=torch.float32, device=dev), nbH=torch.zeros(B, dtype=torch.int32, device=dev),
+                  outs=[dict(H=[], flowD2=[], flowDown8=[], matchDown8=[]) for _ in range(B)], nb=[0] * B, records=records,
+                  eye=torch.eye(3, device=dev), degenerate=self._degenerate_mode(host_draw), featt=None,
+                  kitti=dict(tensor_s=tensor_s, tensor_d2=tensor_d2, tensor_resize=tensor_resize, cc_th=cc_th, remove_small_cc=remove_small_cc))
+        bounds = [(B * k // split, B * (k + 1) // split) for k in range(split)]
+        self._drive_rounds([self._multi_h_rounds(st, lo, hi, None, maskRegionTh, sample_fn, want_lists, trace) for lo, hi in bounds])
+        outs = st["outs"]
         for b in range(B):
-            outs[b]["mask"] = Mask[b]
-            outs[b]["nbH"] = nb[b]
+            outs[b]["mask"] = st["Mask"][b]
+            outs[b]["nbH"] = st["nb"][b]
             outs[b]["matches"] = (idx1[b], idx2[b], cnt[b:b + 1])      # the cached mutual matches (rows beyond the count: undefined)
         return outs
 

@@ -10,6 +10,7 @@ for step in "$@"; do
     ref)        ls oracle/_ref oracle/_ref/utils oracle/_ref/_extract 2>&1 | head -20; python -c "import sys; sys.path.insert(0,'oracle'); import ref_loader; print(ref_loader.REF_ROOT, ref_loader.kind() if ref_loader.available() else 'ABSENT')" ;;
     tests)      timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -${TAIL:-25} ;;
     newtests)   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_multih.py "tests/test_gpu_dropin.py" -x -q -m gpu --durations=5 2>&1 | tail -${TAIL:-25} ;;
+    kittitests) timeout 900 python -m pytest tests -x -q -m gpu -k "kitti or lock_step" --durations=5 2>&1 | tail -${TAIL:-12} ;;
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ;;
     bench)      RFX_PARITY_RECORDS=$OUT/bench_parity_records timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench exit $?"; tail -3 $OUT/bench.err | cut -c1-300
                 python scripts/bench_digest.py $OUT/bench.log ;;

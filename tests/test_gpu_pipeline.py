@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import restate
-from rfx import weights, synth
+from rfx import weights, synth, ops
 from rfx.pipeline import AlignPipeline
 
 pytestmark = pytest.mark.gpu
@@ -325,6 +325,41 @@ def test_kitti_lock_step_driver_equals_the_per_pair_driver(dev):
             assert (s1["flowDown8"][k] - m["flowDown8"][k]).abs().max() < 1e-5
             assert (s1["matchDown8"][k] - m["matchDown8"][k]).abs().max() < 1e-5
         assert float((s1["mask"] != m["mask"]).float().mean()) < 1e-4
+
+
+def test_kitti_lock_step_groups_on_streams_give_the_one_group_records_bit_for_bit(dev):
+    """multi_h_kitti_batched(split=k): the KITTI rounds run on the Hpatch driver's round generator (lock-step groups on HIP
+    streams, ready-first scheduling, the exact mode's host stage under the other groups' kernels).  Device draws are keyed by
+    pair position / id, every kernel computes a pair independently: records, masks and lists equal the one-group run's bit for
+    bit, in the exact mode and the device-null-vector mode; the capacity stop (status 4) too."""
+    sds = _sds()
+    sds["match"] = weights.net_matchability_sd(3, last_std=3.0)
+    pairs = [synth.make_pair(96, 312, seed=s, homography=True, amp=0.03) for s in (11, 12, 13, 14, 15)]
+    for degen in ("lapack", "device"):
+        pipe = AlignPipeline(sds, nbScale=3, nbIter=300, tolerance=0.05, minSize=160, scaleR=1.2, variant="B", device=dev, seed=7,
+                             degenerate=degen)
+        raw = pipe.upload_raw(pairs)
+        w_r, h_r = pipe.resize_img_dims(312, 96, 8, 200)
+        w_d2, h_d2 = pipe.resize_img_dims(312, 96, 8, 100)
+
+        def run(split, max_h=8):
+            pipe.reseed(7)
+            R = ops.MultiHRecords(len(pairs), h_r // 8, w_r // 8, dev, max_h=max_h, hd2=h_d2 // 8, wd2=w_d2 // 8)
+            outs = pipe.multi_h_kitti_batched(raw[0], raw[1], fineSize=200, maskRegionTh=0.005, cc_th=0.01, records=R, split=split)
+            torch.cuda.synchronize()
+            return R, outs
+        R1, outs1 = run(1)
+        assert int(R1.rec[:, 0].sum()) >= len(pairs) + 1
+        for k in (2, 3):
+            Rk, outs = run(k)
+            assert torch.equal(Rk.rec, R1.rec), (degen, k)
+            for a, b in zip(outs, outs1):
+                assert a["nbH"] == b["nbH"] and torch.equal(a["mask"], b["mask"])
+                assert all(torch.equal(x, y) for x, y in zip(a["H"], b["H"]))
+                assert all(torch.equal(x, y) for x, y in zip(a["flowD2"], b["flowD2"]))
+        Rc1, _ = run(1, max_h=1)
+        Rc2, _ = run(2, max_h=1)
+        assert torch.equal(Rc1.rec, Rc2.rec) and bool((Rc1.rec[:, 1] == 4.0).any())
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
