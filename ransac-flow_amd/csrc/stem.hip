@@ -22,6 +22,18 @@ constexpr int TH = 4, TW = 16;                 // pooled outputs per workgroup
 constexpr int CR = 2 * TH + 2, CC = 2 * TW + 2; // conv outputs under the tile: 10 x 34
 constexpr int PRW = CR + 2, PCL = CC + 2;       // input patch 12 x 36
 constexpr int CST = CC + 1;                     // row stride of the conv tile in LDS (35: odd -> rows on different banks)
+// experiments only (scripts/ubench/stem_bench.py; WRONG RESULTS): RFX_STEM3_DBG removes one phase of the 3x3 stem to price it
+//   1 no pooling pass / output stores   2 pooling arithmetic but no interior stores   3 no MFMA phase / C-tile stores
+#ifndef RFX_STEM3_DBG
+#define RFX_STEM3_DBG 0
+#endif
+#ifndef RFX_STEM3_PLANE_PAD
+#define RFX_STEM3_PLANE_PAD 1                   // 0: round 5's 350-word planes (A/B runs)
+#endif
+constexpr int CPS = CR * CST + RFX_STEM3_PLANE_PAD;   // channel-plane stride 351: ODD, so the four channels a wavefront of the pooling pass covers
+                                                // (8 blocks x 2 block rows x 4 channels, block columns 4 words apart) fall into the four bank
+                                                // classes mod 4 -- every bank twice, the minimum for 64 lanes; 350 gave two classes: 4-way
+                                                // conflicts on each of the 36 window reads (SQ_LDS_BANK_CONFLICT 0.20 per instruction, round 6)
 constexpr int NPX = CR * CC;                    // 340 conv pixels
 constexpr int NSUB = (NPX + 31) / 32;           // 11 MFMA sub-tiles of 32 pixels
 constexpr int KKS = 14;                         // 28 = 27 padded k, as k-pairs
@@ -44,7 +56,7 @@ __device__ __forceinline__ float umaxf(float x, float y) {
 
 __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
     __shared__ float P[3][PRW][PCL];          // input patch
-    __shared__ float C[MCH][CR][CST];         // conv + BN + ReLU outputs under the tile
+    __shared__ float C[MCH * CPS];            // conv + BN + ReLU outputs under the tile: [channel][CR][CST], planes CPS apart
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lrow = lane >> 5, lcol = lane & 31;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 
     // ---- 2./3. conv on the MFMA, BN + ReLU, tile -> LDS
     const float* pf = &P[0][0][0];
-    for (int s = wave; s < NSUB; s += 4) {
+    for (int s = wave; s < NSUB && RFX_STEM3_DBG != 3; s += 4) {
         const int p = s * 32 + lcol;
         const bool pv = p < NPX;
         const int pc = pv ? p : 0;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
             for (int r = 0; r < 16; ++r) {
                 float v = fmaf(acc[r], sc[r], sh[r]);
                 v = v > 0.0f ? v : 0.0f;
-                C[4 * lrow + (r & 3) + 8 * (r >> 2)][py][px] = v;
+                C[(4 * lrow + (r & 3) + 8 * (r >> 2)) * CPS + py * CST + px] = v;
             }
         }
     }
@@ -127,12 +139,12 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
     // ---- 4. max 2x2 (stride 1) + blur/2 with reflection on the max-pooled map; 2x2 output blocks
     const float w3[3] = {0.25f, 0.5f, 0.25f};
     const int Hm = a.H - 1, Wm = a.W - 1;
-    for (int b = t; b < MCH * (TH / 2) * (TW / 2); b += 256) {
+    for (int b = t; b < MCH * (TH / 2) * (TW / 2) && RFX_STEM3_DBG != 1; b += 256) {
         const int bx = b % (TW / 2), by = (b / (TW / 2)) % (TH / 2), ch = b / ((TW / 2) * (TH / 2));
         const int oh = oh0 + 2 * by, ow = ow0 + 2 * bx;        // first output of the block
         if (oh >= a.Ho || ow >= a.Wo) continue;
         float* dst = a.out + ((size_t)n * a.Cout + m0 + ch) * a.Ho * a.Wo;
-        const float (*Cc)[CST] = C[ch];
+        const float* Cc = C + ch * CPS;
         // interior: the 5x5 max-map window rows 2oh-1 .. 2oh+3, cols 2ow-1 .. 2ow+3 needs no reflection
         const bool interior = oh >= 1 && 2 * oh + 3 <= Hm - 1 && ow >= 1 && 2 * ow + 3 <= Wm - 1 && oh + 1 < a.Ho && ow + 1 < a.Wo;
         if (interior) {
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 #pragma unroll
             for (int y = 0; y < 6; ++y)
 #pragma unroll
-                for (int x = 0; x < 6; ++x) v[y][x] = Cc[ly + y][lx + x];
+                for (int x = 0; x < 6; ++x) v[y][x] = Cc[(ly + y) * CST + lx + x];
             float hmx[5][6], M[5][5];   // separable: vertical pair max, then horizontal pair max
 #pragma unroll
             for (int y = 0; y < 5; ++y)
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
                     for (int i = 0; i < 3; ++i)
 #pragma unroll
                         for (int j = 0; j < 3; ++j) acc = fmaf(M[2 * dy + i][2 * dx + j], w3[i] * w3[j], acc);
-                    dst[(size_t)(oh + dy) * a.Wo + ow + dx] = acc;
+                    if (RFX_STEM3_DBG != 2 || acc == 12345.678f) dst[(size_t)(oh + dy) * a.Wo + ow + dx] = acc;
                 }
             continue;
         }
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void stem_conv_maxblur_kernel(StemArgs a) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int mx = reflect1i(2 * o_w - 1 + j, Wm) - cx0;
-                        const float m = umaxf(umaxf(Cc[my][mx], Cc[my + 1][mx]), umaxf(Cc[my][mx + 1], Cc[my + 1][mx + 1]));
+                        const float m = umaxf(umaxf(Cc[my * CST + mx], Cc[(my + 1) * CST + mx]), umaxf(Cc[my * CST + mx + 1], Cc[(my + 1) * CST + mx + 1]));
                         acc = fmaf(m, w3[i] * w3[j], acc);
                     }
                 }

@@ -45,6 +45,27 @@ def main():
                    lib=os.environ.get("RFX_LIB", "librfx.so"))
         rows.append(row)
         print(json.dumps(row), flush=True)
+    # the FeatureExtractor stem (conv3x3 3 -> 64 + BN + ReLU + MaxPool(2, 1) + BlurPool/2) on the fine-pass shapes of config 3
+    sdf = weights.feature_extractor_sd(1, randomize_bn=True)
+    plan3 = ConvPlan(sdf["conv1.weight"], {k: sdf["bn1." + k] for k in ("weight", "bias", "running_mean", "running_var")}, 1, 1, ACT_RELU, dev)
+    for (H, W) in ((480, 640), (240, 320)):
+        g = torch.Generator(device=dev).manual_seed(H + 1)
+        x = torch.randn(a.n, 3, H, W, device=dev, generator=g)
+        same = bool(torch.equal(ops.stem_conv_maxblur(x[:2], plan3), ops.maxblurpool2d(plan3(x[:2]), 2)))
+        for _ in range(3):
+            ops.stem_conv_maxblur(x, plan3)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            ops.stem_conv_maxblur(x, plan3)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tf = 2.0 * a.n * H * W * 64 * 27 / ms / 1e9
+        row = dict(kernel="stem3", N=a.n, H=H, W=W, ms=round(ms, 3), tflops=round(tf, 1), frac=round(tf / 157.3, 3), bit_identical=same,
+                   lib=os.environ.get("RFX_LIB", "librfx.so"))
+        rows.append(row)
+        print(json.dumps(row), flush=True)
     if a.out:
         json.dump(rows, open(a.out, "w"), indent=1)
 
