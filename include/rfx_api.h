@@ -42,7 +42,7 @@ const char* rfx_version(void);
  * rfx_compose_flow_f32 gained Hc/Wc, 3x3/s1/p1 geometries moved to rfx_conv3x3_f32's packed weights; round 3: multi-homography
  * round kernels, two-direction correlation, grouped launches; round 4: rfx_draw_samples_i64 keyed by pair id).  A binding
  * compares rfx_abi_version() with the RFX_ABI_VERSION it was written against and refuses a mismatch. */
-#define RFX_ABI_VERSION 9
+#define RFX_ABI_VERSION 10
 int rfx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -495,6 +495,22 @@ int rfx_multih_accept_f32(const float* match, float* mask, const float* bg, cons
                           const float* match12Down8, const float* match21Down8, int h8, int w8, const float* flowD2, int hd2,
                           int wd2, float* rec, long long rec_stride, int max_h, int off_H, int off_flow, int off_match,
                           int off_d2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * rfx_conv1x1_split_f32 (ABI 10): the 1x1 / stride 1 / pad 0 convolution of rfx_conv2d_f32 (the Bottleneck conv1 / conv3 layers,
+ * model/resnet50.py:71-79,93-103) with float32 results computed on the bf16 matrix cores by EXACT operand splitting:
+ *     x = hi + mid + lo,  hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (round to nearest even; the sum is exact)
+ *     out[n,m,p] = act(scale[m] * S + shift[m] + residual),
+ *     S = sum_k (wh xh) + sum_k (wh xm + wm xh + wm xm + wh xl + wl xh)                 (every product exact in float32; the two
+ *         sums in two float32 accumulators that round once per 16 k, added once at the end; the three dropped terms are below
+ *         2^-32 |w x|).  Error against the float64 sum: 0.4x the fp32 kernel's fma chain (profiles/r06_bf16_split_study.json).
+ * NOT bit-identical to rfx_conv2d_f32 (closer to the exact sum); +-inf inputs give NaN.  Cin % 16 == 0.
+ * wS: the weights split on the host and packed in fragment order, bf16 bit patterns (uint16):
+ *     wS[kb = k / 16][piece (hi, mid, lo)][h = (k % 16) / 8][m (Mpad = Cout rounded up to 128, rows >= Cout zero)][k % 8]
+ * in (N,Cin,HW), out / residual (N,Cout,HW) float32.
+ * ------------------------------------------------------------------------------------------ */
+int rfx_conv1x1_split_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
+                          float* out, int N, int Cin, int HW, int Cout, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sky segmentation forward pass: SegNet.getSky (segNet/segEval.py:23-43) = ResNet-50-dilated encoder

@@ -26,12 +26,19 @@ class ResNet50Trunk:
             for b in range(nblk):
                 p = "%s.%d" % (layer, b)
                 s = stride if b == 0 else 1
+                # split=True (round 6): the long-K 1x1 layers -- conv1 of every block but the first (K = 256 ... 1024) and layer3's
+                # conv3 (K = 256, + residual) -- run on rfx_conv1x1_split_f32: float32 sums from exact bf16 operand pieces, closer to
+                # the exact sum than the fp32-MFMA kernel and 1.3-1.5x faster (profiles/r06_split_1x1_bench.json).  The conv3 of a
+                # block whose tail can fuse (layer1 / layer2) stays on the fp32 kernels: fused and two-kernel forms stay bit-identical.
+                w1 = sd[p + ".conv1.weight"]
                 blk = {
-                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), 1, 0, ACT_RELU, device),
+                    "c1": ConvPlan(w1, _bn(sd, p + ".bn1"), 1, 0, ACT_RELU, device, split=w1.shape[1] >= 128),
                     "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device),
                     "c3": ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device),
                     "ds": None,
                 }
+                if not ops.bottleneck_tail_shape(blk["c2"], blk["c3"]):
+                    blk["c3"] = ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device, split=True)
                 if (p + ".downsample.0.weight") in sd:
                     blk["ds"] = ConvPlan(sd[p + ".downsample.0.weight"], _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE,
                                          device)

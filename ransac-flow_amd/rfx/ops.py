@@ -158,10 +158,36 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+KID_SPLIT_1X1 = 32768      # Profiler kernel id of rfx_conv1x1_split_f32 (| 1: 64-channel tiles, | 2: 128-channel tiles)
+
+
+def conv_split_enabled():
+    """RFX_CONV_SPLIT=0: every convolution on the fp32 MFMA kernels (A/B runs; the float32-only figure of the bench line)."""
+    return os.environ.get("RFX_CONV_SPLIT", "1") != "0"
+
+
+def split_weights(w2d):
+    """(Cout, Cin) float32 -> rfx_conv1x1_split_f32's wS: the three bf16 pieces of every weight (hi = bf16(w), mid = bf16(w - hi),
+    lo = bf16(w - hi - mid); round to nearest even, hi + mid + lo == w exactly) in fragment order
+    [k / 16][piece][(k % 16) / 8][m (Mpad)][k % 8], as int16 bit patterns."""
+    w = w2d.detach().float().cpu()
+    Cout, Cin = w.shape
+    if Cin % 16:
+        raise ValueError("split_weights: Cin %% 16 != 0 (%d)" % Cin)
+    hi = w.bfloat16()
+    r1 = w - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    Mpad = (Cout + 127) // 128 * 128
+    pieces = torch.zeros(3, Mpad, Cin, dtype=torch.bfloat16)
+    pieces[:, :Cout] = torch.stack((hi, mid, lo))
+    return pieces.view(3, Mpad, Cin // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous().view(torch.int16)
+
+
 class ConvPlan:
     """Packed weights + folded BatchNorm of one convolution (see rfx_conv2d_f32 in include/rfx_api.h)."""
 
-    def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5, dilation=1, bias=None):
+    def __init__(self, weight, bn=None, stride=1, pad=0, act=ACT_NONE, device=None, eps=1e-5, dilation=1, bias=None, split=False):
         # weight: (Cout, Cin, KH, KW) float32 (any device); bn: dict(weight,bias,running_mean,running_var) or None;
         # dilation > 1: rfx_conv2d_dilated_f32 (the sky-segmentation encoder, segNet/segModel.py:196-205); bias: the convolution's own
         # bias (segModel.py:243,245: the classifier convolutions), only without bn
@@ -180,6 +206,12 @@ class ConvPlan:
         self.w2d = w.reshape(self.Cout, K) if (self.KH == 1 and self.KW == 1) else None   # kept for quad_weights()
         self._wq = None
         self.wP = None
+        # split=True: a 1x1 / stride 1 convolution runs on rfx_conv1x1_split_f32 (float32 sums from exact bf16 operand pieces on the
+        # bf16 matrix cores: csrc/conv1x1s.hip) where the shape allows it and RFX_CONV_SPLIT != 0
+        self.wS = None
+        if (split and conv_split_enabled() and self.KH == 1 and self.KW == 1 and stride == 1 and pad == 0 and self.dilation == 1
+                and self.Cin % 16 == 0):
+            self.wS = split_weights(w.reshape(self.Cout, K)).to(device or "cuda")
         if (self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1 and self.Cin >= 8
                 and (stride == 1 or (stride == 2 and self.Cin % 8 == 0))):
             # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]; a Cin that is not a multiple of 8
@@ -237,6 +269,16 @@ class ConvPlan:
             _call("rfx_conv2d_dilated_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift),
                   _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad, self.dilation,
                   self.act if act is None else act)
+            return out
+        if self.wS is not None:
+            e0 = Profiler.begin(x)
+            _call("rfx_conv1x1_split_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
+                  N, C, H * W, self.Cout, self.act if act is None else act)
+            if e0 is not None:
+                e1 = Profiler.end(e0)
+                Profiler.active().conv.append((KID_SPLIT_1X1 | (2 if self.Cout > 64 else 1), 2.0 * N * H * W * self.Cout * self.Cin, e0, e1,
+                                               (N, self.Cin, H, W, self.Cout, 1, 1),
+                                               4.0 * (N * C * H * W + N * self.Cout * H * W * (2 if res is not None else 1)) + 6.0 * self.Cout * self.Cin))
             return out
         kid0 = 0
         if self.wP is not None:

@@ -951,3 +951,44 @@ def test_fused_bottleneck_tail_equals_two_convs(dev, case):
         assert not torch.equal(mid[:n2], chain) and e_chunk < e_chain
     else:
         assert torch.equal(mid[:n2], chain)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 256, 1024, 20, 28, True, "relu"), (2, 1024, 256, 25, 33, False, "relu"), (1, 128, 64, 9, 11, False, "none"),
+                                   (2, 64, 200, 16, 16, True, "relu"), (1, 32, 24, 5, 5, False, "sigmoid"), (5, 512, 128, 30, 40, False, "relu")])
+def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, shape):
+    """rfx_conv1x1_split_f32 (csrc/conv1x1s.hip): float32 sums from the three exact bf16 pieces of both operands on the bf16 matrix
+    cores.  Every product is exact, the accumulators round once per 16 k: against a float64 convolution its rms error is not larger
+    than the fp32-MFMA kernel's (it is 0.45-0.7x), and both agree to float32 round-off.  Shapes: full / ragged pixel tiles, 64- and
+    128-channel tiles, a Cout that fills neither, every activation, with and without residual."""
+    N, Cin, Cout, H, W, has_res, act = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cout) ** 0.5
+    bn = dict(weight=1.0 + 0.2 * (torch.rand(Cout, generator=g) - 0.5), bias=0.1 * torch.randn(Cout, generator=g),
+              running_mean=0.1 * torch.randn(Cout, generator=g), running_var=1.0 + 0.4 * (torch.rand(Cout, generator=g) - 0.5))
+    a = dict(relu=ops.ACT_RELU, none=ops.ACT_NONE, sigmoid=ops.ACT_SIGMOID)[act]
+    p32 = ops.ConvPlan(w, bn, 1, 0, a, dev)
+    psp = ops.ConvPlan(w, bn, 1, 0, a, dev, split=True)
+    assert psp.wS is not None and p32.wS is None
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
+    res = torch.randn(N, Cout, H, W, generator=g).to(dev) if has_res else None
+    y64 = torch.einsum("mk,nkhw->nmhw", w.view(Cout, Cin).double().to(dev), x.double())
+    y64 = y64 * p32.scale.double().view(1, -1, 1, 1) + p32.shift.double().view(1, -1, 1, 1)
+    if has_res:
+        y64 = y64 + res.double()
+    y64 = torch.relu(y64) if act == "relu" else (torch.sigmoid(y64) if act == "sigmoid" else y64)
+    y32, ysp = p32(x, residual=res), psp(x, residual=res)
+    rms = float(y64.pow(2).mean().sqrt())
+    e32 = float((y32.double() - y64).pow(2).mean().sqrt()) / rms
+    esp = float((ysp.double() - y64).pow(2).mean().sqrt()) / rms
+    assert esp <= 1.05 * e32 + 1e-9, (esp, e32)
+    assert esp < 3e-7 and float((ysp - y32).abs().max()) / rms < 2e-5
+    # the pieces are exact: hi + mid + lo == w
+    pc = psp.wS.view(torch.bfloat16).float().cpu()
+    Mpad = (Cout + 127) // 128 * 128
+    back = pc.view(Cin // 16, 3, 2, Mpad, 8).permute(1, 3, 0, 2, 4).reshape(3, Mpad, Cin).double().sum(0)[:Cout]
+    assert torch.equal(back.float(), w.view(Cout, Cin))
+    # grouped launches record the same kernel
+    with ops.launch_group(dev, False):
+        yg = psp(x, residual=res)
+    assert torch.equal(yg, ysp)

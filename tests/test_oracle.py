@@ -893,3 +893,20 @@ def test_kernel_resources_are_what_design_says():
     assert set(committed) == set(by)
     for k, r in by.items():
         assert all(str(r[c]) == committed[k][c] for c in ("wg", "vgpr", "lds", "scratch", "wg_per_cu", "k_loop_scratch")), (k, r, committed[k])
+
+
+def test_split_weights_are_exact_bf16_pieces_in_fragment_order():
+    """ops.split_weights (the host half of rfx_conv1x1_split_f32 / rfx_conv3x3_split_f32): hi + mid + lo == w exactly for every
+    float32 weight, each piece on the bf16 grid, packed [k / 16][piece][(k % 16) / 8][m (Mpad)][k % 8] with zero rows past Cout."""
+    from rfx import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(70, 48, generator=g) * torch.logspace(-6, 3, 48)[None, :]
+    ws = ops.split_weights(w)
+    assert ws.dtype == torch.int16 and tuple(ws.shape) == (3, 3, 2, 128, 8)
+    pc = ws.view(torch.bfloat16).float()
+    for kb in range(3):
+        for h in range(2):
+            blk = pc[kb, :, h, :70, :]                                        # (piece, m, 8)
+            assert torch.equal(blk.double().sum(0).float(), w[:, 16 * kb + 8 * h:16 * kb + 8 * h + 8])
+            assert torch.equal(blk[0], w[:, 16 * kb + 8 * h:16 * kb + 8 * h + 8].bfloat16().float())
+    assert float(pc[:, :, :, 70:, :].abs().max()) == 0.0
