@@ -511,6 +511,13 @@ int rfx_multih_accept_f32(const float* match, float* mask, const float* bg, cons
  * ------------------------------------------------------------------------------------------ */
 int rfx_conv1x1_split_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
                           float* out, int N, int Cin, int HW, int Cout, int act, void* stream);
+/* rfx_conv3x3_split_f32 (ABI 10): the same scheme for the 3x3 / stride 1 / pad 1 convolution (ResNet-50 layer3 conv2,
+ * model/resnet50.py:75; the FeatureExtractor's BasicBlock convolutions, model/model.py:32-35; conv2 / conv3 of the NetFlowCoarse /
+ * NetMatchability stacks, model/model.py:170-181): nine shifted 1x1 products over one staged, split halo patch.  Cin % 16 == 0.
+ * wS3: bf16 bit patterns, [kb = c / 16][tap = kh * 3 + kw][piece][h = (c % 16) / 8][m (Mpad)][c % 8] = piece of W[m][c][kh][kw].
+ * in (N,Cin,H,W), out / residual (N,Cout,H,W) float32.  NOT bit-identical to rfx_conv3x3_f32 / rfx_conv2d_f32 (closer to the exact sum). */
+int rfx_conv3x3_split_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
+                          float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sky segmentation forward pass: SegNet.getSky (segNet/segEval.py:23-43) = ResNet-50-dilated encoder

@@ -1,0 +1,280 @@
+// conv3x3s.hip -- 3x3 / stride 1 / pad 1 convolution (+ folded BatchNorm, residual, ReLU) with float32 results on the bf16 matrix
+// cores by EXACT operand splitting -- the scheme of conv1x1s.hip (read its header first) applied to the heaviest layer class of the
+// path: ResNet-50 layer3 conv2 (model/resnet50.py:75), every BasicBlock convolution of the FeatureExtractor (model/model.py:32-35),
+// conv2 / conv3 of the NetFlowCoarse / NetMatchability stacks (model/model.py:170-181).
+//
+//     out[m][p] = sum over taps (kh, kw) and channels c of  W[m][c][kh][kw] * in[c][p + (kh-1, kw-1)]
+// = nine shifted 1x1 GEMMs over ONE staged input patch.  A workgroup owns 64*TM output channels x an 8 x 16 pixel patch; per block of
+// 16 input channels it stages the 10 x 18 halo patch ONCE -- float32 from HBM, split into the three bf16 pieces, LDS image
+//     Bs[piece][h = channel half][patch pixel (180)][8 channels]        (16-byte words; zero outside the image = the padding)
+// so that the B fragment of tap (kh, kw) for output pixel (r, x) is the word at patch pixel (r + kh) * 18 + x + kw: one ds_read_b128
+// at a per-lane base + a compile-time tap offset.  The weights of a (channel block, tap) stage come split and packed from the host
+// (rfx_api.h: "wS3"), 12 KB per stage, LDS double buffered, one barrier per stage; a stage = 6 MFMAs per 32 x 32 tile (hi*hi in its
+// own accumulator, the five small terms in a second one: conv1x1s.hip).  k order: channel block, tap, 16 channels -- irrelevant for
+// the result's quality (every product exact, 16 products per rounding), different from the fp32 kernels' channel-major order.
+// The images of a batch are tiled as ONE tall map with a virtual zero row between images (as conv3x3.hip): only the last patch row
+// of the whole batch is ragged; outputs on a virtual row are dropped.
+#include "common.h"
+#include "conv_epilogue.h"
+#include "group.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PT_R = 8, PT_C = 16, PR = PT_R + 2, PC = PT_C + 2, PP = PR * PC;     // 8 x 16 outputs, 10 x 18 = 180 patch pixels
+
+struct C3SArgs {
+    const float* in; const u32x4* wS; const float* scale; const float* shift; const float* res; float* out;
+    int N, Cin, H, W, Cout, act, Mpad;
+    int tilesM, tilesW, tilesS;     // channel tiles, column tiles, row tiles of the N * (H + 1) - 1 row stack
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pack_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);            // exact
+    mid = pack_bf16(ra, rb);
+    lo = pack_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+}
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& w) {
+    bf16x8 f;
+    __builtin_memcpy(&f, &w, 16);
+    return f;
+}
+
+template <int TM>
+__device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsigned bx) {
+    constexpr int BM = 64 * TM;
+    constexpr int A_WORDS = 3 * 2 * BM;                 // 16-byte words of a stage's weight image
+    constexpr int NA = (A_WORDS + 255) / 256;
+    constexpr int B_ITEMS = 2 * PP;                     // (h, patch pixel) staging items: 360 -> threads 0..255 take one, 0..103 a second
+    __shared__ u32x4 As[2][3][2][BM];
+    __shared__ u32x4 Bs[2][3][2][PP];
+    __shared__ float s_scale[BM], s_shift[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const size_t HW = (size_t)a.H * a.W;
+    const int nwg = a.tilesM * a.tilesW * a.tilesS;
+    const int nk = a.Cin / 16;
+    const int Hs = a.H + 1;                             // rows per image in the stack (the last one virtual)
+
+    int m0, row0, col0;
+    {
+        const int v = (int)bx, q = nwg / 8, r = nwg % 8, xcd = v % 8, j = v / 8;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        m0 = (bid % a.tilesM) * BM; bid /= a.tilesM;
+        col0 = (bid % a.tilesW) * PT_C;
+        row0 = (bid / a.tilesW) * PT_R;
+    }
+    // A staging: words t + 256 j of the stage image [piece][h][BM] <- wS[(kb * 9 + tap)][piece][h][m0 + m]; 256 words = 2 (TM = 2) or
+    // 4 (TM = 1) [piece][h] rows: word t + 256 j sits (256 / BM) * j rows below word t
+    constexpr int A_ROWS = 256 / BM;
+    const u32x4* wsrc = a.wS + (size_t)(t / BM) * a.Mpad + m0 + t % BM;              // + q * 6 * Mpad + A_ROWS * j * Mpad
+    bool a_on[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a_on[j] = t + 256 * j < A_WORDS;
+    // B staging: item it = t (+ 256): h = it / 180, patch pixel it % 180 -> 8 channels of one input pixel (or zeros)
+    const float* bsrc[2];
+    bool b_ok[2], b_on[2];
+    int b_word[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int it = t + 256 * u;
+        b_on[u] = it < B_ITEMS;
+        const int h = (b_on[u] ? it : 0) / PP, pp = (b_on[u] ? it : 0) % PP;
+        const int pr = pp / PC, pc = pp % PC;
+        const int sr = row0 - 1 + pr, x = col0 - 1 + pc;
+        const int n = sr >= 0 ? sr / Hs : 0, y = sr >= 0 ? sr - n * Hs : 0;
+        b_ok[u] = b_on[u] && sr >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
+        bsrc[u] = b_ok[u] ? a.in + ((size_t)n * a.Cin + 8 * h) * HW + (size_t)y * a.W + x : a.in;   // + kb * 16 * HW + i * HW
+        b_word[u] = h * PP + pp;
+    }
+    u32x4 ra[NA];
+    float rb[8];                                        // one staging item at a time: item 0 and item 1 of a block share the registers
+    auto load_a = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (a_on[j]) ra[j] = wsrc[((size_t)q * 6 + A_ROWS * j) * a.Mpad];
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (a_on[j]) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
+    };
+    auto load_b = [&](int kb, int u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = b_ok[u] ? bsrc[u][((size_t)kb * 16 + i) * HW] : 0.0f;
+    };
+    auto store_b = [&](int buf, int u) {
+        if (!b_on[u]) return;
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned h_, m_, l_;
+            split_pair(rb[2 * i], rb[2 * i + 1], h_, m_, l_);
+            hi[i] = h_; mid[i] = m_; lo[i] = l_;
+        }
+        u32x4* dst = &Bs[buf][0][0][0] + b_word[u];
+        dst[0] = hi;
+        dst[2 * PP] = mid;
+        dst[4 * PP] = lo;
+    };
+    if (t < BM) {
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0, 0);
+    load_b(0, 1);
+    store_b(0, 1);
+    load_a(1);
+    if (nk > 1) load_b(1, 0);
+    __syncthreads();
+
+    f32x16 acc[TM][2], low[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; low[i][j][r] = 0.0f; }
+
+    // per-lane fragment bases (16-byte words): A row, B patch pixel of output (4 wn + 2 j + lcol / 16, lcol % 16) at tap (0, 0)
+    const int a_base = lrow * BM + wm * TM * 32 + lcol;
+    int b_base[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_base[j] = lrow * PP + (4 * wn + 2 * j + (lcol >> 4)) * PC + (lcol & 15);
+    const int nq = 9 * nk;
+
+    for (int kb = 0; kb < nk; ++kb) {
+        const u32x4* bimg = &Bs[kb & 1][0][0][0];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = kb * 9 + tap;
+            const u32x4* aimg = &As[q & 1][0][0][0];
+            const int toff = (tap / 3) * PC + tap % 3;
+            // the next block's patch: item 0 was loaded at tap 8 of the block before (prologue: block 1), goes to LDS at tap 3; item 1
+            // is loaded behind it and stored at tap 7; the buffer's last readers finished with block kb - 1
+            bf16x8 a0[TM], a1[TM], b0[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = as_frag(aimg[a_base + i * 32]);
+                a1[i] = as_frag(aimg[2 * BM + a_base + i * 32]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b0[j] = as_frag(bimg[b_base[j] + toff]);
+                b1[j] = as_frag(bimg[2 * PP + b_base[j] + toff]);
+            }
+            if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
+            if (q + 2 < nq) load_a(q + 2);
+            if (kb + 1 < nk) {
+                if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
+                if (tap == 7) store_b((kb + 1) & 1, 1);
+            }
+            if (tap == 8 && kb + 2 < nk) load_b(kb + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // hi / mid pieces first (four of the six products), then the lo pieces take the mid pieces' registers
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], low[i][j], 0, 0, 0);    // mid * mid
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], low[i][j], 0, 0, 0);    // mid * hi
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * mid
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);    // hi  * hi
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * PP + b_base[j] + toff]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], low[i][j], 0, 0, 0);    // lo  * hi
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += low[i][j][r];
+
+    size_t pix_off[2];
+    bool pix_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sr = row0 + 4 * wn + 2 * j + (lcol >> 4), x = col0 + (lcol & 15);
+        const int n = sr / Hs, y = sr - n * Hs;
+        pix_ok[j] = n < a.N && y < a.H && x < a.W;
+        pix_off[j] = pix_ok[j] ? (size_t)n * a.Cout * HW + (size_t)y * a.W + x : 0;
+    }
+    conv_epilogue<TM, 2, false>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+}
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3SArgs a) {
+    conv3x3_split_body<TM>(a, blockIdx.x);
+}
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv3x3_split_group_kernel(RfxGroupArgs<C3SArgs> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv3x3_split_body<TM>(g.p[y], blockIdx.x);
+}
+
+template <int TM>
+static int c3s_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<C3SArgs>(conv3x3_split_group_kernel<TM>, 256, blob, gx, n, st);
+}
+
+template <int TM>
+int launch_split3(C3SArgs& a, hipStream_t st) {
+    a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
+    a.tilesW = (a.W + PT_C - 1) / PT_C;
+    const long long rows = (long long)a.N * (a.H + 1) - 1;
+    a.tilesS = (int)((rows + PT_R - 1) / PT_R);
+    const long long nwg = (long long)a.tilesM * a.tilesW * a.tilesS;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    if (rfx_group_recording()) return rfx_group_record(&c3s_group_launch<TM>, &a, sizeof(a), (unsigned)nwg);
+    hipLaunchKernelGGL((conv3x3_split_kernel<TM>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
+}
+
+}  // namespace
+
+extern "C" int rfx_conv3x3_split_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
+                                     float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream) {
+    if (!in || !wS3 || !out || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (Cin % 16 != 0) return RFX_E_ARG;
+    if (act != RFX_ACT_NONE && act != RFX_ACT_RELU && act != RFX_ACT_SIGMOID) return RFX_E_ARG;
+    if ((long long)N * (H + 1) > 0x7fffffffLL) return RFX_E_LIMIT;
+    C3SArgs a;
+    a.in = in; a.wS = reinterpret_cast<const u32x4*>(wS3); a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = (Cout + 127) / 128 * 128;
+    return Cout > 64 ? launch_split3<2>(a, rfx_stream(stream)) : launch_split3<1>(a, rfx_stream(stream));
+}

@@ -28,7 +28,7 @@ class ResNet50Trunk:
                 s = stride if b == 0 else 1
                 # split=True (round 6): the long-K 1x1 layers -- conv1 of every block but the first (K = 256 ... 1024) and layer3's
                 # conv3 (K = 256, + residual) -- run on rfx_conv1x1_split_f32: float32 sums from exact bf16 operand pieces, closer to
-                # the exact sum than the fp32-MFMA kernel and 1.3-1.5x faster (profiles/r06_split_1x1_bench.json).  The conv3 of a
+                # the exact sum than the fp32-MFMA kernel and 1.3-1.5x faster (profiles/r06_split_conv_bench.json).  The conv3 of a
                 # block whose tail can fuse (layer1 / layer2) stays on the fp32 kernels: fused and two-kernel forms stay bit-identical.
                 w1 = sd[p + ".conv1.weight"]
                 blk = {
@@ -39,6 +39,8 @@ class ResNet50Trunk:
                 }
                 if not ops.bottleneck_tail_shape(blk["c2"], blk["c3"]):
                     blk["c3"] = ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device, split=True)
+                    if s == 1:   # layer3's 256 -> 256 3x3 (K = 2304): rfx_conv3x3_split_f32
+                        blk["c2"] = ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device, split=True)
                 if (p + ".downsample.0.weight") in sd:
                     blk["ds"] = ConvPlan(sd[p + ".downsample.0.weight"], _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE,
                                          device)
@@ -98,8 +100,9 @@ class FeatureExtractorNet:
                 p = "%s.%d" % (layer, b)
                 s = stride if b == 0 else 1
                 blk = {
-                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), s, 1, ACT_RELU, device),
-                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), 1, 1, ACT_RELU, device),
+                    # the stride-1 3x3 convolutions (64 / 128 / 256 channels): rfx_conv3x3_split_f32 (round 6; csrc/conv3x3s.hip)
+                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), s, 1, ACT_RELU, device, split=s == 1),
+                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), 1, 1, ACT_RELU, device, split=True),
                     "ds": None, "stride": s,
                 }
                 if (p + ".downsample.1.weight") in sd:
@@ -119,8 +122,8 @@ class FeatureExtractorNet:
 class _HeadTrunk:
     def __init__(self, sd, last_act, device):
         self.c1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), 1, 1, ACT_RELU, device)
-        self.c2 = ConvPlan(sd["conv2.weight"], _bn(sd, "bn2"), 1, 1, ACT_RELU, device)
-        self.c3 = ConvPlan(sd["conv3.weight"], _bn(sd, "bn3"), 1, 1, ACT_RELU, device)
+        self.c2 = ConvPlan(sd["conv2.weight"], _bn(sd, "bn2"), 1, 1, ACT_RELU, device, split=True)      # 512 -> 256, 256 -> 128:
+        self.c3 = ConvPlan(sd["conv3.weight"], _bn(sd, "bn3"), 1, 1, ACT_RELU, device, split=True)      # rfx_conv3x3_split_f32
         self.c4 = ConvPlan(sd["conv4.weight"], None, 1, 1, last_act, device)
 
     def __call__(self, coef):

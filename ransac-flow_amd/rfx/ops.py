@@ -158,6 +158,7 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+KID_SPLIT_3X3 = 65536      # ... of rfx_conv3x3_split_f32
 KID_SPLIT_1X1 = 32768      # Profiler kernel id of rfx_conv1x1_split_f32 (| 1: 64-channel tiles, | 2: 128-channel tiles)
 
 
@@ -212,6 +213,10 @@ class ConvPlan:
         if (split and conv_split_enabled() and self.KH == 1 and self.KW == 1 and stride == 1 and pad == 0 and self.dilation == 1
                 and self.Cin % 16 == 0):
             self.wS = split_weights(w.reshape(self.Cout, K)).to(device or "cuda")
+        elif (split and conv_split_enabled() and self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.dilation == 1
+                and self.Cin % 16 == 0):
+            # rfx_conv3x3_split_f32's wS3: [c / 16][tap][piece][h][m][8]
+            self.wS = torch.stack([split_weights(w[:, :, kh, kw]) for kh in range(3) for kw in range(3)], dim=1).contiguous().to(device or "cuda")
         if (self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1 and self.Cin >= 8
                 and (stride == 1 or (stride == 2 and self.Cin % 8 == 0))):
             # rfx_conv3x3_f32's order: wP[mt][s][h][m][kk] = W[mt*128 + m][s*72 + 2*kk + h]; a Cin that is not a multiple of 8
@@ -269,6 +274,16 @@ class ConvPlan:
             _call("rfx_conv2d_dilated_f32", _one_device(x, res, self.wT), _p(x), _p(self.wT), _p(self.ktab), _p(self.scale), _p(self.shift),
                   _p(res), _p(out), N, C, H, W, self.Cout, self.KH, self.KW, self.stride, self.pad, self.dilation,
                   self.act if act is None else act)
+            return out
+        if self.wS is not None and self.KH == 3:
+            e0 = Profiler.begin(x)
+            _call("rfx_conv3x3_split_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
+                  N, C, H, W, self.Cout, self.act if act is None else act)
+            if e0 is not None:
+                e1 = Profiler.end(e0)
+                Profiler.active().conv.append((KID_SPLIT_3X3 | (2 if self.Cout > 64 else 1), 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1,
+                                               (N, self.Cin, H, W, self.Cout, 3, 1),
+                                               4.0 * (N * C * H * W + N * self.Cout * H * W * (2 if res is not None else 1)) + 54.0 * self.Cout * self.Cin))
             return out
         if self.wS is not None:
             e0 = Profiler.begin(x)

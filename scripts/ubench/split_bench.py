@@ -13,7 +13,11 @@ import torch  # noqa: E402
 from rfx import ops  # noqa: E402
 from rfx.ops import ConvPlan, ACT_RELU  # noqa: E402
 
-SHAPES = [  # (Cin, Cout, H, W, residual)
+SHAPES3 = [  # 3x3 / stride 1 / pad 1: (Cin, Cout, H, W, residual)
+    (256, 256, 60, 80, False), (512, 256, 60, 80, False), (256, 128, 60, 80, False), (64, 64, 240, 320, True), (128, 128, 120, 160, True),
+    (256, 256, 30, 40, True), (256, 256, 50, 66, False), (256, 256, 25, 33, False), (64, 64, 200, 264, False),
+]
+SHAPES = [  # 1x1: (Cin, Cout, H, W, residual)
     (256, 1024, 60, 80, True), (1024, 256, 60, 80, False), (512, 128, 120, 160, False), (256, 64, 240, 320, False),
     (64, 256, 240, 320, False), (1024, 256, 50, 66, False), (256, 1024, 50, 66, True), (1024, 256, 25, 33, False), (256, 1024, 25, 33, True),
 ]
@@ -38,20 +42,21 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    ap_k = [(3, sh) for sh in SHAPES3] + [(1, sh) for sh in SHAPES]
     rows = []
-    for (Cin, Cout, H, W, has_res) in SHAPES:
+    for ksz, (Cin, Cout, H, W, has_res) in ap_k:
         g = torch.Generator().manual_seed(Cin + Cout + H)
-        w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cout) ** 0.5
+        w = torch.randn(Cout, Cin, ksz, ksz, generator=g) * (2.0 / (Cout * ksz * ksz)) ** 0.5
         bn = dict(weight=1.0 + 0.2 * (torch.rand(Cout, generator=g) - 0.5), bias=0.1 * torch.randn(Cout, generator=g),
                   running_mean=0.1 * torch.randn(Cout, generator=g), running_var=1.0 + 0.4 * (torch.rand(Cout, generator=g) - 0.5))
-        p32 = ConvPlan(w, bn, 1, 0, ACT_RELU, dev)
-        psp = ConvPlan(w, bn, 1, 0, ACT_RELU, dev, split=True)
+        p32 = ConvPlan(w, bn, 1, ksz // 2, ACT_RELU, dev)
+        psp = ConvPlan(w, bn, 1, ksz // 2, ACT_RELU, dev, split=True)
         assert psp.wS is not None
         x = torch.relu(torch.randn(a.n, Cin, H, W, generator=g)).to(dev)
         res = torch.randn(a.n, Cout, H, W, generator=g).to(dev) if has_res else None
         # float64 reference on 2 images
         xs, rs = x[:2], (res[:2] if has_res else None)
-        s64 = torch.einsum("mk,nkhw->nmhw", w.view(Cout, Cin).double().to(dev), xs.double())
+        s64 = torch.nn.functional.conv2d(xs.double(), w.double().to(dev), padding=ksz // 2)
         y64 = s64 * p32.scale.double().view(1, -1, 1, 1) + p32.shift.double().view(1, -1, 1, 1)
         if has_res:
             y64 = y64 + rs.double()
@@ -61,8 +66,8 @@ def main():
         esp = (psp(xs, residual=rs).double() - y64)
         ms32 = timed(lambda: p32(x, residual=res), a.iters)
         mssp = timed(lambda: psp(x, residual=res), a.iters)
-        fl = 2.0 * a.n * H * W * Cin * Cout
-        row = dict(Cin=Cin, Cout=Cout, H=H, W=W, N=a.n, residual=has_res,
+        fl = 2.0 * a.n * H * W * Cin * Cout * ksz * ksz
+        row = dict(k=ksz, Cin=Cin, Cout=Cout, H=H, W=W, N=a.n, residual=has_res,
                    fp32_ms=round(ms32, 3), split_ms=round(mssp, 3), speedup=round(ms32 / mssp, 3),
                    fp32_tflops=round(fl / ms32 / 1e9, 1), split_tflops_equiv=round(fl / mssp / 1e9, 1),
                    fp32_rms_err=float(e32.pow(2).mean().sqrt()) / rms, split_rms_err=float(esp.pow(2).mean().sqrt()) / rms,
