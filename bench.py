@@ -480,8 +480,20 @@ def timed_loop(step, args, dist, sync, prof_factory):
     return elapsed, out, prof
 
 
+SPLIT_PRODUCTS = 6            # bf16 MFMA products per float32 product in the split kernels (csrc/conv1x1s.hip, conv3x3s.hip)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 matrix peak (MI355X_MICROARCH.md)
+
+
+def is_split(kid):
+    return bool(kid & (32768 | 65536))
+
+
 def kernel_name(kid):
     tf = lambda b: "true" if b else "false"
+    if kid & 65536:        # float32 3x3 on the bf16 matrix cores by exact operand splitting (conv3x3s.hip)
+        return "conv3x3_split_kernel<%d>" % (1 if kid & 1 else 2)
+    if kid & 32768:        # ... 1x1 (conv1x1s.hip); 4: strided pixels (the projection shortcuts)
+        return "conv1x1_split_kernel<%d>" % (1 if kid & 1 else 2)
     if kid & (32 | 512):   # direct 3x3 kernel; 512 = fused with the 1x1 expansion (Bottleneck tail); 16384 = chunked accumulation (KCH = 4)
         return "conv3x3_direct_kernel<%d, %d, %s, %d, %s, %d>" % (1 if kid & 3 else 2, 4 if kid & 128 else (8 if kid & 64 else 16), tf(kid & 512),
                                                                    4 if kid & 2048 else 2, tf(kid & 4096), 4 if kid & 16384 else 0)
@@ -555,14 +567,26 @@ def rooflines(prof, elapsed, rank, cfg="3", dev=None):
     n, f, t, b = by[dom]
     tot_f, tot_t = sum(g[1] for g in by.values()), sum(g[2] for g in by.values())
     ach = f / t / 1e12
-    roof = {"kernel": kernel_name(dom), "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+    # peak of the dominant kernel: an fp32-MFMA kernel is bounded by the fp32 matrix peak; a split kernel executes SPLIT_PRODUCTS bf16
+    # products per float32 product on the bf16 matrix cores, so ITS ceiling in algorithmic (float32) FLOP/s is the dense bf16 peak / 6
+    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS if is_split(dom) else PEAK_F32_MFMA_TFLOPS
+    roof = {"kernel": kernel_name(dom), "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None,
             "traffic_note": "not measured inside the bench (rocprofv3 cannot wrap itself): the per-launch FETCH_SIZE / WRITE_SIZE "
                             "of this kernel from separate --pmc passes of this command are committed in profiles/ (static)",
             "launches": n, "avg_launch_us": round(t / n * 1e6, 2), "flop_per_launch": f / n, "algorithmic_bytes_per_launch": round(b / n),
             "time_share": round(t / elapsed, 3), "all_conv_tflops": round(tot_f / tot_t / 1e12, 2), "conv_time_share": round(tot_t / elapsed, 3),
             "conv_kernels": {("%d" % k): {"launches": g[0], "tflops": round(g[1] / g[2] / 1e12, 1), "time_share": round(g[2] / elapsed, 3)}
                              for k, g in sorted(by.items())}}
+    if is_split(dom):
+        roof["peak_note"] = ("algorithmic float32 FLOP/s; the kernel computes every float32 product as %d exact bf16 x bf16 products on the bf16 "
+                             "matrix cores (float32 = hi + mid + lo bf16 pieces, csrc/conv3x3s.hip), so its ceiling is the dense bf16 peak "
+                             "%.0f / %d = %.1f TFLOP/s; executed bf16 matrix FLOP/s = %d x achieved; against the fp32 matrix peak (%.1f TFLOP/s, "
+                             "the bound of the fp32-MFMA kernel it replaced at 0.80) it stands at %.2f"
+                             % (SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS, peak, SPLIT_PRODUCTS, PEAK_F32_MFMA_TFLOPS,
+                                ach / PEAK_F32_MFMA_TFLOPS))
+        roof["executed_bf16_tflops"] = round(ach * SPLIT_PRODUCTS, 1)
+        roof["vs_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
     tr, src = pmc_traffic(roof["kernel"], cfg)
     if tr is not None:
         roof["traffic"] = round(tr)
@@ -733,6 +757,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": dict({k: v for k, v in meta.items() if k != "col"}, config=args.config, baseline_config=names.get(args.config, "dry run"),
                            pairs_per_step_per_gpu=B, weights="random-init",
+                           arithmetic=("float32 in and out of every kernel; convolution sums: fp32 matrix cores (v_mfma_f32_32x32x2_f32) or, for the "
+                                       "long-K 1x1 and the stride-1 3x3 layers, float32 = hi + mid + lo bf16 pieces (exact) multiplied on the bf16 "
+                                       "matrix cores (every product exact, float32 accumulators) -- error against float64 not larger than the "
+                                       "fp32 kernels'; extra.fp32_mfma_only = the same workload with RFX_CONV_SPLIT=0"
+                                       if os.environ.get("RFX_CONV_SPLIT", "1") != "0" else "float32, fp32 matrix cores only (RFX_CONV_SPLIT=0)"),
                            parallelism="pairs sharded over %d rank(s) (pair i -> rank i mod N), one all_gather of result records per step" % world,
                            gathered_records=int(out.shape[0]), record_bytes_per_pair=int(out.shape[1]) * 4, aligned_ok_last_step=ok_pairs,
                            ranks_seen_in_gather=sorted(set(int(x) for x in out[:, col["rank"]].tolist())),
@@ -827,6 +856,30 @@ def main():
                           "mode (no host stage); host_draw_lapack = torch.randint on the CPU generator per pair and round: the mode `parity` is "
                           "measured in (one lock-step group, a second sync per round)")
             extras["exact_mode"] = ex
+            # ---- every convolution on the fp32-MFMA kernels (RFX_CONV_SPLIT=0: no bf16-piece kernels, fused Bottleneck tails): the
+            # figure to read if one does not accept float32 sums formed from exact bf16 operand pieces as float32 arithmetic
+            prev = os.environ.get("RFX_CONV_SPLIT")
+            os.environ["RFX_CONV_SPLIT"] = "0"
+            try:
+                af = argparse.Namespace(**vars(args))
+                af.steps, af.warmup = 5, 1
+                stepf, _, extraf = build_workload(af, dev, rank, world, score_chunk=score_chunk)
+                torch.manual_seed(123)
+                ef, outf, _ = timed_loop(stepf, af, None, sync, _NoProf)
+                extras["fp32_mfma_only"] = {"pairs_per_s": round(B * af.steps / ef, 3), "ms_per_step": round(ef / af.steps * 1e3, 2), "steps": af.steps,
+                                            "vs_value": round((B * af.steps / ef) / line["value"], 4),
+                                            "aligned_ok_last_step": int((outf[:, col["status"]] == 0).sum().item()),
+                                            "note": "RFX_CONV_SPLIT=0: the same workload with every convolution on the fp32 matrix-core kernels "
+                                                    "(v_mfma_f32_32x32x2_f32) of rounds 1-5; `value` runs the long-K 1x1 and the stride-1 3x3 layers "
+                                                    "on rfx_conv1x1_split_f32 / rfx_conv3x3_split_f32 (float32 results from exact bf16 operand pieces; "
+                                                    "error against float64 not larger than the fp32 kernels': profiles/r06_split_conv_bench.json)"}
+                del stepf, extraf
+                torch.cuda.empty_cache()
+            finally:
+                if prev is None:
+                    os.environ.pop("RFX_CONV_SPLIT", None)
+                else:
+                    os.environ["RFX_CONV_SPLIT"] = prev
             log("exact-mode leg done: %s" % {k: v["pairs_per_s"] for k, v in ex.items() if isinstance(v, dict) and "pairs_per_s" in v})
         # ---- CPU legs: bounded oracle baseline, then the parity sweeps over pairs of the timed batches ----
         if not args.no_cpu_baseline:

@@ -511,6 +511,10 @@ int rfx_multih_accept_f32(const float* match, float* mask, const float* bg, cons
  * ------------------------------------------------------------------------------------------ */
 int rfx_conv1x1_split_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
                           float* out, int N, int Cin, int HW, int Cout, int act, void* stream);
+/* ... with a stride (1 or 2; pad 0): the projection shortcuts of the trunk (model/resnet50.py:139-143): out (N,Cout,Ho,Wo),
+ * Ho = (Hin - 1) / stride + 1, reads input pixel (y * stride, x * stride). */
+int rfx_conv1x1_split_strided_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
+                                  float* out, int N, int Cin, int Hin, int Win, int Cout, int stride, int act, void* stream);
 /* rfx_conv3x3_split_f32 (ABI 10): the same scheme for the 3x3 / stride 1 / pad 1 convolution (ResNet-50 layer3 conv2,
  * model/resnet50.py:75; the FeatureExtractor's BasicBlock convolutions, model/model.py:32-35; conv2 / conv3 of the NetFlowCoarse /
  * NetMatchability stacks, model/model.py:170-181): nine shifted 1x1 products over one staged, split halo patch.  Cin % 16 == 0.

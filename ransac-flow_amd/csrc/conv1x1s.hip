@@ -36,9 +36,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct C1SArgs {
     const float* in; const u32x4* wS; const float* scale; const float* shift; const float* res; float* out;
-    int Cin, HW, Cout, act, Mpad;
+    int Cin, HW, Cout, act, Mpad;      // HW: OUTPUT pixels per image
     long long P;   // N*HW
     int tilesM, tilesP;
+    int stride, Win, Wo, HWin;         // stride 2 (the projection shortcuts, model/resnet50.py:139-143): input pixel (2y, 2x) of a Win-wide map
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // (bf16(a) | bf16(b) << 16), round to nearest even: v_cvt_pk_bf16_f32
@@ -73,7 +74,7 @@ __device__ __forceinline__ void conv1x1_split_body(const C1SArgs& a, const unsig
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
-    const size_t HW = (size_t)a.HW;
+    const size_t HW = (size_t)a.HW, HWin = (size_t)a.HWin;
     const int nwg = a.tilesM * a.tilesP;
     const int nk = a.Cin / KB;
 
@@ -102,7 +103,9 @@ __device__ __forceinline__ void conv1x1_split_body(const C1SArgs& a, const unsig
         long long p = n0 + bp;
         if (p >= a.P) p = a.P - 1;                                                  // columns past the end: any valid address
         const long long n = p / a.HW;
-        bsrc = a.in + (size_t)n * a.Cin * HW + (size_t)(p - n * a.HW) + (size_t)(8 * bh) * HW;    // + k0 * HW
+        int off = (int)(p - n * a.HW);
+        if (a.stride != 1) { const int y = off / a.Wo, x = off - y * a.Wo; off = y * a.stride * a.Win + x * a.stride; }
+        bsrc = a.in + ((size_t)n * a.Cin + 8 * bh) * HWin + (size_t)off;                          // + k0 * HWin
     }
     u32x4 ra[NA];
     float rb[8];
@@ -111,7 +114,7 @@ __device__ __forceinline__ void conv1x1_split_body(const C1SArgs& a, const unsig
         for (int j = 0; j < NA; ++j)
             if (a_on[j]) ra[j] = wsrc[j][(size_t)kb * 6 * a.Mpad];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = bsrc[(size_t)(kb * KB + i) * HW];
+        for (int i = 0; i < 8; ++i) rb[i] = bsrc[(size_t)(kb * KB + i) * HWin];
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
@@ -231,14 +234,26 @@ int launch_split(C1SArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int rfx_conv1x1_split_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
-                                     float* out, int N, int Cin, int HW, int Cout, int act, void* stream) {
-    if (!in || !wS || !out || N <= 0 || Cin <= 0 || HW <= 0 || Cout <= 0) return RFX_E_ARG;
-    if (Cin % 16 != 0) return RFX_E_ARG;
+static int conv1x1_split_launch(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
+                                float* out, int N, int Cin, int Hin, int Win, int Cout, int stride, int act, void* stream) {
+    if (!in || !wS || !out || N <= 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (Cin % 16 != 0 || (stride != 1 && stride != 2)) return RFX_E_ARG;
     if (act != RFX_ACT_NONE && act != RFX_ACT_RELU && act != RFX_ACT_SIGMOID) return RFX_E_ARG;
+    const int Ho = (Hin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
     C1SArgs a;
     a.in = in; a.wS = reinterpret_cast<const u32x4*>(wS); a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
-    a.Cin = Cin; a.HW = HW; a.Cout = Cout; a.act = act; a.Mpad = (Cout + 127) / 128 * 128;
-    a.P = (long long)N * HW;
+    a.Cin = Cin; a.HW = Ho * Wo; a.Cout = Cout; a.act = act; a.Mpad = (Cout + 127) / 128 * 128;
+    a.P = (long long)N * a.HW;
+    a.stride = stride; a.Win = Win; a.Wo = Wo; a.HWin = Hin * Win;
     return Cout > 64 ? launch_split<2>(a, rfx_stream(stream)) : launch_split<1>(a, rfx_stream(stream));
+}
+
+extern "C" int rfx_conv1x1_split_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
+                                     float* out, int N, int Cin, int HW, int Cout, int act, void* stream) {
+    return conv1x1_split_launch(in, wS, scale, shift, residual, out, N, Cin, 1, HW, Cout, 1, act, stream);
+}
+
+extern "C" int rfx_conv1x1_split_strided_f32(const float* in, const void* wS, const float* scale, const float* shift, const float* residual,
+                                             float* out, int N, int Cin, int Hin, int Win, int Cout, int stride, int act, void* stream) {
+    return conv1x1_split_launch(in, wS, scale, shift, residual, out, N, Cin, Hin, Win, Cout, stride, act, stream);
 }

@@ -4,6 +4,8 @@ Each class is built from a reference-keyed ``state_dict`` (see rfx/weights.py), 
 folds eval-mode BatchNorm once, and then runs forward-only on device tensors.  Activations stay NCHW fp32
 from the first layer to the last: there is no layout conversion between kernels.
 """
+import os
+
 import torch
 
 from . import ops
@@ -42,9 +44,15 @@ class ResNet50Trunk:
                     if s == 1:   # layer3's 256 -> 256 3x3 (K = 2304): rfx_conv3x3_split_f32
                         blk["c2"] = ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device, split=True)
                 if (p + ".downsample.0.weight") in sd:
-                    blk["ds"] = ConvPlan(sd[p + ".downsample.0.weight"], _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE,
-                                         device)
+                    wd = sd[p + ".downsample.0.weight"]       # the stride-2 projections (256 -> 512, 512 -> 1024): split kernel, strided pixels
+                    blk["ds"] = ConvPlan(wd, _bn(sd, p + ".downsample.1"), s, 0, ACT_NONE, device, split=wd.shape[1] >= 128)
                 if ops.bottleneck_tail_shape(blk["c2"], blk["c3"]):
+                    if ops.conv_split_enabled() and os.environ.get("RFX_SPLIT_TAILS", "1") != "0":
+                        # layer1 / layer2 tails (3x3 64 -> 64 / 128 -> 128, then the 1x1 expansion): two split kernels beat the fused fp32
+                        # kernel (the 3x3 runs 1.3-1.45x faster on the bf16 pipe; measured per block in profiles/r06_split_conv_bench.json)
+                        blk["c2"] = ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device, split=True)
+                        blk["c3"] = ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device,
+                                             split=blk["c3"].Cin >= 128)
                     # the tail's 3x3 (K = 576 / 1152) sums in chunks of 4 K steps -- in the fused kernel and, with this argument,
                     # in the stand-alone one (RFX_FUSE_BOTTLENECK=0): the two forms stay bit-identical
                     blk["c2"].k_chunk = 4

@@ -210,7 +210,7 @@ class ConvPlan:
         # split=True: a 1x1 / stride 1 convolution runs on rfx_conv1x1_split_f32 (float32 sums from exact bf16 operand pieces on the
         # bf16 matrix cores: csrc/conv1x1s.hip) where the shape allows it and RFX_CONV_SPLIT != 0
         self.wS = None
-        if (split and conv_split_enabled() and self.KH == 1 and self.KW == 1 and stride == 1 and pad == 0 and self.dilation == 1
+        if (split and conv_split_enabled() and self.KH == 1 and self.KW == 1 and stride in (1, 2) and pad == 0 and self.dilation == 1
                 and self.Cin % 16 == 0):
             self.wS = split_weights(w.reshape(self.Cout, K)).to(device or "cuda")
         elif (split and conv_split_enabled() and self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.dilation == 1
@@ -287,13 +287,17 @@ class ConvPlan:
             return out
         if self.wS is not None:
             e0 = Profiler.begin(x)
-            _call("rfx_conv1x1_split_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
-                  N, C, H * W, self.Cout, self.act if act is None else act)
+            if self.stride == 1:
+                _call("rfx_conv1x1_split_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
+                      N, C, H * W, self.Cout, self.act if act is None else act)
+            else:
+                _call("rfx_conv1x1_split_strided_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res),
+                      _p(out), N, C, H, W, self.Cout, self.stride, self.act if act is None else act)
             if e0 is not None:
                 e1 = Profiler.end(e0)
-                Profiler.active().conv.append((KID_SPLIT_1X1 | (2 if self.Cout > 64 else 1), 2.0 * N * H * W * self.Cout * self.Cin, e0, e1,
-                                               (N, self.Cin, H, W, self.Cout, 1, 1),
-                                               4.0 * (N * C * H * W + N * self.Cout * H * W * (2 if res is not None else 1)) + 6.0 * self.Cout * self.Cin))
+                Profiler.active().conv.append((KID_SPLIT_1X1 | (2 if self.Cout > 64 else 1) | (4 if self.stride != 1 else 0),
+                                               2.0 * N * Ho * Wo * self.Cout * self.Cin, e0, e1, (N, self.Cin, H, W, self.Cout, 1, self.stride),
+                                               4.0 * (N * C * Ho * Wo + N * self.Cout * Ho * Wo * (2 if res is not None else 1)) + 6.0 * self.Cout * self.Cin))
             return out
         kid0 = 0
         if self.wP is not None:
@@ -330,7 +334,8 @@ def bottleneck_tail_shape(plan2, plan3):
 
 def bottleneck_tail_eligible(plan2, plan3):
     """Can conv2 (3x3) + conv3 (1x1 expansion) of a Bottleneck run as one kernel (rfx_conv3x3_conv1x1_f32)?"""
-    return bottleneck_tail_shape(plan2, plan3) and os.environ.get("RFX_FUSE_BOTTLENECK", "1") != "0"
+    return (bottleneck_tail_shape(plan2, plan3) and os.environ.get("RFX_FUSE_BOTTLENECK", "1") != "0"
+            and getattr(plan2, "wS", None) is None and getattr(plan3, "wS", None) is None)        # split plans run as two kernels
 
 
 def bottleneck_tail(x, plan2, plan3, residual=None):

@@ -955,24 +955,27 @@ def test_fused_bottleneck_tail_equals_two_convs(dev, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 256, 1024, 20, 28, True, "relu"), (2, 1024, 256, 25, 33, False, "relu"), (1, 128, 64, 9, 11, False, "none"),
-                                   (2, 64, 200, 16, 16, True, "relu"), (1, 32, 24, 5, 5, False, "sigmoid"), (5, 512, 128, 30, 40, False, "relu")])
+                                   (2, 64, 200, 16, 16, True, "relu"), (1, 32, 24, 5, 5, False, "sigmoid"), (5, 512, 128, 30, 40, False, "relu"),
+                                   (3, 256, 512, 25, 33, False, "none", 2), (2, 512, 1024, 20, 28, False, "none", 2)])
 def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, shape):
     """rfx_conv1x1_split_f32 (csrc/conv1x1s.hip): float32 sums from the three exact bf16 pieces of both operands on the bf16 matrix
     cores.  Every product is exact, the accumulators round once per 16 k: against a float64 convolution its rms error is not larger
     than the fp32-MFMA kernel's (it is 0.45-0.7x), and both agree to float32 round-off.  Shapes: full / ragged pixel tiles, 64- and
     128-channel tiles, a Cout that fills neither, every activation, with and without residual."""
-    N, Cin, Cout, H, W, has_res, act = shape
+    N, Cin, Cout, H, W, has_res, act = shape[:7]
+    stride = shape[7] if len(shape) > 7 else 1            # 2: the projection shortcuts (rfx_conv1x1_split_strided_f32)
     g = torch.Generator().manual_seed(Cin * 7 + Cout)
     w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cout) ** 0.5
     bn = dict(weight=1.0 + 0.2 * (torch.rand(Cout, generator=g) - 0.5), bias=0.1 * torch.randn(Cout, generator=g),
               running_mean=0.1 * torch.randn(Cout, generator=g), running_var=1.0 + 0.4 * (torch.rand(Cout, generator=g) - 0.5))
     a = dict(relu=ops.ACT_RELU, none=ops.ACT_NONE, sigmoid=ops.ACT_SIGMOID)[act]
-    p32 = ops.ConvPlan(w, bn, 1, 0, a, dev)
-    psp = ops.ConvPlan(w, bn, 1, 0, a, dev, split=True)
+    p32 = ops.ConvPlan(w, bn, stride, 0, a, dev)
+    psp = ops.ConvPlan(w, bn, stride, 0, a, dev, split=True)
     assert psp.wS is not None and p32.wS is None
     x = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
-    res = torch.randn(N, Cout, H, W, generator=g).to(dev) if has_res else None
-    y64 = torch.einsum("mk,nkhw->nmhw", w.view(Cout, Cin).double().to(dev), x.double())
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(N, Cout, Ho, Wo, generator=g).to(dev) if has_res else None
+    y64 = torch.einsum("mk,nkhw->nmhw", w.view(Cout, Cin).double().to(dev), x[:, :, ::stride, ::stride].double())
     y64 = y64 * p32.scale.double().view(1, -1, 1, 1) + p32.shift.double().view(1, -1, 1, 1)
     if has_res:
         y64 = y64 + res.double()
@@ -989,6 +992,41 @@ def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, sh
     back = pc.view(Cin // 16, 3, 2, Mpad, 8).permute(1, 3, 0, 2, 4).reshape(3, Mpad, Cin).double().sum(0)[:Cout]
     assert torch.equal(back.float(), w.view(Cout, Cin))
     # grouped launches record the same kernel
+    with ops.launch_group(dev, False):
+        yg = psp(x, residual=res)
+    assert torch.equal(yg, ysp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 256, 256, 30, 40, False, "relu"), (2, 64, 64, 25, 33, True, "relu"), (1, 128, 128, 9, 11, True, "none"),
+                                   (2, 512, 256, 17, 19, False, "relu"), (1, 16, 24, 5, 7, False, "sigmoid"), (4, 256, 128, 8, 16, False, "relu")])
+def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
+    """rfx_conv3x3_split_f32 (csrc/conv3x3s.hip): the 3x3 / stride 1 / pad 1 convolution from exact bf16 operand pieces.  Against a
+    float64 convolution its rms error stays within 1.6x of the fp32 kernel's K-blocked sum (it is 0.4-1.0x up to K = 2304, 1.5x at
+    K = 4608) and far below the fp32 MFMA's single fma chain; borders (zero padding), images that straddle a workgroup's patch
+    (the batch is tiled as one tall map), ragged column tiles, 64- and 128-channel tiles, partial channel tiles, every activation."""
+    N, Cin, Cout, H, W, has_res, act = shape
+    g = torch.Generator().manual_seed(Cin * 5 + Cout + H)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+    bn = dict(weight=1.0 + 0.2 * (torch.rand(Cout, generator=g) - 0.5), bias=0.1 * torch.randn(Cout, generator=g),
+              running_mean=0.1 * torch.randn(Cout, generator=g), running_var=1.0 + 0.4 * (torch.rand(Cout, generator=g) - 0.5))
+    a = dict(relu=ops.ACT_RELU, none=ops.ACT_NONE, sigmoid=ops.ACT_SIGMOID)[act]
+    p32 = ops.ConvPlan(w, bn, 1, 1, a, dev)
+    psp = ops.ConvPlan(w, bn, 1, 1, a, dev, split=True)
+    assert psp.wS is not None and tuple(psp.wS.shape[:3]) == (Cin // 16, 9, 3)
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
+    res = torch.randn(N, Cout, H, W, generator=g).to(dev) if has_res else None
+    y64 = F.conv2d(x.double(), w.double().to(dev), padding=1)
+    y64 = y64 * p32.scale.double().view(1, -1, 1, 1) + p32.shift.double().view(1, -1, 1, 1)
+    if has_res:
+        y64 = y64 + res.double()
+    y64 = torch.relu(y64) if act == "relu" else (torch.sigmoid(y64) if act == "sigmoid" else y64)
+    y32, ysp = p32(x, residual=res), psp(x, residual=res)
+    rms = float(y64.pow(2).mean().sqrt())
+    e32 = float((y32.double() - y64).pow(2).mean().sqrt()) / rms
+    esp = float((ysp.double() - y64).pow(2).mean().sqrt()) / rms
+    assert esp <= 1.6 * e32 + 1e-9 and esp < 5e-7, (esp, e32)
+    assert float((ysp - y32).abs().max()) / rms < 3e-5
     with ops.launch_group(dev, False):
         yg = psp(x, residual=res)
     assert torch.equal(yg, ysp)
