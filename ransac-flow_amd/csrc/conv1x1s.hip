@@ -87,15 +87,11 @@ __device__ __forceinline__ void conv1x1_split_body(const C1SArgs& a, const unsig
         n0 = (long long)(bid / a.tilesM) * BN;
     }
     // staging roles.  A: words t + 256 j of the stage image [piece][h][BM] <- wS[kb][piece][h][m0 + m]
-    const u32x4* wsrc[NA];
-    bool a_on[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int idx = t + 256 * j;
-        a_on[j] = idx < A_WORDS;
-        const int ph = (a_on[j] ? idx : 0) / BM, m = (a_on[j] ? idx : 0) % BM;      // ph = piece * 2 + h
-        wsrc[j] = a.wS + (size_t)ph * a.Mpad + m0 + m;                             // + kb * 6 * Mpad
-    }
+    constexpr int A_ROWS = 256 / BM;                                                  // word t + 256 j sits A_ROWS * j [piece][h] rows below word t
+    const u32x4* wsrc = a.wS + (size_t)(t / BM) * a.Mpad + m0 + t % BM;              // + (kb * 6 + A_ROWS * j) * Mpad
+    // piece j exists for every thread (compile time) or for the first wavefronts only (TM = 1: 384 words): no per-lane branches around
+    // the loads -- a divergent region makes the compiler drain the vector-memory counter between two loads
+    auto a_on = [&](int j) { return (j + 1) * 256 <= A_WORDS || t + 256 * j < A_WORDS; };
     // B: thread = (h = t >> 7, pixel t & 127): rows k0 + 8 h .. + 7 of that pixel
     const int bh = t >> 7, bp = t & 127;
     const float* bsrc;
@@ -112,14 +108,14 @@ __device__ __forceinline__ void conv1x1_split_body(const C1SArgs& a, const unsig
     auto load_stage = [&](int kb) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            if (a_on[j]) ra[j] = wsrc[j][(size_t)kb * 6 * a.Mpad];
+            ra[j] = wsrc[((size_t)kb * 6 + (a_on(j) ? A_ROWS * j : 0)) * a.Mpad];              // off lanes: any valid word
 #pragma unroll
         for (int i = 0; i < 8; ++i) rb[i] = bsrc[(size_t)(kb * KB + i) * HWin];
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            if (a_on[j]) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
+            if (a_on(j)) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
         u32x4 hi, mid, lo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

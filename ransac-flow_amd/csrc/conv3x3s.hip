@@ -82,9 +82,9 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
     // 4 (TM = 1) [piece][h] rows: word t + 256 j sits (256 / BM) * j rows below word t
     constexpr int A_ROWS = 256 / BM;
     const u32x4* wsrc = a.wS + (size_t)(t / BM) * a.Mpad + m0 + t % BM;              // + q * 6 * Mpad + A_ROWS * j * Mpad
-    bool a_on[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) a_on[j] = t + 256 * j < A_WORDS;
+    // piece j of a thread exists for every thread (compile time) or for the first wavefronts only (TM = 1: 384 words): no per-lane
+    // branches around the loads -- a divergent region makes the compiler drain the vector-memory counter between two loads
+    auto a_on = [&](int j) { return (j + 1) * 256 <= A_WORDS || t + 256 * j < A_WORDS; };
     // B staging: item it = t (+ 256): h = it / 180, patch pixel it % 180 -> 8 channels of one input pixel (or zeros)
     const float* bsrc[2];
     bool b_ok[2], b_on[2];
@@ -106,16 +106,16 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
     auto load_a = [&](int q) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            if (a_on[j]) ra[j] = wsrc[((size_t)q * 6 + A_ROWS * j) * a.Mpad];
+            ra[j] = wsrc[((size_t)q * 6 + (a_on(j) ? A_ROWS * j : 0)) * a.Mpad];              // off lanes: any valid word
     };
     auto store_a = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            if (a_on[j]) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
+            if (a_on(j)) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
     };
     auto load_b = [&](int kb, int u) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = b_ok[u] ? bsrc[u][((size_t)kb * 16 + i) * HW] : 0.0f;
+        for (int i = 0; i < 8; ++i) rb[i] = bsrc[u][((size_t)kb * 16 + i) * HW];      // unconditional (pixels outside: image 0's, zeroed below)
     };
     auto store_b = [&](int buf, int u) {
         if (!b_on[u]) return;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned h_, m_, l_;
-            split_pair(rb[2 * i], rb[2 * i + 1], h_, m_, l_);
+            split_pair(b_ok[u] ? rb[2 * i] : 0.0f, b_ok[u] ? rb[2 * i + 1] : 0.0f, h_, m_, l_);
             hi[i] = h_; mid[i] = m_; lo[i] = l_;
         }
         u32x4* dst = &Bs[buf][0][0][0] + b_word[u];
@@ -189,21 +189,29 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
             }
             if (tap == 8 && kb + 2 < nk) load_b(kb + 2, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // hi / mid pieces first (four of the six products), then the lo pieces take the mid pieces' registers
+            // the twelve products that read the mid pieces first; then the lo pieces are fetched into the mid pieces' registers while the
+            // four hi * hi products run; then the lo products
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], low[i][j], 0, 0, 0);    // mid * mid
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], low[i][j], 0, 0, 0);    // mid * hi
-                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * mid
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);    // hi  * hi
                 }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi * mid
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * PP + b_base[j] + toff]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);    // hi * hi
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
