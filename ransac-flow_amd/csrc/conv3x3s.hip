@@ -25,7 +25,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PT_R = 8, PT_C = 16, PR = PT_R + 2, PC = PT_C + 2, PP = PR * PC;     // 8 x 16 outputs, 10 x 18 = 180 patch pixels
+// experiments (scripts/ubench/split_bench.py): RFX_C3S_PC = row stride of the LDS patch in pixels (>= 18)
+#ifndef RFX_C3S_PC
+#define RFX_C3S_PC 18
+#endif
+constexpr int PT_R = 8, PT_C = 16, PR = PT_R + 2, PC = RFX_C3S_PC, PP = PR * PC;    // 8 x 16 outputs, 10 x 18 = 180 patch pixels
 
 struct C3SArgs {
     const float* in; const u32x4* wS; const float* scale; const float* shift; const float* res; float* out;
@@ -94,10 +98,10 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
         const int it = t + 256 * u;
         b_on[u] = it < B_ITEMS;
         const int h = (b_on[u] ? it : 0) / PP, pp = (b_on[u] ? it : 0) % PP;
-        const int pr = pp / PC, pc = pp % PC;
+        const int pr = pp / PC, pc = pp % PC;            // pc >= 18 (padded strides): never read, staged as zeros
         const int sr = row0 - 1 + pr, x = col0 - 1 + pc;
         const int n = sr >= 0 ? sr / Hs : 0, y = sr >= 0 ? sr - n * Hs : 0;
-        b_ok[u] = b_on[u] && sr >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
+        b_ok[u] = b_on[u] && pc < PT_C + 2 && sr >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
         bsrc[u] = b_ok[u] ? a.in + ((size_t)n * a.Cin + 8 * h) * HW + (size_t)y * a.W + x : a.in;   // + kb * 16 * HW + i * HW
         b_word[u] = h * PP + pp;
     }

@@ -40,9 +40,10 @@ def main():
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--k", type=int, default=0, help="3 / 1: only the 3x3 / 1x1 shapes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    ap_k = [(3, sh) for sh in SHAPES3] + [(1, sh) for sh in SHAPES]
+    ap_k = [(k_, sh) for k_, sh in [(3, sh) for sh in SHAPES3] + [(1, sh) for sh in SHAPES] if a.k in (0, k_)]
     rows = []
     for ksz, (Cin, Cout, H, W, has_res) in ap_k:
         g = torch.Generator().manual_seed(Cin + Cout + H)
