@@ -25,11 +25,15 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// experiments (scripts/ubench/split_bench.py): RFX_C3S_PC = row stride of the LDS patch in pixels (>= 18)
-#ifndef RFX_C3S_PC
-#define RFX_C3S_PC 18
-#endif
-constexpr int PT_R = 8, PT_C = 16, PR = PT_R + 2, PC = RFX_C3S_PC, PP = PR * PC;    // 8 x 16 outputs, 10 x 18 = 180 patch pixels
+// Patch geometry.  WM = wavefronts along the channels: 2 -> 128 channels x (8 x 16) pixels per workgroup; 1 (Cout <= 64) -> 64 channels x
+// (16 x 16) pixels, the four wavefronts along the rows: every wavefront keeps 2 x 2 MFMA tiles (24 MFMAs per stage) and the weight image of
+// a stage is shared by twice the pixels (64 -> 64 at 240 x 320: 172 -> 185 TFLOP/s float32-equivalent).  LDS patch rows are PC pixels apart
+// (a stride of 20 / 22 / 24 changes nothing: measured).
+constexpr int PT_C = 16, PC = PT_C + 2;
+template <int WM> struct Geo {
+    static constexpr int BM = 64 * WM, WN = 4 / WM, PT_R = 4 * WN, PR = PT_R + 2, PP = PR * PC;     // PP: 180 / 324 patch pixels
+    static constexpr int B_ITEMS = 2 * PP, NBI = (B_ITEMS + 255) / 256;                               // staging items per thread: 2 / 3
+};
 
 struct C3SArgs {
     const float* in; const u32x4* wS; const float* scale; const float* shift; const float* res; float* out;
@@ -56,18 +60,19 @@ __device__ __forceinline__ bf16x8 as_frag(const u32x4& w) {
     return f;
 }
 
-template <int TM>
+template <int WM>
 __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsigned bx) {
-    constexpr int BM = 64 * TM;
+    using G = Geo<WM>;
+    constexpr int TM = 2;                               // MFMA tiles per wavefront along the channels (and 2 along the pixels)
+    constexpr int BM = G::BM, PT_R = G::PT_R, PP = G::PP, B_ITEMS = G::B_ITEMS, NBI = G::NBI;
     constexpr int A_WORDS = 3 * 2 * BM;                 // 16-byte words of a stage's weight image
     constexpr int NA = (A_WORDS + 255) / 256;
-    constexpr int B_ITEMS = 2 * PP;                     // (h, patch pixel) staging items: 360 -> threads 0..255 take one, 0..103 a second
     __shared__ u32x4 As[2][3][2][BM];
     __shared__ u32x4 Bs[2][3][2][PP];
     __shared__ float s_scale[BM], s_shift[BM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
     const int lrow = lane >> 5, lcol = lane & 31;
     const size_t HW = (size_t)a.H * a.W;
     const int nwg = a.tilesM * a.tilesW * a.tilesS;
@@ -90,18 +95,18 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
     // branches around the loads -- a divergent region makes the compiler drain the vector-memory counter between two loads
     auto a_on = [&](int j) { return (j + 1) * 256 <= A_WORDS || t + 256 * j < A_WORDS; };
     // B staging: item it = t (+ 256): h = it / 180, patch pixel it % 180 -> 8 channels of one input pixel (or zeros)
-    const float* bsrc[2];
-    bool b_ok[2], b_on[2];
-    int b_word[2];
+    const float* bsrc[NBI];
+    bool b_ok[NBI], b_on[NBI];
+    int b_word[NBI];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NBI; ++u) {
         const int it = t + 256 * u;
         b_on[u] = it < B_ITEMS;
         const int h = (b_on[u] ? it : 0) / PP, pp = (b_on[u] ? it : 0) % PP;
         const int pr = pp / PC, pc = pp % PC;            // pc >= 18 (padded strides): never read, staged as zeros
         const int sr = row0 - 1 + pr, x = col0 - 1 + pc;
         const int n = sr >= 0 ? sr / Hs : 0, y = sr >= 0 ? sr - n * Hs : 0;
-        b_ok[u] = b_on[u] && pc < PT_C + 2 && sr >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
+        b_ok[u] = b_on[u] && sr >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
         bsrc[u] = b_ok[u] ? a.in + ((size_t)n * a.Cin + 8 * h) * HW + (size_t)y * a.W + x : a.in;   // + kb * 16 * HW + i * HW
         b_word[u] = h * PP + pp;
     }
@@ -141,11 +146,9 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
         s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
     }
     load_a(0);
-    load_b(0, 0);
     store_a(0);
-    store_b(0, 0);
-    load_b(0, 1);
-    store_b(0, 1);
+#pragma unroll
+    for (int u = 0; u < NBI; ++u) { load_b(0, u); store_b(0, u); }
     load_a(1);
     if (nk > 1) load_b(1, 0);
     __syncthreads();
@@ -187,9 +190,15 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
             }
             if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
             if (q + 2 < nq) load_a(q + 2);
-            if (kb + 1 < nk) {
-                if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
-                if (tap == 7) store_b((kb + 1) & 1, 1);
+            if (kb + 1 < nk) {      // the items of a thread share the registers: store item u, request item u + 1 behind it
+                if (NBI == 2) {
+                    if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
+                    if (tap == 7) store_b((kb + 1) & 1, 1);
+                } else {
+                    if (tap == 2) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
+                    if (tap == 5) { store_b((kb + 1) & 1, 1); load_b(kb + 1, NBI - 1); }
+                    if (tap == 8) store_b((kb + 1) & 1, NBI - 1);
+                }
             }
             if (tap == 8 && kb + 2 < nk) load_b(kb + 2, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -268,7 +277,7 @@ int launch_split3(C3SArgs& a, hipStream_t st) {
     a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
     a.tilesW = (a.W + PT_C - 1) / PT_C;
     const long long rows = (long long)a.N * (a.H + 1) - 1;
-    a.tilesS = (int)((rows + PT_R - 1) / PT_R);
+    a.tilesS = (int)((rows + Geo<TM>::PT_R - 1) / Geo<TM>::PT_R);
     const long long nwg = (long long)a.tilesM * a.tilesW * a.tilesS;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
     if (rfx_group_recording()) return rfx_group_record(&c3s_group_launch<TM>, &a, sizeof(a), (unsigned)nwg);

@@ -129,7 +129,7 @@ class FeatureExtractorNet:
 
 class _HeadTrunk:
     def __init__(self, sd, last_act, device):
-        self.c1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), 1, 1, ACT_RELU, device)
+        self.c1 = ConvPlan(sd["conv1.weight"], _bn(sd, "bn1"), 1, 1, ACT_RELU, device, split=True)      # 49 -> 512 (a ragged 4th channel block),
         self.c2 = ConvPlan(sd["conv2.weight"], _bn(sd, "bn2"), 1, 1, ACT_RELU, device, split=True)      # 512 -> 256, 256 -> 128:
         self.c3 = ConvPlan(sd["conv3.weight"], _bn(sd, "bn3"), 1, 1, ACT_RELU, device, split=True)      # rfx_conv3x3_split_f32
         self.c4 = ConvPlan(sd["conv4.weight"], None, 1, 1, last_act, device)

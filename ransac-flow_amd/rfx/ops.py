@@ -173,8 +173,9 @@ def split_weights(w2d):
     [k / 16][piece][(k % 16) / 8][m (Mpad)][k % 8], as int16 bit patterns."""
     w = w2d.detach().float().cpu()
     Cout, Cin = w.shape
-    if Cin % 16:
-        raise ValueError("split_weights: Cin %% 16 != 0 (%d)" % Cin)
+    if Cin % 16:       # a ragged last block (rfx_conv3x3_split_f32 stages the missing channels as zeros): zero weights
+        w = torch.cat((w, torch.zeros(Cout, 16 - Cin % 16)), dim=1)
+        Cin = w.shape[1]
     hi = w.bfloat16()
     r1 = w - hi.float()
     mid = r1.bfloat16()
@@ -214,7 +215,7 @@ class ConvPlan:
                 and self.Cin % 16 == 0):
             self.wS = split_weights(w.reshape(self.Cout, K)).to(device or "cuda")
         elif (split and conv_split_enabled() and self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.dilation == 1
-                and self.Cin % 16 == 0):
+                and self.Cin >= 16):
             # rfx_conv3x3_split_f32's wS3: [c / 16][tap][piece][h][m][8]
             self.wS = torch.stack([split_weights(w[:, :, kh, kw]) for kh in range(3) for kw in range(3)], dim=1).contiguous().to(device or "cuda")
         if (self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1 and self.Cin >= 8
@@ -277,8 +278,15 @@ class ConvPlan:
             return out
         if self.wS is not None and self.KH == 3:
             e0 = Profiler.begin(x)
-            _call("rfx_conv3x3_split_f32", _one_device(x, res, self.wS), _p(x), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
-                  N, C, H, W, self.Cout, self.act if act is None else act)
+            xin, Cp = x, C
+            if C % 16:
+                # the 49-channel correlation volume: the kernel takes whole blocks of 16 channels -- the input goes into a zero-padded
+                # buffer (one device copy, 5 % of the layer's time; the padded weights are zero: split_weights)
+                Cp = (C + 15) // 16 * 16
+                xin = torch.zeros((N, Cp, H, W), dtype=torch.float32, device=x.device)
+                xin[:, :C].copy_(x)
+            _call("rfx_conv3x3_split_f32", _one_device(xin, res, self.wS), _p(xin), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
+                  N, Cp, H, W, self.Cout, self.act if act is None else act)
             if e0 is not None:
                 e1 = Profiler.end(e0)
                 Profiler.active().conv.append((KID_SPLIT_3X3 | (2 if self.Cout > 64 else 1), 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1,

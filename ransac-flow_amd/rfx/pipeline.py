@@ -713,7 +713,7 @@ class AlignPipeline:
         idx1, idx2, cnt = self._mutual_batched(feats, B)
         host_draw = sample_fn is not None or self.draw == "host"
         if split is None:
-            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (3 if B >= 12 else (2 if B >= 8 else 1))
+            split = int(os.environ.get("RFX_MULTIH_SPLIT", "0")) or (4 if B >= 32 else (3 if B >= 12 else (2 if B >= 8 else 1)))
         if host_draw or trace is not None or ops.Profiler.active() is not None and os.environ.get("RFX_MULTIH_SPLIT_PROFILED", "0") != "1":
             split = 1
         split = max(1, min(int(split), B))

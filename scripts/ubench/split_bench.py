@@ -15,7 +15,7 @@ from rfx.ops import ConvPlan, ACT_RELU  # noqa: E402
 
 SHAPES3 = [  # 3x3 / stride 1 / pad 1: (Cin, Cout, H, W, residual)
     (256, 256, 60, 80, False), (512, 256, 60, 80, False), (256, 128, 60, 80, False), (64, 64, 240, 320, True), (128, 128, 120, 160, True),
-    (256, 256, 30, 40, True), (256, 256, 50, 66, False), (256, 256, 25, 33, False), (64, 64, 200, 264, False),
+    (256, 256, 30, 40, True), (256, 256, 50, 66, False), (256, 256, 25, 33, False), (64, 64, 200, 264, False), (49, 512, 60, 80, False),
 ]
 SHAPES = [  # 1x1: (Cin, Cout, H, W, residual)
     (256, 1024, 60, 80, True), (1024, 256, 60, 80, False), (512, 128, 120, 160, False), (256, 64, 240, 320, False),

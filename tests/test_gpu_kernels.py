@@ -999,7 +999,8 @@ def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, sh
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 256, 256, 30, 40, False, "relu"), (2, 64, 64, 25, 33, True, "relu"), (1, 128, 128, 9, 11, True, "none"),
-                                   (2, 512, 256, 17, 19, False, "relu"), (1, 16, 24, 5, 7, False, "sigmoid"), (4, 256, 128, 8, 16, False, "relu")])
+                                   (2, 512, 256, 17, 19, False, "relu"), (1, 16, 24, 5, 7, False, "sigmoid"), (4, 256, 128, 8, 16, False, "relu"),
+                                   (3, 49, 512, 15, 20, False, "relu"), (2, 40, 64, 33, 17, True, "none")])
 def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
     """rfx_conv3x3_split_f32 (csrc/conv3x3s.hip): the 3x3 / stride 1 / pad 1 convolution from exact bf16 operand pieces.  Against a
     float64 convolution its rms error stays within 1.6x of the fp32 kernel's K-blocked sum (it is 0.4-1.0x up to K = 2304, 1.5x at
@@ -1013,7 +1014,7 @@ def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
     a = dict(relu=ops.ACT_RELU, none=ops.ACT_NONE, sigmoid=ops.ACT_SIGMOID)[act]
     p32 = ops.ConvPlan(w, bn, 1, 1, a, dev)
     psp = ops.ConvPlan(w, bn, 1, 1, a, dev, split=True)
-    assert psp.wS is not None and tuple(psp.wS.shape[:3]) == (Cin // 16, 9, 3)
+    assert psp.wS is not None and tuple(psp.wS.shape[:3]) == ((Cin + 15) // 16, 9, 3)        # a ragged last block: 49 / 40 channels
     x = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
     res = torch.randn(N, Cout, H, W, generator=g).to(dev) if has_res else None
     y64 = F.conv2d(x.double(), w.double().to(dev), padding=1)
