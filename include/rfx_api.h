@@ -522,6 +522,10 @@ int rfx_conv1x1_split_strided_f32(const float* in, const void* wS, const float* 
  * in (N,Cin,H,W), out / residual (N,Cout,H,W) float32.  NOT bit-identical to rfx_conv3x3_f32 / rfx_conv2d_f32 (closer to the exact sum). */
 int rfx_conv3x3_split_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
                           float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
+/* ... stride 2 (pad 1): ResNet-50 layer2.0 / layer3.0 conv2 (model/resnet50.py:75), the FeatureExtractor's strided conv1
+ * (model/model.py:32).  out (N,Cout,Ho,Wo), Ho = (H - 1) / 2 + 1; same wS3; Cin % 16 == 0; 128-channel tiles. */
+int rfx_conv3x3_split_s2_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
+                             float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sky segmentation forward pass: SegNet.getSky (segNet/segEval.py:23-43) = ResNet-50-dilated encoder

@@ -286,6 +286,211 @@ int launch_split3(C3SArgs& a, hipStream_t st) {
     return RFX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Stride 2 (ResNet-50 layer2.0 / layer3.0 conv2, model/resnet50.py:75 with stride; the FeatureExtractor's strided BasicBlock conv1,
+// model/model.py:32): out(y, x) = sum W[kh][kw] in(2y + kh - 1, 2x + kw - 1).  128 channels x 8 x 16 outputs per workgroup; the 17 x 33 input
+// patch of a 16-channel block is staged ONCE per block, its rows de-interleaved by column parity ([17 even | 16 odd]) so that the 16
+// lanes of an output row read consecutive words for every tap: word = row * 33 + (kw & 1) * 17 + x + (kw >> 1).  The patch (54 KB in split
+// form) does not double-buffer next to the weights: it is staged between two barriers at the start of a block (the frag registers are
+// free then: four staging items in flight per thread) while the CU's other workgroup computes.  Everything else -- weights per
+// (block, tap) stage through a double-buffered image, six products per tile and stage, two accumulators -- as the stride-1 kernel.
+// Rows: the batch is one tall map in OUTPUT rows (Ho + 1 per image, the last one virtual); input row of output stack row sr, tap kh:
+// 2 sr + kh - 1 in an input stack of 2 (Ho + 1) rows per image (rows >= H: zero = the padding / the virtual rows).
+constexpr int S2_PR = 2 * 8 + 1, S2_PC = 33, S2_PP = S2_PR * S2_PC;            // 17 x 33 = 561 patch pixels
+constexpr int S2_ITEMS = 2 * S2_PP, S2_NBI = (S2_ITEMS + 255) / 256;           // 1122 staging items: 5 per thread (the fifth: 98 threads)
+
+struct C3S2Args {
+    const float* in; const u32x4* wS; const float* scale; const float* shift; const float* res; float* out;
+    int N, Cin, H, W, Ho, Wo, Cout, act, Mpad;
+    int tilesM, tilesW, tilesS;
+};
+
+__device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const unsigned bx) {
+    constexpr int TM = 2, BM = 128;
+    constexpr int NA = 3;                               // 768 weight words per stage: 3 per thread
+    __shared__ u32x4 As[2][3][2][BM];
+    __shared__ u32x4 Bs[3][2][S2_PP];
+    __shared__ float s_scale[BM], s_shift[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+    const int nwg = a.tilesM * a.tilesW * a.tilesS;
+    const int nk = a.Cin / 16;
+    const int Hs = a.Ho + 1, Hin = 2 * Hs;              // output / input rows per image in the stacks
+
+    int m0, row0, col0;
+    {
+        const int v = (int)bx, q = nwg / 8, r = nwg % 8, xcd = v % 8, j = v / 8;
+        int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        m0 = (bid % a.tilesM) * BM; bid /= a.tilesM;
+        col0 = (bid % a.tilesW) * 16;
+        row0 = (bid / a.tilesW) * 8;
+    }
+    const u32x4* wsrc = a.wS + (size_t)(t / BM) * a.Mpad + m0 + t % BM;              // + (q * 6 + 2 j) * Mpad
+    const float* bsrc[S2_NBI];
+    bool b_ok[S2_NBI];
+    int b_word[S2_NBI];
+#pragma unroll
+    for (int u = 0; u < S2_NBI; ++u) {
+        const int it = t + 256 * u;
+        const bool on = it < S2_ITEMS;
+        const int h = (on ? it : 0) / S2_PP, pp = (on ? it : 0) % S2_PP;
+        const int pr = pp / S2_PC, pc = pp % S2_PC;
+        const int si = 2 * row0 - 1 + pr, x = 2 * col0 - 1 + pc;
+        const int n = si >= 0 ? si / Hin : 0, y = si >= 0 ? si - n * Hin : 0;
+        b_ok[u] = on && si >= 0 && n < a.N && y < a.H && x >= 0 && x < a.W;
+        bsrc[u] = b_ok[u] ? a.in + ((size_t)n * a.Cin + 8 * h) * HW + (size_t)y * a.W + x : a.in;
+        b_word[u] = on ? h * S2_PP + pr * S2_PC + (pc & 1) * 17 + (pc >> 1) : -1;
+    }
+    u32x4 ra[NA];
+    auto load_a = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) ra[j] = wsrc[((size_t)q * 6 + 2 * j) * a.Mpad];
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
+    };
+    auto stage_b = [&](int kb) {     // the whole patch of block kb: four items in flight, then the fifth
+        float rb[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rb[u][i] = bsrc[u][((size_t)kb * 16 + i) * HW];
+        auto put = [&](const float (&v)[8], int u) {
+            if (b_word[u] < 0) return;
+            u32x4 hi, mid, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned h_, m_, l_;
+                split_pair(b_ok[u] ? v[2 * i] : 0.0f, b_ok[u] ? v[2 * i + 1] : 0.0f, h_, m_, l_);
+                hi[i] = h_; mid[i] = m_; lo[i] = l_;
+            }
+            u32x4* dst = &Bs[0][0][0] + b_word[u];
+            dst[0] = hi;
+            dst[2 * S2_PP] = mid;
+            dst[4 * S2_PP] = lo;
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) put(rb[u], u);
+        float r4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r4[i] = bsrc[4][((size_t)kb * 16 + i) * HW];
+        put(r4, 4);
+    };
+    if (t < BM) {
+        const int m = m0 + t;
+        s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
+        s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
+    }
+    load_a(0);
+    store_a(0);
+    load_a(1);
+
+    f32x16 acc[TM][2], low[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.0f; low[i][j][r] = 0.0f; }
+
+    const int a_base = lrow * BM + wm * TM * 32 + lcol;
+    int b_base[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_base[j] = lrow * S2_PP + 2 * (4 * wn + 2 * j + (lcol >> 4)) * S2_PC + (lcol & 15);
+    const int nq = 9 * nk;
+    const u32x4* bimg = &Bs[0][0][0];
+
+    for (int kb = 0; kb < nk; ++kb) {
+        stage_b(kb);                                    // the last readers of the patch passed the barrier that closed block kb - 1
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int q = kb * 9 + tap;
+            const u32x4* aimg = &As[q & 1][0][0][0];
+            const int toff = (tap / 3) * S2_PC + (tap % 3 & 1) * 17 + (tap % 3 >> 1);
+            bf16x8 a0[TM], a1[TM], b0[2], b1[2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = as_frag(aimg[a_base + i * 32]);
+                a1[i] = as_frag(aimg[2 * BM + a_base + i * 32]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b0[j] = as_frag(bimg[b_base[j] + toff]);
+                b1[j] = as_frag(bimg[2 * S2_PP + b_base[j] + toff]);
+            }
+            if (q + 1 < nq) store_a((q + 1) & 1);
+            if (q + 2 < nq) load_a(q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], low[i][j], 0, 0, 0);    // mid * mid
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], low[i][j], 0, 0, 0);    // mid * hi
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi * mid
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * S2_PP + b_base[j] + toff]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);    // hi * hi
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b0[j], low[i][j], 0, 0, 0);    // lo  * hi
+                    low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += low[i][j][r];
+
+    size_t pix_off[2];
+    bool pix_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sr = row0 + 4 * wn + 2 * j + (lcol >> 4), x = col0 + (lcol & 15);
+        const int n = sr / Hs, y = sr - n * Hs;
+        pix_ok[j] = n < a.N && y < a.Ho && x < a.Wo;
+        pix_off[j] = pix_ok[j] ? (size_t)n * a.Cout * HWo + (size_t)y * a.Wo + x : 0;
+    }
+    conv_epilogue<TM, 2, false>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HWo, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_split_s2_kernel(C3S2Args a) {
+    conv3x3_split_s2_body(a, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_split_s2_group_kernel(RfxGroupArgs<C3S2Args> g) {
+    const unsigned y = blockIdx.y;
+    if (blockIdx.x >= g.gx[y]) return;
+    conv3x3_split_s2_body(g.p[y], blockIdx.x);
+}
+
+static int c3s2_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
+    return rfx_group_launch_impl<C3S2Args>(conv3x3_split_s2_group_kernel, 256, blob, gx, n, st);
+}
+
 }  // namespace
 
 extern "C" int rfx_conv3x3_split_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
@@ -298,4 +503,26 @@ extern "C" int rfx_conv3x3_split_f32(const float* in, const void* wS3, const flo
     a.in = in; a.wS = reinterpret_cast<const u32x4*>(wS3); a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
     a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.act = act; a.Mpad = (Cout + 127) / 128 * 128;
     return Cout > 64 ? launch_split3<2>(a, rfx_stream(stream)) : launch_split3<1>(a, rfx_stream(stream));
+}
+
+extern "C" int rfx_conv3x3_split_s2_f32(const float* in, const void* wS3, const float* scale, const float* shift, const float* residual,
+                                        float* out, int N, int Cin, int H, int W, int Cout, int act, void* stream) {
+    if (!in || !wS3 || !out || N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return RFX_E_ARG;
+    if (Cin % 16 != 0) return RFX_E_ARG;
+    if (act != RFX_ACT_NONE && act != RFX_ACT_RELU && act != RFX_ACT_SIGMOID) return RFX_E_ARG;
+    C3S2Args a;
+    a.in = in; a.wS = reinterpret_cast<const u32x4*>(wS3); a.scale = scale; a.shift = shift; a.res = residual; a.out = out;
+    a.N = N; a.Cin = Cin; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.Cout = Cout; a.act = act;
+    a.Mpad = (Cout + 127) / 128 * 128;
+    if ((long long)N * (a.Ho + 1) * 2 > 0x7fffffffLL) return RFX_E_LIMIT;
+    a.tilesM = (Cout + 127) / 128;
+    a.tilesW = (a.Wo + 15) / 16;
+    a.tilesS = (int)(((long long)N * (a.Ho + 1) - 1 + 7) / 8);
+    const long long nwg = (long long)a.tilesM * a.tilesW * a.tilesS;
+    if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
+    hipStream_t st = rfx_stream(stream);
+    if (rfx_group_recording()) return rfx_group_record(&c3s2_group_launch, &a, sizeof(a), (unsigned)nwg);
+    hipLaunchKernelGGL(conv3x3_split_s2_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
+    RFX_LAUNCH_CHECK();
+    return RFX_OK;
 }

@@ -23,6 +23,7 @@ SIGNATURES = {
     "rfx_conv2d_dilated_f32": (c_int, [c_void_p] * 7 + [c_int] * 11 + [c_void_p]),
     "rfx_conv1x1_split_f32": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     "rfx_conv3x3_split_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
+    "rfx_conv3x3_split_s2_f32": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p]),
     "rfx_conv1x1_split_strided_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "rfx_adaptive_avgpool2d_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "rfx_softmax_accum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_longlong, c_float, c_int, c_void_p]),

@@ -35,7 +35,7 @@ class ResNet50Trunk:
                 w1 = sd[p + ".conv1.weight"]
                 blk = {
                     "c1": ConvPlan(w1, _bn(sd, p + ".bn1"), 1, 0, ACT_RELU, device, split=w1.shape[1] >= 128),
-                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device),
+                    "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), s, 1, ACT_RELU, device, split=s == 2),   # stride 2: rfx_conv3x3_split_s2_f32
                     "c3": ConvPlan(sd[p + ".conv3.weight"], _bn(sd, p + ".bn3"), 1, 0, ACT_RELU, device),
                     "ds": None,
                 }
@@ -109,7 +109,7 @@ class FeatureExtractorNet:
                 s = stride if b == 0 else 1
                 blk = {
                     # the stride-1 3x3 convolutions (64 / 128 / 256 channels): rfx_conv3x3_split_f32 (round 6; csrc/conv3x3s.hip)
-                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), s, 1, ACT_RELU, device, split=s == 1),
+                    "c1": ConvPlan(sd[p + ".conv1.weight"], _bn(sd, p + ".bn1"), s, 1, ACT_RELU, device, split=True),      # stride 2: ..._split_s2_f32
                     "c2": ConvPlan(sd[p + ".conv2.weight"], _bn(sd, p + ".bn2"), 1, 1, ACT_RELU, device, split=True),
                     "ds": None, "stride": s,
                 }

@@ -214,8 +214,8 @@ class ConvPlan:
         if (split and conv_split_enabled() and self.KH == 1 and self.KW == 1 and stride in (1, 2) and pad == 0 and self.dilation == 1
                 and self.Cin % 16 == 0):
             self.wS = split_weights(w.reshape(self.Cout, K)).to(device or "cuda")
-        elif (split and conv_split_enabled() and self.KH == 3 and self.KW == 3 and stride == 1 and pad == 1 and self.dilation == 1
-                and self.Cin >= 16):
+        elif (split and conv_split_enabled() and self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1
+                and ((stride == 1 and self.Cin >= 16) or (stride == 2 and self.Cin % 16 == 0 and self.Cout >= 128))):
             # rfx_conv3x3_split_f32's wS3: [c / 16][tap][piece][h][m][8]
             self.wS = torch.stack([split_weights(w[:, :, kh, kw]) for kh in range(3) for kw in range(3)], dim=1).contiguous().to(device or "cuda")
         if (self.KH == 3 and self.KW == 3 and pad == 1 and self.dilation == 1 and self.Cin >= 8
@@ -285,13 +285,13 @@ class ConvPlan:
                 Cp = (C + 15) // 16 * 16
                 xin = torch.zeros((N, Cp, H, W), dtype=torch.float32, device=x.device)
                 xin[:, :C].copy_(x)
-            _call("rfx_conv3x3_split_f32", _one_device(xin, res, self.wS), _p(xin), _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out),
-                  N, Cp, H, W, self.Cout, self.act if act is None else act)
+            _call("rfx_conv3x3_split_f32" if self.stride == 1 else "rfx_conv3x3_split_s2_f32", _one_device(xin, res, self.wS), _p(xin),
+                  _p(self.wS), _p(self.scale), _p(self.shift), _p(res), _p(out), N, Cp, H, W, self.Cout, self.act if act is None else act)
             if e0 is not None:
                 e1 = Profiler.end(e0)
-                Profiler.active().conv.append((KID_SPLIT_3X3 | (2 if self.Cout > 64 else 1), 2.0 * N * H * W * self.Cout * self.Cin * 9, e0, e1,
-                                               (N, self.Cin, H, W, self.Cout, 3, 1),
-                                               4.0 * (N * C * H * W + N * self.Cout * H * W * (2 if res is not None else 1)) + 54.0 * self.Cout * self.Cin))
+                Profiler.active().conv.append((KID_SPLIT_3X3 | (2 if self.Cout > 64 else 1) | (4 if self.stride != 1 else 0),
+                                               2.0 * N * Ho * Wo * self.Cout * self.Cin * 9, e0, e1, (N, self.Cin, H, W, self.Cout, 3, self.stride),
+                                               4.0 * (N * C * H * W + N * self.Cout * Ho * Wo * (2 if res is not None else 1)) + 54.0 * self.Cout * self.Cin))
             return out
         if self.wS is not None:
             e0 = Profiler.begin(x)

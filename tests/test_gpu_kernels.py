@@ -1031,3 +1031,34 @@ def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
     with ops.launch_group(dev, False):
         yg = psp(x, residual=res)
     assert torch.equal(yg, ysp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 128, 128, 30, 40, "relu"), (2, 256, 256, 25, 33, "relu"), (2, 64, 128, 17, 19, "none"), (5, 128, 256, 8, 16, "relu"),
+                                   (1, 64, 200, 9, 7, "sigmoid")])
+def test_split_3x3_stride2_convolution_against_float64_and_the_fp32_kernel(dev, shape):
+    """rfx_conv3x3_split_s2_f32: the stride-2 form (parity-de-interleaved 17 x 33 patch, odd and even input sizes, images straddling a
+    workgroup's output rows, ragged column tiles, a Cout that does not fill its last channel tile)."""
+    N, Cin, Cout, H, W, act = shape
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + H)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+    bn = dict(weight=1.0 + 0.2 * (torch.rand(Cout, generator=g) - 0.5), bias=0.1 * torch.randn(Cout, generator=g),
+              running_mean=0.1 * torch.randn(Cout, generator=g), running_var=1.0 + 0.4 * (torch.rand(Cout, generator=g) - 0.5))
+    a = dict(relu=ops.ACT_RELU, none=ops.ACT_NONE, sigmoid=ops.ACT_SIGMOID)[act]
+    p32 = ops.ConvPlan(w, bn, 2, 1, a, dev)
+    psp = ops.ConvPlan(w, bn, 2, 1, a, dev, split=True)
+    assert psp.wS is not None
+    x = torch.relu(torch.randn(N, Cin, H, W, generator=g)).to(dev)
+    y64 = F.conv2d(x.double(), w.double().to(dev), stride=2, padding=1)
+    y64 = y64 * p32.scale.double().view(1, -1, 1, 1) + p32.shift.double().view(1, -1, 1, 1)
+    y64 = torch.relu(y64) if act == "relu" else (torch.sigmoid(y64) if act == "sigmoid" else y64)
+    y32, ysp = p32(x), psp(x)
+    assert ysp.shape == y64.shape
+    rms = float(y64.pow(2).mean().sqrt())
+    e32 = float((y32.double() - y64).pow(2).mean().sqrt()) / rms
+    esp = float((ysp.double() - y64).pow(2).mean().sqrt()) / rms
+    assert esp <= 1.6 * e32 + 1e-9 and esp < 5e-7, (esp, e32)
+    assert float((ysp - y32).abs().max()) / rms < 3e-5
+    with ops.launch_group(dev, False):
+        yg = psp(x)
+    assert torch.equal(yg, ysp)
