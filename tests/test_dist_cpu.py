@@ -180,7 +180,7 @@ def test_committed_profiles_carry_the_kernel_names_bench_prints():
         assert any(name in s for s in stats), (kid, name)
         assert any(p.startswith(name) for p in pmc), (kid, name)
         checked += 1
-    assert checked >= 8
-    assert roof["kernel"].replace(" ", "") == bench.kernel_name(16416).replace(" ", "")     # the chunked 128-channel direct 3x3 instance
+    assert checked >= 6
+    assert roof["kernel"].replace(" ", "") == bench.kernel_name(65538).replace(" ", "")     # the 128-channel split 3x3 instance (round 6)
     t, src = bench.pmc_traffic(roof["kernel"], "3")
     assert abs(t - roof["traffic"]) < 0.02 * t and src.endswith("r06_pmc_summary_config3.json")    # (the summary was re-taken once more after the line)
