@@ -17,6 +17,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "group.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,7 +61,12 @@ __device__ __forceinline__ bf16x8 as_frag(const u32x4& w) {
     return f;
 }
 
-template <int WM>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ADMA: the weight image of a stage goes global -> LDS by global_load_lds (no registers, no ds_write, and no wait for it in front of the
+// stage's MFMAs: the counted wait sits in front of the barrier that publishes the image).
+template <int WM, bool ADMA>
 __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsigned bx) {
     using G = Geo<WM>;
     constexpr int TM = 2;                               // MFMA tiles per wavefront along the channels (and 2 along the pixels)
@@ -71,7 +77,7 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
     __shared__ u32x4 Bs[2][3][2][PP];
     __shared__ float s_scale[BM], s_shift[BM];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = WM == 2 ? wave >> 1 : 0, wn = WM == 2 ? wave & 1 : wave;
     const int lrow = lane >> 5, lcol = lane & 31;
     const size_t HW = (size_t)a.H * a.W;
@@ -122,6 +128,13 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
         for (int j = 0; j < NA; ++j)
             if (a_on(j)) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
     };
+    auto dma_a = [&](int q, int buf) {                  // piece j of this wavefront: words 256 j + 64 wave .. + 63 of the stage image
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if ((j + 1) * 256 <= A_WORDS || wave < (A_WORDS - 256 * j) / 64)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ((size_t)q * 6 + A_ROWS * j) * a.Mpad),
+                                                 (lptr_t)(&As[buf][0][0][0] + 256 * j + 64 * wave), 16, 0, 0);
+    };
     auto load_b = [&](int kb, int u) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) rb[i] = bsrc[u][((size_t)kb * 16 + i) * HW];      // unconditional (pixels outside: image 0's, zeroed below)
@@ -145,11 +158,12 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
         s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
         s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
     }
-    load_a(0);
-    store_a(0);
+    if (ADMA) dma_a(0, 0);
+    else { load_a(0); store_a(0); }
 #pragma unroll
     for (int u = 0; u < NBI; ++u) { load_b(0, u); store_b(0, u); }
-    load_a(1);
+    if (ADMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else load_a(1);
     if (nk > 1) load_b(1, 0);
     __syncthreads();
 
@@ -188,19 +202,24 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
                 b0[j] = as_frag(bimg[b_base[j] + toff]);
                 b1[j] = as_frag(bimg[2 * PP + b_base[j] + toff]);
             }
-            if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
-            if (q + 2 < nq) load_a(q + 2);
+            if (ADMA) {
+                if (q + 1 < nq) dma_a(q + 1, (q + 1) & 1);  // its readers (stage q - 1) passed the last barrier
+            } else {
+                if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
+                if (q + 2 < nq) load_a(q + 2);
+            }
+            bool b_req = false;                             // did this stage request activations BEHIND its DMA? (they may stay in flight)
             if (kb + 1 < nk) {      // the items of a thread share the registers: store item u, request item u + 1 behind it
                 if (NBI == 2) {
-                    if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
+                    if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); b_req = true; }
                     if (tap == 7) store_b((kb + 1) & 1, 1);
                 } else {
-                    if (tap == 2) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); }
-                    if (tap == 5) { store_b((kb + 1) & 1, 1); load_b(kb + 1, NBI - 1); }
+                    if (tap == 2) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); b_req = true; }
+                    if (tap == 5) { store_b((kb + 1) & 1, 1); load_b(kb + 1, NBI - 1); b_req = true; }
                     if (tap == 8) store_b((kb + 1) & 1, NBI - 1);
                 }
             }
-            if (tap == 8 && kb + 2 < nk) load_b(kb + 2, 0);
+            if (tap == 8 && kb + 2 < nk) { load_b(kb + 2, 0); b_req = true; }
             __builtin_amdgcn_sched_barrier(0);
             // the twelve products that read the mid pieces first; then the lo pieces are fetched into the mid pieces' registers while the
             // four hi * hi products run; then the lo products
@@ -233,6 +252,10 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (ADMA) {     // the next stage's weight image has landed once at most this stage's 8 activation loads are in flight
+                if (b_req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();
         }
     }
@@ -255,35 +278,41 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
     conv_epilogue<TM, 2, false>(acc, s_scale, s_shift, a.res, a.out, a.act, a.Cout, HW, m0, wm, lrow, pix_off, pix_ok, m0 + BM <= a.Cout);
 }
 
-template <int TM>
+template <int TM, bool ADMA>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(C3SArgs a) {
-    conv3x3_split_body<TM>(a, blockIdx.x);
+    conv3x3_split_body<TM, ADMA>(a, blockIdx.x);
 }
 
-template <int TM>
+template <int TM, bool ADMA>
 __global__ __launch_bounds__(256, 2) void conv3x3_split_group_kernel(RfxGroupArgs<C3SArgs> g) {
     const unsigned y = blockIdx.y;
     if (blockIdx.x >= g.gx[y]) return;
-    conv3x3_split_body<TM>(g.p[y], blockIdx.x);
+    conv3x3_split_body<TM, ADMA>(g.p[y], blockIdx.x);
 }
 
-template <int TM>
+template <int TM, bool ADMA>
 static int c3s_group_launch(const void* blob, const unsigned* gx, int n, hipStream_t st) {
-    return rfx_group_launch_impl<C3SArgs>(conv3x3_split_group_kernel<TM>, 256, blob, gx, n, st);
+    return rfx_group_launch_impl<C3SArgs>(conv3x3_split_group_kernel<TM, ADMA>, 256, blob, gx, n, st);
 }
 
-template <int TM>
-int launch_split3(C3SArgs& a, hipStream_t st) {
+template <int TM, bool ADMA>
+int launch_split3_a(C3SArgs& a, hipStream_t st) {
     a.tilesM = (a.Cout + 64 * TM - 1) / (64 * TM);
     a.tilesW = (a.W + PT_C - 1) / PT_C;
     const long long rows = (long long)a.N * (a.H + 1) - 1;
     a.tilesS = (int)((rows + Geo<TM>::PT_R - 1) / Geo<TM>::PT_R);
     const long long nwg = (long long)a.tilesM * a.tilesW * a.tilesS;
     if (nwg > 0x7fffffffLL) return RFX_E_LIMIT;
-    if (rfx_group_recording()) return rfx_group_record(&c3s_group_launch<TM>, &a, sizeof(a), (unsigned)nwg);
-    hipLaunchKernelGGL((conv3x3_split_kernel<TM>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    if (rfx_group_recording()) return rfx_group_record(&c3s_group_launch<TM, ADMA>, &a, sizeof(a), (unsigned)nwg);
+    hipLaunchKernelGGL((conv3x3_split_kernel<TM, ADMA>), dim3((unsigned)nwg), dim3(256), 0, st, a);
     RFX_LAUNCH_CHECK();
     return RFX_OK;
+}
+
+template <int TM>
+int launch_split3(C3SArgs& a, hipStream_t st) {
+    static const bool adma = !(getenv("RFX_C3S_ADMA") && atoi(getenv("RFX_C3S_ADMA")) == 0);   // 0: weights through registers (A/B runs; +2-4 % with the DMA)
+    return adma ? launch_split3_a<TM, true>(a, st) : launch_split3_a<TM, false>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -312,7 +341,7 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
     __shared__ u32x4 Bs[3][2][S2_PP];
     __shared__ float s_scale[BM], s_shift[BM];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane >> 5, lcol = lane & 31;
     const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
@@ -344,14 +373,11 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
         bsrc[u] = b_ok[u] ? a.in + ((size_t)n * a.Cin + 8 * h) * HW + (size_t)y * a.W + x : a.in;
         b_word[u] = on ? h * S2_PP + pr * S2_PC + (pc & 1) * 17 + (pc >> 1) : -1;
     }
-    u32x4 ra[NA];
-    auto load_a = [&](int q) {
+    auto dma_a = [&](int q, int buf) {                  // the stage's weight image global -> LDS (global_load_lds): words 256 j + 64 wave .. + 63
 #pragma unroll
-        for (int j = 0; j < NA; ++j) ra[j] = wsrc[((size_t)q * 6 + 2 * j) * a.Mpad];
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j) (&As[buf][0][0][0])[t + 256 * j] = ra[j];
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + ((size_t)q * 6 + 2 * j) * a.Mpad), (lptr_t)(&As[buf][0][0][0] + 256 * j + 64 * wave),
+                                             16, 0, 0);
     };
     auto stage_b = [&](int kb) {     // the whole patch of block kb: four items in flight, then the fifth
         float rb[4][8];
@@ -385,9 +411,7 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
         s_scale[t] = (a.scale && m < a.Cout) ? a.scale[m] : 1.0f;
         s_shift[t] = (a.shift && m < a.Cout) ? a.shift[m] : 0.0f;
     }
-    load_a(0);
-    store_a(0);
-    load_a(1);
+    dma_a(0, 0);                                        // lands before the first block's staging barrier (vmcnt(0) below)
 
     f32x16 acc[TM][2], low[TM][2];
 #pragma unroll
@@ -406,6 +430,7 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
 
     for (int kb = 0; kb < nk; ++kb) {
         stage_b(kb);                                    // the last readers of the patch passed the barrier that closed block kb - 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -423,8 +448,7 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
                 b0[j] = as_frag(bimg[b_base[j] + toff]);
                 b1[j] = as_frag(bimg[2 * S2_PP + b_base[j] + toff]);
             }
-            if (q + 1 < nq) store_a((q + 1) & 1);
-            if (q + 2 < nq) load_a(q + 2);
+            if (q + 1 < nq) dma_a(q + 1, (q + 1) & 1);      // its readers (stage q - 1) passed the last barrier
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -455,6 +479,7 @@ __device__ __forceinline__ void conv3x3_split_s2_body(const C3S2Args& a, const u
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
                 }
             __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next stage's weight image has landed
             __syncthreads();
         }
     }
