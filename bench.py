@@ -491,7 +491,9 @@ def is_split(kid):
 def kernel_name(kid):
     tf = lambda b: "true" if b else "false"
     if kid & 65536:        # float32 3x3 on the bf16 matrix cores by exact operand splitting (conv3x3s.hip)
-        return "conv3x3_split_s2_kernel" if kid & 4 else "conv3x3_split_kernel<%d>" % (1 if kid & 1 else 2)
+        # <TM, true>: the weight images by LDS-DMA (the default; RFX_C3S_ADMA=0 runs <TM, false>)
+        return "conv3x3_split_s2_kernel" if kid & 4 else "conv3x3_split_kernel<%d, %s>" % (
+            1 if kid & 1 else 2, "false" if os.environ.get("RFX_C3S_ADMA", "1") == "0" else "true")
     if kid & 32768:        # ... 1x1 (conv1x1s.hip); 4: strided pixels (the projection shortcuts)
         return "conv1x1_split_kernel<%d>" % (1 if kid & 1 else 2)
     if kid & (32 | 512):   # direct 3x3 kernel; 512 = fused with the 1x1 expansion (Bottleneck tail); 16384 = chunked accumulation (KCH = 4)
