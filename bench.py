@@ -760,7 +760,7 @@ def main():
             "config": dict({k: v for k, v in meta.items() if k != "col"}, config=args.config, baseline_config=names.get(args.config, "dry run"),
                            pairs_per_step_per_gpu=B, weights="random-init",
                            arithmetic=("float32 in and out of every kernel; convolution sums: fp32 matrix cores (v_mfma_f32_32x32x2_f32) or, for the "
-                                       "long-K 1x1 and the stride-1 3x3 layers, float32 = hi + mid + lo bf16 pieces (exact) multiplied on the bf16 "
+                                       "long-K 1x1 and the 3x3 layers, float32 = hi + mid + lo bf16 pieces (exact) multiplied on the bf16 "
                                        "matrix cores (every product exact, float32 accumulators) -- error against float64 not larger than the "
                                        "fp32 kernels'; extra.fp32_mfma_only = the same workload with RFX_CONV_SPLIT=0"
                                        if os.environ.get("RFX_CONV_SPLIT", "1") != "0" else "float32, fp32 matrix cores only (RFX_CONV_SPLIT=0)"),
@@ -872,10 +872,17 @@ def main():
                                             "vs_value": round((B * af.steps / ef) / line["value"], 4),
                                             "aligned_ok_last_step": int((outf[:, col["status"]] == 0).sum().item()),
                                             "note": "RFX_CONV_SPLIT=0: the same workload with every convolution on the fp32 matrix-core kernels "
-                                                    "(v_mfma_f32_32x32x2_f32) of rounds 1-5; `value` runs the long-K 1x1 and the stride-1 3x3 layers "
-                                                    "on rfx_conv1x1_split_f32 / rfx_conv3x3_split_f32 (float32 results from exact bf16 operand pieces; "
+                                                    "(v_mfma_f32_32x32x2_f32) of rounds 1-5; `value` runs the long-K 1x1 layers, the stride-2 projections and "
+                                                    "every 3x3 layer on rfx_conv1x1_split_* / rfx_conv3x3_split_* (float32 results from exact bf16 operand pieces; "
                                                     "error against float64 not larger than the fp32 kernels': profiles/r06_split_conv_bench.json)"}
-                del stepf, extraf
+                # the fp32-MFMA build's own roofline (3 steps under the per-launch events): the kernel `roofline` named in rounds 3-5
+                ap = argparse.Namespace(**vars(af))
+                ap.steps, ap.warmup = 3, 0
+                ep, _, proff = timed_loop(stepf, ap, None, sync, ops.Profiler)
+                rf, _ = rooflines(proff, ep, rank, "3", dev)
+                extras["fp32_mfma_only"]["roofline"] = {k: rf[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                                         "time_share", "all_conv_tflops", "conv_time_share")}
+                del stepf, extraf, proff
                 torch.cuda.empty_cache()
             finally:
                 if prev is None:
