@@ -1,7 +1,8 @@
-// conv3x3s.hip -- 3x3 / stride 1 / pad 1 convolution (+ folded BatchNorm, residual, ReLU) with float32 results on the bf16 matrix
-// cores by EXACT operand splitting -- the scheme of conv1x1s.hip (read its header first) applied to the heaviest layer class of the
-// path: ResNet-50 layer3 conv2 (model/resnet50.py:75), every BasicBlock convolution of the FeatureExtractor (model/model.py:32-35),
-// conv2 / conv3 of the NetFlowCoarse / NetMatchability stacks (model/model.py:170-181).
+// conv3x3s.hip -- 3x3 / pad 1 convolutions, stride 1 and (second half of the file) stride 2 (+ folded BatchNorm, residual, ReLU) with
+// float32 results on the bf16 matrix cores by EXACT operand splitting -- the scheme of conv1x1s.hip (read its header first) applied to
+// the heaviest layer class of the path: ResNet-50 conv2 of every Bottleneck (model/resnet50.py:75), every BasicBlock convolution of the
+// FeatureExtractor (model/model.py:32-35), conv1 / conv2 / conv3 of the NetFlowCoarse / NetMatchability stacks (model/model.py:170-181;
+// the 49-channel conv1 through a zero-padded 64-channel copy of its input, rfx/ops.py).
 //
 //     out[m][p] = sum over taps (kh, kw) and channels c of  W[m][c][kh][kw] * in[c][p + (kh-1, kw-1)]
 // = nine shifted 1x1 GEMMs over ONE staged input patch.  A workgroup owns 64*TM output channels x an 8 x 16 pixel patch; per block of
@@ -9,7 +10,8 @@
 //     Bs[piece][h = channel half][patch pixel (180)][8 channels]        (16-byte words; zero outside the image = the padding)
 // so that the B fragment of tap (kh, kw) for output pixel (r, x) is the word at patch pixel (r + kh) * 18 + x + kw: one ds_read_b128
 // at a per-lane base + a compile-time tap offset.  The weights of a (channel block, tap) stage come split and packed from the host
-// (rfx_api.h: "wS3"), 12 KB per stage, LDS double buffered, one barrier per stage; a stage = 6 MFMAs per 32 x 32 tile (hi*hi in its
+// (rfx_api.h: "wS3"), 12 KB per stage, global -> LDS by global_load_lds into a double-buffered image (no staging registers; a counted
+// vmcnt in front of the stage's ONE barrier publishes it); a stage = 6 MFMAs per 32 x 32 tile (hi*hi in its
 // own accumulator, the five small terms in a second one: conv1x1s.hip).  k order: channel block, tap, 16 channels -- irrelevant for
 // the result's quality (every product exact, 16 products per rounding), different from the fp32 kernels' channel-major order.
 // The images of a batch are tiled as ONE tall map with a virtual zero row between images (as conv3x3.hip): only the last patch row
