@@ -108,6 +108,24 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the sustained clock under the six-product loop: s_memtime ticks of a wave around the loop / wall time of the launch (one workgroup of 4
+// waves per CU = one wave per SIMD, and four per SIMD), long launches
+template <int NT>
+__global__ __launch_bounds__(256) void clock_kernel(float* out, unsigned long long* ticks, int iters) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    bf16x8 p[3], q[3];
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 8; ++i) { p[j][i] = as_bf16(bf16_round((float)(threadIdx.x + i + j))); q[j][i] = as_bf16(bf16_round(1.0f + i * j)); }
+    f32x16 acc[4] = {};
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p[u % 3], q[u / 3 % 3], acc[u & 3], 0, 0, 0);
+    float s = 0.f;
+    for (int u = 0; u < 4; ++u) for (int r = 0; r < 16; ++r) s += acc[u][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 static double gauss() {
     double u = (rand() + 1.0) / (RAND_MAX + 2.0), v = (rand() + 1.0) / (RAND_MAX + 2.0);
     return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v);
@@ -174,6 +192,30 @@ int main() {
     run(rate_kernel<0>, "fp32_mfma_32x32x2 x8", 8, F); printf(",\n");
     run(rate_kernel<9>, "bf16x9", 9, F); printf(",\n");
     run(rate_kernel<6>, "bf16x6", 6, F); printf(",\n");
-    run(rate_kernel<3>, "bf16x3", 3, F); printf("\n]}\n");
+    run(rate_kernel<3>, "bf16x3", 3, F); printf("\n],\n\"clock\": [\n");
+    {
+        unsigned long long* ticks; hipMalloc(&ticks, 4096 * 8);
+        static unsigned long long host[4096];
+        for (int cfg = 0; cfg < 4; ++cfg) {
+            const int nt = cfg < 2 ? 6 : 8, wgs = (cfg & 1) ? 1024 : 256, it = 600000 / (wgs / 256);   // ~0.2-0.5 s per launch
+            hipEvent_t c0, c1; hipEventCreate(&c0); hipEventCreate(&c1);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(c0);
+                if (nt == 6) hipLaunchKernelGGL(clock_kernel<6>, dim3(wgs), dim3(256), 0, 0, dout, ticks, it);
+                else hipLaunchKernelGGL(clock_kernel<8>, dim3(wgs), dim3(256), 0, 0, dout, ticks, it);
+                hipEventRecord(c1); hipEventSynchronize(c1);
+            }
+            float ms; hipEventElapsedTime(&ms, c0, c1);
+            hipMemcpy(host, ticks, (size_t)wgs * 4 * 8, hipMemcpyDeviceToHost);
+            unsigned long long mx = 0;
+            for (int i = 0; i < wgs * 4; ++i) mx = host[i] > mx ? host[i] : mx;
+            const double mfma_per_simd = (double)it * nt * (wgs / 256);
+            printf(" {\"loop\": \"%d bf16 MFMAs per trip, 4 accumulators\", \"waves_per_simd\": %d, \"ms\": %.1f, \"bf16_TFLOPs\": %.0f, \"ticks_per_mfma\": %.1f, "
+                   "\"GHz_if_a_tick_is_a_shader_cycle\": %.3f, \"ns_per_mfma_per_simd\": %.2f}%s\n", nt, wgs / 256, ms,
+                   (double)it * nt * wgs * 4 * 32768.0 / ms / 1e9, (double)mx / ((double)it * nt), mx / (ms * 1e6), ms * 1e6 / mfma_per_simd, cfg == 3 ? "" : ",");
+        }
+        hipFree(ticks);
+    }
+    printf("]}\n");
     return 0;
 }
