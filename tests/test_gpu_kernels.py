@@ -957,11 +957,12 @@ def test_fused_bottleneck_tail_equals_two_convs(dev, case):
 @pytest.mark.parametrize("shape", [(3, 256, 1024, 20, 28, True, "relu"), (2, 1024, 256, 25, 33, False, "relu"), (1, 128, 64, 9, 11, False, "none"),
                                    (2, 64, 200, 16, 16, True, "relu"), (1, 32, 24, 5, 5, False, "sigmoid"), (5, 512, 128, 30, 40, False, "relu"),
                                    (3, 256, 512, 25, 33, False, "none", 2), (2, 512, 1024, 20, 28, False, "none", 2)])
-def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, shape):
+def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, shape, monkeypatch):
     """rfx_conv1x1_split_f32 (csrc/conv1x1s.hip): float32 sums from the three exact bf16 pieces of both operands on the bf16 matrix
     cores.  Every product is exact, the accumulators round once per 16 k: against a float64 convolution its rms error is not larger
     than the fp32-MFMA kernel's (it is 0.45-0.7x), and both agree to float32 round-off.  Shapes: full / ragged pixel tiles, 64- and
     128-channel tiles, a Cout that fills neither, every activation, with and without residual."""
+    monkeypatch.setenv("RFX_CONV_SPLIT", "1")            # the kernels under test, whatever the environment routes
     N, Cin, Cout, H, W, has_res, act = shape[:7]
     stride = shape[7] if len(shape) > 7 else 1            # 2: the projection shortcuts (rfx_conv1x1_split_strided_f32)
     g = torch.Generator().manual_seed(Cin * 7 + Cout)
@@ -1001,11 +1002,12 @@ def test_split_1x1_convolution_is_closer_to_float64_than_the_fp32_kernel(dev, sh
 @pytest.mark.parametrize("shape", [(3, 256, 256, 30, 40, False, "relu"), (2, 64, 64, 25, 33, True, "relu"), (1, 128, 128, 9, 11, True, "none"),
                                    (2, 512, 256, 17, 19, False, "relu"), (1, 16, 24, 5, 7, False, "sigmoid"), (4, 256, 128, 8, 16, False, "relu"),
                                    (3, 49, 512, 15, 20, False, "relu"), (2, 40, 64, 33, 17, True, "none")])
-def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
+def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape, monkeypatch):
     """rfx_conv3x3_split_f32 (csrc/conv3x3s.hip): the 3x3 / stride 1 / pad 1 convolution from exact bf16 operand pieces.  Against a
     float64 convolution its rms error stays within 1.6x of the fp32 kernel's K-blocked sum (it is 0.4-1.0x up to K = 2304, 1.5x at
     K = 4608) and far below the fp32 MFMA's single fma chain; borders (zero padding), images that straddle a workgroup's patch
     (the batch is tiled as one tall map), ragged column tiles, 64- and 128-channel tiles, partial channel tiles, every activation."""
+    monkeypatch.setenv("RFX_CONV_SPLIT", "1")            # the kernels under test, whatever the environment routes
     N, Cin, Cout, H, W, has_res, act = shape
     g = torch.Generator().manual_seed(Cin * 5 + Cout + H)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
@@ -1036,9 +1038,10 @@ def test_split_3x3_convolution_against_float64_and_the_fp32_kernel(dev, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(3, 128, 128, 30, 40, "relu"), (2, 256, 256, 25, 33, "relu"), (2, 64, 128, 17, 19, "none"), (5, 128, 256, 8, 16, "relu"),
                                    (1, 64, 200, 9, 7, "sigmoid")])
-def test_split_3x3_stride2_convolution_against_float64_and_the_fp32_kernel(dev, shape):
+def test_split_3x3_stride2_convolution_against_float64_and_the_fp32_kernel(dev, shape, monkeypatch):
     """rfx_conv3x3_split_s2_f32: the stride-2 form (parity-de-interleaved 17 x 33 patch, odd and even input sizes, images straddling a
     workgroup's output rows, ragged column tiles, a Cout that does not fill its last channel tile)."""
+    monkeypatch.setenv("RFX_CONV_SPLIT", "1")            # the kernels under test, whatever the environment routes
     N, Cin, Cout, H, W, act = shape
     g = torch.Generator().manual_seed(Cin * 3 + Cout + H)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
