@@ -210,18 +210,25 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
                 if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
                 if (q + 2 < nq) load_a(q + 2);
             }
-            bool b_req = false;                             // did this stage request activations BEHIND its DMA? (they may stay in flight)
-            if (kb + 1 < nk) {      // the items of a thread share the registers: store item u, request item u + 1 behind it
+            // the items of a thread share the registers: store item u here, request item u + 1 LATER in the stage (b_next / b_kb), behind the
+            // lo-piece fragment reads: the compiler drains the vector-memory counter in front of an LDS read that follows an LDS-DMA (it cannot
+            // tell the images apart: the ISA shows an s_waitcnt vmcnt(0) there), and a request issued before that point is drained with it
+            // (+2 %: 223.5 -> 225.4 on 256 -> 256 at 60 x 80).  Moving the DMA itself behind the stage's last LDS read and making the counted
+            // wait a builtin the compiler sees leaves ONE drain per stage, right in front of the barrier -- and measures 1.5 % slower (221.9).
+            int b_next = -1, b_kb = 0;
+            if (kb + 1 < nk) {
                 if (NBI == 2) {
-                    if (tap == 3) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); b_req = true; }
+                    if (tap == 3) { store_b((kb + 1) & 1, 0); b_next = 1; b_kb = kb + 1; }
                     if (tap == 7) store_b((kb + 1) & 1, 1);
                 } else {
-                    if (tap == 2) { store_b((kb + 1) & 1, 0); load_b(kb + 1, 1); b_req = true; }
-                    if (tap == 5) { store_b((kb + 1) & 1, 1); load_b(kb + 1, NBI - 1); b_req = true; }
+                    if (tap == 2) { store_b((kb + 1) & 1, 0); b_next = 1; b_kb = kb + 1; }
+                    if (tap == 5) { store_b((kb + 1) & 1, 1); b_next = NBI - 1; b_kb = kb + 1; }
                     if (tap == 8) store_b((kb + 1) & 1, NBI - 1);
                 }
             }
-            if (tap == 8 && kb + 2 < nk) { load_b(kb + 2, 0); b_req = true; }
+            if (tap == 8 && kb + 2 < nk) { b_next = 0; b_kb = kb + 2; }
+            const bool b_req = b_next >= 0;
+            if (!ADMA && b_req) { if (b_next == 0) load_b(b_kb, 0); else if (b_next == 1) load_b(b_kb, 1); else load_b(b_kb, NBI - 1); }
             __builtin_amdgcn_sched_barrier(0);
             // the twelve products that read the mid pieces first; then the lo pieces are fetched into the mid pieces' registers while the
             // four hi * hi products run; then the lo products
@@ -241,6 +248,11 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
             for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * PP + b_base[j] + toff]);
+            if (ADMA && b_req) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (b_next == 0) load_b(b_kb, 0); else if (b_next == 1) load_b(b_kb, 1); else load_b(b_kb, NBI - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
