@@ -68,6 +68,20 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ADMA: the weight image of a stage goes global -> LDS by global_load_lds (no registers, no ds_write, and no wait for it in front of the
 // stage's MFMAs: the counted wait sits in front of the barrier that publishes the image).
+// Fragment reads of the DMA instances are hand-written ds_read_b128 (as in corr.hip): in front of an LDS read it can see, the compiler
+// drains the vector-memory counter whenever an LDS-DMA is in flight (it cannot tell the weight image being written from the one being read) --
+// priced by removal, the weight DMA cost 18 % of the kernel that way (224.5 -> 265.5 TFLOP/s float32-equivalent without it).
+template <int OFF>
+__device__ __forceinline__ void lds_rd(u32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait8(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f, u32x4& g, u32x4& h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
 template <int WM, bool ADMA>
 __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsigned bx) {
     using G = Geo<WM>;
@@ -183,6 +197,7 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
 #pragma unroll
     for (int j = 0; j < 2; ++j) b_base[j] = lrow * PP + (4 * wn + 2 * j + (lcol >> 4)) * PC + (lcol & 15);
     const int nq = 9 * nk;
+    const unsigned as_lds = (unsigned)(uintptr_t)(lptr_t)&As[0][0][0][0], bs_lds = (unsigned)(uintptr_t)(lptr_t)&Bs[0][0][0][0];
 
     for (int kb = 0; kb < nk; ++kb) {
         const u32x4* bimg = &Bs[kb & 1][0][0][0];
@@ -194,19 +209,33 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
             // the next block's patch: item 0 was loaded at tap 8 of the block before (prologue: block 1), goes to LDS at tap 3; item 1
             // is loaded behind it and stored at tap 7; the buffer's last readers finished with block kb - 1
             bf16x8 a0[TM], a1[TM], b0[2], b1[2];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                a0[i] = as_frag(aimg[a_base + i * 32]);
-                a1[i] = as_frag(aimg[2 * BM + a_base + i * 32]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                b0[j] = as_frag(bimg[b_base[j] + toff]);
-                b1[j] = as_frag(bimg[2 * PP + b_base[j] + toff]);
-            }
-            if (ADMA) {
-                if (q + 1 < nq) dma_a(q + 1, (q + 1) & 1);  // its readers (stage q - 1) passed the last barrier
+            u32x4 ra0[2], ra1[2], rb0[2], rb1[2];           // ADMA: the raw fragment words (TM = 2)
+            unsigned a_addr = 0, b_addr[2] = {0, 0};
+            if constexpr (ADMA) {
+                static_assert(TM == 2, "hand-written fragment reads: two channel tiles per wavefront");
+                a_addr = as_lds + (unsigned)(((q & 1) * A_WORDS + a_base) * 16);
+                b_addr[0] = bs_lds + (unsigned)(((kb & 1) * 6 * PP + b_base[0] + toff) * 16);
+                b_addr[1] = bs_lds + (unsigned)(((kb & 1) * 6 * PP + b_base[1] + toff) * 16);
+                lds_rd<0>(ra0[0], a_addr); lds_rd<512>(ra0[1], a_addr);
+                lds_rd<2 * BM * 16>(ra1[0], a_addr); lds_rd<2 * BM * 16 + 512>(ra1[1], a_addr);
+                lds_rd<0>(rb0[0], b_addr[0]); lds_rd<0>(rb0[1], b_addr[1]);
+                lds_rd<2 * PP * 16>(rb1[0], b_addr[0]); lds_rd<2 * PP * 16>(rb1[1], b_addr[1]);
             } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    a0[i] = as_frag(aimg[a_base + i * 32]);
+                    a1[i] = as_frag(aimg[2 * BM + a_base + i * 32]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b0[j] = as_frag(bimg[b_base[j] + toff]);
+                    b1[j] = as_frag(bimg[2 * PP + b_base[j] + toff]);
+                }
+            }
+#ifndef RFX_C3S_DBG          // experiments only (WRONG RESULTS): 1 = no weight DMA in the loop, 2 = no activation requests in the loop
+#define RFX_C3S_DBG 0
+#endif
+            if (!ADMA) {
                 if (q + 1 < nq) store_a((q + 1) & 1);       // stage q+1's weights: registers -> the other buffer
                 if (q + 2 < nq) load_a(q + 2);
             }
@@ -228,8 +257,15 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
             }
             if (tap == 8 && kb + 2 < nk) { b_next = 0; b_kb = kb + 2; }
             const bool b_req = b_next >= 0;
+            // the DMA BEHIND the stage's ds_writes (store_b): the compiler drains the counter in front of an LDS write that follows an LDS-DMA
+            if (ADMA && q + 1 < nq && RFX_C3S_DBG != 1) dma_a(q + 1, (q + 1) & 1);      // its readers (stage q - 1) passed the last barrier
             if (!ADMA && b_req) { if (b_next == 0) load_b(b_kb, 0); else if (b_next == 1) load_b(b_kb, 1); else load_b(b_kb, NBI - 1); }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ADMA) {
+                lds_wait8(ra0[0], ra0[1], ra1[0], ra1[1], rb0[0], rb0[1], rb1[0], rb1[1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a0[i] = as_frag(ra0[i]); a1[i] = as_frag(ra1[i]); b0[i] = as_frag(rb0[i]); b1[i] = as_frag(rb1[i]); }
+            }
             // the twelve products that read the mid pieces first; then the lo pieces are fetched into the mid pieces' registers while the
             // four hi * hi products run; then the lo products
 #pragma unroll
@@ -244,11 +280,16 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
 #pragma unroll
                 for (int j = 0; j < 2; ++j) low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi * mid
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ADMA) {
+                lds_rd<4 * BM * 16>(ra1[0], a_addr); lds_rd<4 * BM * 16 + 512>(ra1[1], a_addr);
+                lds_rd<4 * PP * 16>(rb1[0], b_addr[0]); lds_rd<4 * PP * 16>(rb1[1], b_addr[1]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
+                for (int i = 0; i < TM; ++i) a1[i] = as_frag(aimg[4 * BM + a_base + i * 32]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * PP + b_base[j] + toff]);
-            if (ADMA && b_req) {
+                for (int j = 0; j < 2; ++j) b1[j] = as_frag(bimg[4 * PP + b_base[j] + toff]);
+            }
+            if (ADMA && b_req && RFX_C3S_DBG != 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (b_next == 0) load_b(b_kb, 0); else if (b_next == 1) load_b(b_kb, 1); else load_b(b_kb, NBI - 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -258,6 +299,11 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);    // hi * hi
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ADMA) {
+                lds_wait4(ra1[0], ra1[1], rb1[0], rb1[1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a1[i] = as_frag(ra1[i]); b1[i] = as_frag(rb1[i]); }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -266,11 +312,14 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (ADMA) {     // the next stage's weight image has landed once at most this stage's 8 activation loads are in flight
-                if (b_req) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ADMA) {     // the next stage's weight image has landed once at most this stage's 8 activation loads are in flight; the bare
+                            // barrier instead of __syncthreads(): its fence would drain the counter (and the activation requests with it)
+                if (b_req) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 #pragma unroll
