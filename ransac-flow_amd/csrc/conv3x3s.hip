@@ -10,7 +10,7 @@
 //     Bs[piece][h = channel half][patch pixel (180)][8 channels]        (16-byte words; zero outside the image = the padding)
 // so that the B fragment of tap (kh, kw) for output pixel (r, x) is the word at patch pixel (r + kh) * 18 + x + kw: one ds_read_b128
 // at a per-lane base + a compile-time tap offset.  The weights of a (channel block, tap) stage come split and packed from the host
-// (rfx_api.h: "wS3"), 12 KB per stage, global -> LDS by global_load_lds into a double-buffered image (no staging registers; a counted
+// (rfx_api.h: "wS3"), 12 KB per stage, global -> LDS by global_load_lds into a double-buffered image (no staging registers; an explicit
 // vmcnt in front of the stage's ONE barrier publishes it); a stage = 6 MFMAs per 32 x 32 tile (hi*hi in its
 // own accumulator, the five small terms in a second one: conv1x1s.hip).  k order: channel block, tap, 16 channels -- irrelevant for
 // the result's quality (every product exact, 16 products per rounding), different from the fp32 kernels' channel-major order.
@@ -67,7 +67,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ADMA: the weight image of a stage goes global -> LDS by global_load_lds (no registers, no ds_write, and no wait for it in front of the
-// stage's MFMAs: the counted wait sits in front of the barrier that publishes the image).
+// stage's MFMAs: the wait (vmcnt(0)) sits in front of the barrier that publishes the image).
 // Fragment reads of the DMA instances are hand-written ds_read_b128 (as in corr.hip): in front of an LDS read it can see, the compiler
 // drains the vector-memory counter whenever an LDS-DMA is in flight (it cannot tell the weight image being written from the one being read) --
 // priced by removal, the weight DMA cost 18 % of the kernel that way (224.5 -> 265.5 TFLOP/s float32-equivalent without it).
@@ -312,10 +312,11 @@ __device__ __forceinline__ void conv3x3_split_body(const C3SArgs& a, const unsig
                     low[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b1[j], low[i][j], 0, 0, 0);    // hi  * lo
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (ADMA) {     // the next stage's weight image has landed once at most this stage's 8 activation loads are in flight; the bare
-                            // barrier instead of __syncthreads(): its fence would drain the counter (and the activation requests with it)
-                if (b_req) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ADMA) {     // the next stage's weight image has landed; the bare barrier + explicit waits instead of __syncthreads()
+                // vmcnt(0) in EVERY stage, also the ones that requested activations behind the DMA: a counted vmcnt(8) would rely on the DMA
+                // completing before the eight younger register loads, and the compiler's own bookkeeping treats LDS-DMA and register loads as
+                // able to complete out of order (it forces 0 wherever both are pending); no result may depend on that (costs about 1 %)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             } else {
                 __syncthreads();
