@@ -9,6 +9,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """An unused TCP port from the kernel (a pid-derived port collided now and then with a socket of an earlier run still in TIME_WAIT)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "ransac-flow_amd"))
     import torch.distributed as dist
@@ -26,7 +34,7 @@ def _worker(rank, world, port, q):
     rec = rdist.pack_records(res)
     assert rec.shape == (len(mine), rdist.record_width(h8, w8))
     out = rdist.gather_records(rec, dist)
-    q.put((rank, out.clone()))
+    q.put((rank, out.clone().numpy()))          # by value: a tensor travels as a file descriptor the parent may ask for after this process has exited
     dist.barrier()
     dist.destroy_process_group()
 
@@ -35,11 +43,11 @@ def test_shard_and_single_gather_world2():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=120) for _ in range(world))
+    outs = {r: torch.from_numpy(o) for r, o in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -76,7 +84,7 @@ def _pipelined_worker(rank, world, port, q):
             got.append(prev.clone())
     got.append(pg.flush().clone())
     assert pg.flush() is None
-    q.put((rank, torch.stack(got)))
+    q.put((rank, torch.stack(got).numpy()))      # by value (see _worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,11 +96,11 @@ def test_pipelined_gather_returns_every_steps_block_one_step_late_world2():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=120) for _ in range(world))
+    outs = {r: torch.from_numpy(o) for r, o in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
